@@ -1,0 +1,405 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/ops.py header).
+
+Stand-alone NumPy restatement of the networks and of one training step, written directly from
+the reference's model files so that the topology is stated independently of the product's
+graph builder:
+
+  * ResNet (basic and bottleneck, v1.5)   — models/resnet_v1_5.py:9-203
+  * VGG-16/19 trunk (+ head at 224x224)   — models/vggnet.py:11-139
+  * loss                                  — convnet.py:528-601
+  * optimizer step, EMA, BN running stats — optimizers.py:89-177, 668-677; convnet.py:183-184,
+                                            1898-1914
+
+Variables are addressed by the reference's scope names, e.g. 'block_1/res_0/conv_1/weights',
+'block_1/res_0/conv_1/bn/gamma', 'block_None/logits/biases'.
+"""
+import numpy as np
+from . import ops
+
+
+class V(object):
+    """A value on the oracle's tape: array + accumulated gradient."""
+    __slots__ = ('a', 'g')
+
+    def __init__(self, a):
+        self.a = a
+        self.g = None
+
+    def acc(self, g):
+        self.g = g if self.g is None else self.g + g
+
+
+class Tape(object):
+    def __init__(self, params, train=True, bn_stats=None, eps=1e-3):
+        self.params = params          # name -> ndarray
+        self.pv = {}                  # name -> V (created on first use)
+        self.train = train
+        self.bn_stats = bn_stats      # name -> ndarray (mu / sigma), used when train=False
+        self.eps = eps
+        self.bw = []                  # backward closures
+        self.batch_stats = {}         # bn scope -> (batch_mean, batch_var_unbiased)
+        self.d = {}
+
+    def p(self, name):
+        if name not in self.pv:
+            self.pv[name] = V(self.params[name])
+        return self.pv[name]
+
+    # ---- ops ---------------------------------------------------------------------------
+    def conv(self, x, scope, stride, padding='SAME', dilation=1, biased=False):
+        w = self.p(scope + '/weights')
+        y = V(ops.conv2d_fwd(x.a, w.a, stride, padding, dilation))
+
+        def bw():
+            w.acc(ops.conv2d_wgrad(x.a, y.g, w.a.shape, stride, padding, dilation))
+            if x.g is not False:
+                x.acc(ops.conv2d_dgrad(y.g, w.a, x.a.shape, stride, padding, dilation))
+        self.bw.append(bw)
+        if biased:
+            b = self.p(scope + '/biases')
+            y2 = V(ops.bias_add_fwd(y.a, b.a))
+
+            def bwb():
+                b.acc(ops.bias_add_bwd(y2.g))
+                y.acc(y2.g)
+            # bias backward must run before conv backward -> append after (reverse order)
+            self.bw.append(bwb)
+            return y2
+        return y
+
+    def bn(self, x, scope):
+        gamma = self.p(scope + '/gamma')
+        beta = self.p(scope + '/beta')
+        if self.train:
+            ya, bm, bv, sm, si = ops.bn_fwd_train(x.a, gamma.a, beta.a, self.eps)
+            self.batch_stats[scope] = (bm, bv)
+            y = V(ya)
+
+            def bw():
+                dx, dg, db = ops.bn_bwd(y.g, x.a, gamma.a, sm, si)
+                x.acc(dx)
+                gamma.acc(dg)
+                beta.acc(db)
+            self.bw.append(bw)
+            return y
+        mu = self.bn_stats[scope + '/mu']
+        sigma = self.bn_stats[scope + '/sigma']
+        return V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps))
+
+    def relu(self, x):
+        y = V(ops.relu_fwd(x.a))
+        self.bw.append(lambda: x.acc(ops.relu_bwd(y.g, y.a)))
+        return y
+
+    def add(self, x, skip):
+        y = V(ops.add_fwd(x.a, skip.a))
+
+        def bw():
+            x.acc(y.g)
+            skip.acc(y.g)
+        self.bw.append(bw)
+        return y
+
+    def max_pool(self, x, k, s, padding='SAME'):
+        ya, arg = ops.maxpool_fwd(x.a, k, s, padding)
+        y = V(ya)
+        self.bw.append(lambda: x.acc(ops.maxpool_bwd(y.g, arg, x.a.shape, k, s, padding)))
+        return y
+
+    def avg_pool(self, x, k, s, padding='SAME'):
+        y = V(ops.avgpool_fwd(x.a, k, s, padding))
+        self.bw.append(lambda: x.acc(ops.avgpool_bwd(y.g, x.a.shape, k, s, padding)))
+        return y
+
+    def global_avgpool(self, x):
+        y = V(ops.global_avgpool_fwd(x.a))
+        self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g, x.a.shape)))
+        return y
+
+    def fc(self, x, scope):
+        w = self.p(scope + '/weights')
+        b = self.p(scope + '/biases')
+        y = V(ops.fc_fwd(x.a, w.a, b.a))
+
+        def bw():
+            dx, dw, db = ops.fc_bwd(y.g, x.a, w.a)
+            x.acc(dx)
+            w.acc(dw)
+            b.acc(db)
+        self.bw.append(bw)
+        return y
+
+    def backward(self):
+        for f in reversed(self.bw):
+            f()
+        return {name: v.g for name, v in self.pv.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet v1.5  (models/resnet_v1_5.py)
+# ------------------------------------------------------------------------------------------------
+class ResNetSpec(object):
+    def __init__(self, channels=(64, 256, 512, 1024, 2048), kernels=(7, 3, 3, 3, 3), strides=(2, 1, 2, 2, 2),
+                 res_units=(None, 3, 4, 6, 3), bottleneck=True, num_classes=1000, in_channels=3,
+                 backbone_only=False):
+        self.channels = list(channels)
+        self.kernels = list(kernels)
+        self.strides = list(strides)
+        self.res_units = list(res_units)
+        self.bottleneck = bottleneck
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+        self.backbone_only = backbone_only
+
+    @staticmethod
+    def resnet50(num_classes=1000, width_div=1):
+        return ResNetSpec(channels=[64 // width_div] + [c // width_div for c in (256, 512, 1024, 2048)],
+                          num_classes=num_classes)
+
+    @staticmethod
+    def resnet18(num_classes=1000, width_div=1):
+        return ResNetSpec(channels=[c // width_div for c in (64, 64, 128, 256, 512)],
+                          res_units=(None, 2, 2, 2, 2), bottleneck=False, num_classes=num_classes)
+
+    # -- variable inventory in creation order (the order tf.trainable_variables() would list) ------
+    def variables(self):
+        """[(name, shape, kind)], kind in {'weight','bias','gamma','gamma0','beta','mu','sigma'}."""
+        out = []
+
+        def conv(scope, k, cin, cout):
+            out.append((scope + '/weights', (k, k, cin, cout), 'weight'))
+
+        def bn(scope, c, zero=False):
+            out.append((scope + '/mu', (c,), 'mu'))
+            out.append((scope + '/sigma', (c,), 'sigma'))
+            out.append((scope + '/gamma', (c,), 'gamma0' if zero else 'gamma'))
+            out.append((scope + '/beta', (c,), 'beta'))
+
+        ch = self.channels
+        conv('block_0/conv_0', self.kernels[0], self.in_channels, ch[0])
+        bn('block_0/conv_0/bn', ch[0])
+        cin = ch[0]
+        for i in range(1, len(ch)):
+            for j in range(self.res_units[i]):
+                name = 'block_{}/res_{}'.format(i, j)
+                cout = ch[i]
+                if cin != cout:
+                    conv(name + '/conv_skip', 1, cin, cout)
+                    bn(name + '/conv_skip/bn', cout)
+                if self.bottleneck:
+                    conv(name + '/conv_0', 1, cin, cout // 4)
+                    bn(name + '/conv_0/bn', cout // 4)
+                    conv(name + '/conv_1', self.kernels[i], cout // 4, cout // 4)
+                    bn(name + '/conv_1/bn', cout // 4)
+                    conv(name + '/conv_2', 1, cout // 4, cout)
+                    bn(name + '/conv_2/bn', cout, zero=True)
+                else:
+                    conv(name + '/conv_0', self.kernels[i], cin, cout)
+                    bn(name + '/conv_0/bn', cout)
+                    conv(name + '/conv_1', 3, cout, cout)
+                    bn(name + '/conv_1/bn', cout)
+                cin = cout
+        if not self.backbone_only:
+            out.append(('block_None/logits/weights', (cin, self.num_classes), 'weight'))
+            out.append(('block_None/logits/biases', (self.num_classes,), 'bias'))
+        return out
+
+    def forward(self, t, x):
+        """x: V holding the prepared NHWC input.  Mirrors ResNet._build_model / _res_unit."""
+        d = t.d
+        ch = self.channels
+        h = t.conv(x, 'block_0/conv_0', self.strides[0])
+        d['block_0/conv_0'] = h
+        h = t.bn(h, 'block_0/conv_0/bn')
+        d['block_0/conv_0/bn'] = h
+        h = t.relu(h)
+        h = t.max_pool(h, 3, 2, 'SAME')
+        d['block_0'] = h
+        cin = ch[0]
+        for i in range(1, len(ch)):
+            for j in range(self.res_units[i]):
+                s = self.strides[i] if j == 0 else 1
+                name = 'block_{}/res_{}'.format(i, j)
+                cout = ch[i]
+                if cin == cout:
+                    skip = t.max_pool(h, s, s, 'VALID') if s > 1 else h
+                else:
+                    skip = t.conv(h, name + '/conv_skip', s)
+                    skip = t.bn(skip, name + '/conv_skip/bn')
+                if self.bottleneck:
+                    y = t.conv(h, name + '/conv_0', 1)
+                    y = t.relu(t.bn(y, name + '/conv_0/bn'))
+                    y = t.conv(y, name + '/conv_1', s)          # v1.5: stride on the 3x3
+                    d[name + '/conv_1'] = y
+                    y = t.relu(t.bn(y, name + '/conv_1/bn'))
+                    y = t.conv(y, name + '/conv_2', 1)
+                    y = t.bn(y, name + '/conv_2/bn')
+                else:
+                    y = t.conv(h, name + '/conv_0', s)
+                    y = t.relu(t.bn(y, name + '/conv_0/bn'))
+                    y = t.conv(y, name + '/conv_1', 1)
+                    y = t.bn(y, name + '/conv_1/bn')
+                h = t.relu(t.add(y, skip))
+                d[name] = h
+                cin = cout
+            d['block_{}'.format(i)] = h
+        if self.backbone_only:
+            return h
+        h = t.global_avgpool(h)
+        d['logits/avgpool'] = h
+        logits = t.fc(h, 'block_None/logits')
+        d['logits'] = logits
+        return logits
+
+
+# ------------------------------------------------------------------------------------------------
+# VGG  (models/vggnet.py)
+# ------------------------------------------------------------------------------------------------
+VGG_MEAN = np.array([123.68, 116.78, 103.94])
+
+
+class VGGSpec(object):
+    def __init__(self, num_layers=16, num_classes=10, backbone_only=True, width_div=1):
+        self.num_layers = num_layers
+        self.num_classes = num_classes
+        self.backbone_only = backbone_only
+        self.plan = [[64, 64], [128, 128], [256] * (3 if num_layers == 16 else 4),
+                     [512] * (3 if num_layers == 16 else 4), [512] * (3 if num_layers == 16 else 4)]
+        self.plan = [[c // width_div for c in blk] for blk in self.plan]
+
+    def variables(self):
+        out = []
+        cin = 3
+        for b, blk in enumerate(self.plan):
+            for j, c in enumerate(blk):
+                out.append(('block_{}/conv_{}/weights'.format(b, j), (3, 3, cin, c), 'weight'))
+                out.append(('block_{}/conv_{}/biases'.format(b, j), (c,), 'bias'))
+                cin = c
+        return out
+
+    def forward(self, t, x, image_mean=0.5, scale_factor=2.0):
+        """vggnet.py:23-25 re-scales the prepared input: (X/scale + mean)*255 - VGG_MEAN."""
+        d = t.d
+        xin = V(((x.a / scale_factor + image_mean) * 255.0 - VGG_MEAN.astype(x.a.dtype)).astype(x.a.dtype))
+        xin.g = False
+        h = xin
+        for b, blk in enumerate(self.plan):
+            for j, _ in enumerate(blk):
+                h = t.relu(t.conv(h, 'block_{}/conv_{}'.format(b, j), 1, 'SAME', biased=True))
+            h = t.max_pool(h, 2, 2, 'SAME')
+            d['block_{}'.format(b)] = h
+        return h
+
+
+# ------------------------------------------------------------------------------------------------
+# initialisation (deterministic stand-in; the TF RNG stream is not reproducible — SURVEY §8c (10))
+# ------------------------------------------------------------------------------------------------
+def init_variables(var_list, seed=0, dtype=np.float32):
+    """He-normal (truncated at 2 sigma, std = sqrt(2/fan_in)/0.8796) for weights; zeros for biases,
+    beta, mu; ones for gamma, sigma; zeros for zero_scale_init gammas (convnet.py:1382,1805-1854)."""
+    rng = np.random.default_rng(seed)
+    params, stats = {}, {}
+    for name, shape, kind in var_list:
+        if kind == 'weight':
+            fan_in = int(np.prod(shape[:-1]))
+            std = np.sqrt(2.0 / fan_in) / 0.87962566103423978
+            w = rng.standard_normal(shape)
+            bad = np.abs(w) > 2
+            while bad.any():
+                w[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(w) > 2
+            params[name] = (w * std).astype(dtype)
+        elif kind in ('bias', 'beta'):
+            params[name] = np.zeros(shape, dtype)
+        elif kind == 'gamma':
+            params[name] = np.ones(shape, dtype)
+        elif kind == 'gamma0':
+            params[name] = np.zeros(shape, dtype)
+        elif kind == 'mu':
+            stats[name] = np.zeros(shape, dtype)
+        elif kind == 'sigma':
+            stats[name] = np.ones(shape, dtype)
+    return params, stats
+
+
+# ------------------------------------------------------------------------------------------------
+# one training step  (Optimizer._step -> session.run of optimization_operation, optimizers.py:565-606)
+# ------------------------------------------------------------------------------------------------
+DEFAULT_HP = dict(image_mean=0.5, scale_factor=2.0, l2_reg=1e-4, momentum=0.9, base_learning_rate=0.1,
+                  moving_average_decay=0.99, batch_norm_decay=0.99, label_smoothing=0.0,
+                  base_weight_decay=0.0, loss_scaling_factor=1.0, eps=1e-3)
+
+
+class TrainState(object):
+    def __init__(self, params, stats):
+        self.params = {k: v.copy() for k, v in params.items()}
+        self.stats = {k: v.copy() for k, v in stats.items()}
+        self.accum = {k: np.zeros_like(v) for k, v in params.items()}
+        self.ema = {k: v.copy() for k, v in params.items()}          # shadow starts at the initial value
+        self.ema_stats = {k: v.copy() for k, v in stats.items()}
+        self.step = 0
+
+
+def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False):
+    hp = dict(DEFAULT_HP, **(hp or {}))
+    params = state.ema if use_ema else state.params
+    stats = state.ema_stats if use_ema else state.stats
+    t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'])
+    dt = next(iter(params.values())).dtype
+    x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']))
+    x.g = False
+    if isinstance(spec, VGGSpec):
+        out = spec.forward(t, x, hp['image_mean'], hp['scale_factor'])
+    else:
+        out = spec.forward(t, x)
+    if spec.backbone_only:
+        return t, out, None, None, None
+    onehot = ops.one_hot_labels(y_float, spec.num_classes, dtype=dt)
+    pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
+    weights = [v for k, v in params.items() if k.endswith('/weights')]
+    loss = float(sm_loss) + ops.l2_reg_loss(weights, hp['l2_reg'])
+    out.g = dlogits
+    return t, out, pred, loss, onehot
+
+
+def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=None,
+               tower_batches=None):
+    """One optimisation step.  `tower_batches` (list of (x,y)) restates the multi-tower path:
+    gradients averaged over towers (optimizers.py:125-142), BN running stats chained
+    (convnet.py:1899-1909), loss = mean of tower losses (convnet.py:510)."""
+    hp = dict(DEFAULT_HP, **(hp or {}))
+    towers = tower_batches if tower_batches is not None else [(x_raw, y_float)]
+    btot = batch_total if batch_total is not None else sum(len(t_[0]) for t_ in towers)
+    lr = hp['base_learning_rate'] * btot / 256.0 * lr_mult          # optimizers.py:46,57
+    grads_sum, losses, preds, bstats = None, [], [], []
+    for (xr, yf) in towers:
+        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True)
+        g = t.backward()
+        grads_sum = g if grads_sum is None else {k: grads_sum[k] + g[k] for k in g}
+        losses.append(loss)
+        preds.append(pred)
+        bstats.append(t.batch_stats)
+    ntow = len(towers)
+    grads = {k: v / ntow for k, v in grads_sum.items()}
+    d = ops.ema_decay(hp['moving_average_decay'], state.step)
+    m = hp['batch_norm_decay']
+    # EMA of running stats (pre-assign value), then the chained running-stat update
+    for scope in bstats[0]:
+        for nm, idx in (('/mu', 0), ('/sigma', 1)):
+            key = scope + nm
+            state.ema_stats[key] = d * state.ema_stats[key] + (1.0 - d) * state.stats[key]
+        mu, sg = ops.bn_running_update_chain(state.stats[scope + '/mu'], state.stats[scope + '/sigma'],
+                                             [b[scope][0] for b in bstats], [b[scope][1] for b in bstats], m)
+        state.stats[scope + '/mu'] = mu.astype(state.stats[scope + '/mu'].dtype)
+        state.stats[scope + '/sigma'] = sg.astype(state.stats[scope + '/sigma'].dtype)
+    wd = hp['base_weight_decay'] * btot / 256.0 * lr_mult
+    for k in state.params:
+        is_w = k.endswith('/weights')
+        w, a, e = ops.sgd_nesterov_step(state.params[k], grads[k], state.accum[k], lr, hp['momentum'],
+                                        l2=hp['l2_reg'] if is_w else 0.0, ema=state.ema[k], ema_d=d,
+                                        wd=wd if is_w else 0.0)
+        dt = state.params[k].dtype
+        state.params[k], state.accum[k], state.ema[k] = w.astype(dt), a.astype(dt), e.astype(dt)
+    state.step += 1
+    return float(np.mean(losses)), np.concatenate(preds, axis=0), grads

@@ -1,0 +1,415 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+
+CPU (NumPy) restatement of the arithmetic of MyConvNet's conv / batch-norm / ReLU / pooling /
+loss / momentum hot path.  The reference executes this arithmetic inside TensorFlow 1.14-1.15
+(third-party, pinned only as "tensorflow-gpu >= 1.14.0" in the reference README.md:57, not
+vendored under /root/reference and not installable here), so every function below restates the
+*documented TF-1.15 op semantics* at the reference's call site, which is cited per function.
+The reference ships no tests, golden vectors or fixtures for this path and
+TensorFlow cannot be imported in this environment (ordinary ModuleNotFoundError), therefore the
+oracle cannot be pinned against the real reference: "parity unpinned".  It is cross-checked
+against torch-CPU (tests/test_oracle_vs_torch.py), which is an independent implementation of
+the same published op definitions, not the oracle of record.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product path (myconvnet_amd) never imports it.
+
+Conventions: activations NHWC, conv filters HWIO (reference convnet.py:1655), all math in the
+dtype of the inputs (use float64 for tight checks, float32 for the timed CPU baseline).
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------
+# padding  (TF "SAME"/"VALID"; reference call sites convnet.py:1625-1628, 1493-1496)
+# --------------------------------------------------------------------------------------------
+def out_size(in_size, k, s, padding, d=1):
+    """TF output size.  SAME: ceil(in/s).  VALID: ceil((in - (k-1)*d)/s)."""
+    if padding.upper() == 'SAME':
+        return -(-in_size // s)
+    eff = (k - 1) * d + 1
+    return -(-(in_size - eff + 1) // s)
+
+
+def same_pads(in_size, k, s, d=1):
+    """TF SAME padding: total = max((out-1)*s + (k-1)*d + 1 - in, 0); before = total//2."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + (k - 1) * d + 1 - in_size, 0)
+    before = total // 2
+    return before, total - before
+
+
+def resolve_pads(h, w, kh, kw, sh, sw, padding, dh=1, dw=1):
+    if padding.upper() == 'SAME':
+        pt, pb = same_pads(h, kh, sh, dh)
+        pl, pr = same_pads(w, kw, sw, dw)
+    else:
+        pt = pb = pl = pr = 0
+    return pt, pb, pl, pr
+
+
+def _pair(v):
+    if isinstance(v, (list, tuple)):
+        return (v[0], v[0]) if len(v) == 1 else (v[0], v[1])
+    return (v, v)
+
+
+# --------------------------------------------------------------------------------------------
+# conv2d  (tf.nn.conv2d at convnet.py:1659; gradients via optimizer.compute_gradients,
+#          optimizers.py:106 -> Conv2DBackpropInput / Conv2DBackpropFilter)
+# --------------------------------------------------------------------------------------------
+def _tap_view(xp, r, s, oh, ow, sh, sw, dh, dw):
+    return xp[:, r * dh: r * dh + (oh - 1) * sh + 1: sh, s * dw: s * dw + (ow - 1) * sw + 1: sw, :]
+
+
+def conv2d_fwd(x, w, stride=1, padding='SAME', dilation=1):
+    """y[n,oy,ox,k] = sum_{r,s,c} x[n, oy*sh + r*dh - pt, ox*sw + s*dw - pl, c] * w[r,s,c,k]
+    (cross-correlation, zero padding)."""
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
+    n, h, wd, c = x.shape
+    kh, kw, c2, k = w.shape
+    assert c == c2
+    pt, pb, pl, pr = resolve_pads(h, wd, kh, kw, sh, sw, padding, dh, dw)
+    oh = out_size(h, kh, sh, padding, dh)
+    ow = out_size(wd, kw, sw, padding, dw)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    y = np.zeros((n, oh, ow, k), dtype=x.dtype)
+    for r in range(kh):
+        for s in range(kw):
+            v = _tap_view(xp, r, s, oh, ow, sh, sw, dh, dw)
+            y += (v.reshape(-1, c) @ w[r, s]).reshape(n, oh, ow, k)
+    return y
+
+
+def conv2d_dgrad(dy, w, x_shape, stride=1, padding='SAME', dilation=1):
+    """dx = d(sum(dy*y))/dx."""
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
+    n, h, wd, c = x_shape
+    kh, kw, _, k = w.shape
+    pt, pb, pl, pr = resolve_pads(h, wd, kh, kw, sh, sw, padding, dh, dw)
+    oh, ow = dy.shape[1:3]
+    dxp = np.zeros((n, h + pt + pb, wd + pl + pr, c), dtype=dy.dtype)
+    dy2 = dy.reshape(-1, k)
+    for r in range(kh):
+        for s in range(kw):
+            v = _tap_view(dxp, r, s, oh, ow, sh, sw, dh, dw)
+            v += (dy2 @ w[r, s].T).reshape(n, oh, ow, c)
+    return np.ascontiguousarray(dxp[:, pt:pt + h, pl:pl + wd, :])
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding='SAME', dilation=1):
+    """dw[r,s,c,k] = sum_{n,oy,ox} x[n, oy*sh + r*dh - pt, ox*sw + s*dw - pl, c] * dy[n,oy,ox,k]."""
+    sh, sw = _pair(stride)
+    dh, dw_ = _pair(dilation)
+    n, h, wd, c = x.shape
+    kh, kw, _, k = w_shape
+    pt, pb, pl, pr = resolve_pads(h, wd, kh, kw, sh, sw, padding, dh, dw_)
+    oh, ow = dy.shape[1:3]
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    dwt = np.zeros(w_shape, dtype=x.dtype)
+    dy2 = dy.reshape(-1, k)
+    for r in range(kh):
+        for s in range(kw):
+            v = _tap_view(xp, r, s, oh, ow, sh, sw, dh, dw_)
+            dwt[r, s] = v.reshape(-1, c).T @ dy2
+    return dwt
+
+
+def bias_add_fwd(x, b):
+    """tf.nn.bias_add (convnet.py:1694)."""
+    return x + b
+
+
+def bias_add_bwd(dy):
+    return dy.reshape(-1, dy.shape[-1]).sum(axis=0)
+
+
+# --------------------------------------------------------------------------------------------
+# batch norm  (tf.nn.fused_batch_norm, convnet.py:1883-1896; running stats convnet.py:1898-1914)
+# --------------------------------------------------------------------------------------------
+def bn_fwd_train(x, gamma, beta, eps=1e-3):
+    """Returns y, batch_mean, batch_var_unbiased, save_mean, save_invstd.
+    TF semantics: normalise with the *biased* batch variance, eps inside the sqrt; the returned
+    batch variance is Bessel-corrected (x n/max(n-1,1))."""
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c)
+    n = x2.shape[0]
+    mean = x2.mean(axis=0)
+    var = ((x2 - mean) ** 2).mean(axis=0)
+    invstd = 1.0 / np.sqrt(var + eps)
+    y = ((x2 - mean) * (invstd * gamma) + beta).reshape(x.shape)
+    var_unbiased = var * (n / max(n - 1, 1))
+    return y.astype(x.dtype), mean, var_unbiased, mean, invstd
+
+
+def bn_fwd_infer(x, gamma, beta, mean, var, eps=1e-3):
+    """fused_batch_norm(is_training=False) (convnet.py:1889-1896, 1916-1923)."""
+    invstd = 1.0 / np.sqrt(var + eps)
+    return ((x - mean) * (invstd * gamma) + beta).astype(x.dtype)
+
+
+def bn_bwd(dy, x, gamma, save_mean, save_invstd):
+    """FusedBatchNormGrad: gradient through the batch statistics."""
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c)
+    dy2 = dy.reshape(-1, c)
+    n = x2.shape[0]
+    xhat = (x2 - save_mean) * save_invstd
+    dbeta = dy2.sum(axis=0)
+    dgamma = (dy2 * xhat).sum(axis=0)
+    dx = (gamma * save_invstd) * (dy2 - dbeta / n - xhat * (dgamma / n))
+    return dx.reshape(x.shape).astype(x.dtype), dgamma, dbeta
+
+
+def bn_running_update(mu, sigma, batch_mean, batch_var_unbiased, momentum=0.99):
+    """convnet.py:1898-1901: mu <- m*mu + (1-m)*batch_mean (same for sigma = running variance)."""
+    r = 1.0 - momentum
+    return momentum * mu + r * batch_mean, momentum * sigma + r * batch_var_unbiased
+
+
+def bn_running_update_chain(mu, sigma, batch_means, batch_vars, momentum=0.99):
+    """Multi-tower chain of convnet.py:1899-1909: tower k's update starts from tower k-1's."""
+    for bm, bv in zip(batch_means, batch_vars):
+        mu, sigma = bn_running_update(mu, sigma, bm, bv, momentum)
+    return mu, sigma
+
+
+# --------------------------------------------------------------------------------------------
+# activations / residual  (convnet.py:2536-2537, 2500-2512)
+# --------------------------------------------------------------------------------------------
+def relu_fwd(x):
+    return np.maximum(x, 0)
+
+
+def relu_bwd(dy, y):
+    """ReluGrad: dy * [y > 0]."""
+    return dy * (y > 0)
+
+
+def add_fwd(x, skip):
+    """stochastic_depth with drop_rate == 0 (convnet.py:2511)."""
+    return x + skip
+
+
+# --------------------------------------------------------------------------------------------
+# pooling  (tf.nn.max_pool convnet.py:1509, tf.nn.avg_pool convnet.py:1548,
+#           tf.reduce_mean models/resnet_v1_5.py:73)
+# --------------------------------------------------------------------------------------------
+def maxpool_fwd(x, k, s, padding='SAME'):
+    """Padded cells never win.  Returns y and the window-local arg-max (r*kw + s_) of the FIRST
+    maximum in row-major window scan order (the TF-CPU / Eigen tie rule: strict '>' update)."""
+    kh, kw = _pair(k)
+    sh, sw = _pair(s)
+    n, h, w, c = x.shape
+    pt, pb, pl, pr = resolve_pads(h, w, kh, kw, sh, sw, padding)
+    oh = out_size(h, kh, sh, padding)
+    ow = out_size(w, kw, sw, padding)
+    neg = np.finfo(x.dtype).min if np.issubdtype(x.dtype, np.floating) else np.iinfo(x.dtype).min
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf)
+    y = np.full((n, oh, ow, c), -np.inf, dtype=x.dtype)
+    arg = np.zeros((n, oh, ow, c), dtype=np.int8)
+    for r in range(kh):
+        for s_ in range(kw):
+            v = _tap_view(xp, r, s_, oh, ow, sh, sw, 1, 1)
+            upd = v > y
+            y = np.where(upd, v, y)
+            arg = np.where(upd, np.int8(r * kw + s_), arg)
+    del neg
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, x_shape, k, s, padding='SAME'):
+    kh, kw = _pair(k)
+    sh, sw = _pair(s)
+    n, h, w, c = x_shape
+    pt, pb, pl, pr = resolve_pads(h, w, kh, kw, sh, sw, padding)
+    oh, ow = dy.shape[1:3]
+    dxp = np.zeros((n, h + pt + pb, w + pl + pr, c), dtype=dy.dtype)
+    for r in range(kh):
+        for s_ in range(kw):
+            v = _tap_view(dxp, r, s_, oh, ow, sh, sw, 1, 1)
+            v += dy * (arg == r * kw + s_)
+    return np.ascontiguousarray(dxp[:, pt:pt + h, pl:pl + w, :])
+
+
+def avgpool_fwd(x, k, s, padding='SAME'):
+    """SAME divides by the number of valid (un-padded) cells."""
+    kh, kw = _pair(k)
+    sh, sw = _pair(s)
+    n, h, w, c = x.shape
+    pt, pb, pl, pr = resolve_pads(h, w, kh, kw, sh, sw, padding)
+    oh = out_size(h, kh, sh, padding)
+    ow = out_size(w, kw, sw, padding)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    ones = np.pad(np.ones((1, h, w, 1), dtype=x.dtype), ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    y = np.zeros((n, oh, ow, c), dtype=x.dtype)
+    cnt = np.zeros((1, oh, ow, 1), dtype=x.dtype)
+    for r in range(kh):
+        for s_ in range(kw):
+            y += _tap_view(xp, r, s_, oh, ow, sh, sw, 1, 1)
+            cnt += _tap_view(ones, r, s_, oh, ow, sh, sw, 1, 1)
+    return y / cnt
+
+
+def avgpool_bwd(dy, x_shape, k, s, padding='SAME'):
+    kh, kw = _pair(k)
+    sh, sw = _pair(s)
+    n, h, w, c = x_shape
+    pt, pb, pl, pr = resolve_pads(h, w, kh, kw, sh, sw, padding)
+    oh, ow = dy.shape[1:3]
+    ones = np.pad(np.ones((1, h, w, 1), dtype=dy.dtype), ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    cnt = np.zeros((1, oh, ow, 1), dtype=dy.dtype)
+    for r in range(kh):
+        for s_ in range(kw):
+            cnt += _tap_view(ones, r, s_, oh, ow, sh, sw, 1, 1)
+    g = dy / cnt
+    dxp = np.zeros((n, h + pt + pb, w + pl + pr, c), dtype=dy.dtype)
+    for r in range(kh):
+        for s_ in range(kw):
+            v = _tap_view(dxp, r, s_, oh, ow, sh, sw, 1, 1)
+            v += g
+    return np.ascontiguousarray(dxp[:, pt:pt + h, pl:pl + w, :])
+
+
+def global_avgpool_fwd(x):
+    """tf.reduce_mean(x, axis=[1,2]) (models/resnet_v1_5.py:72-73)."""
+    return x.mean(axis=(1, 2))
+
+
+def global_avgpool_bwd(dy, x_shape):
+    n, h, w, c = x_shape
+    return np.broadcast_to((dy / (h * w))[:, None, None, :], x_shape).astype(dy.dtype).copy()
+
+
+# --------------------------------------------------------------------------------------------
+# fc  (tf.matmul(x, W) + b, convnet.py:1743)
+# --------------------------------------------------------------------------------------------
+def fc_fwd(x, w, b=None):
+    y = x @ w
+    return y if b is None else y + b
+
+
+def fc_bwd(dy, x, w):
+    return dy @ w.T, x.T @ dy, dy.sum(axis=0)
+
+
+# --------------------------------------------------------------------------------------------
+# input preparation and labels  (convnet.py:438-471)
+# --------------------------------------------------------------------------------------------
+def input_prep(x, image_mean=0.5, scale_factor=2.0):
+    """(X - image_mean) * scale_factor (convnet.py:452, 466); zero_pad/center_crop are no-ops at
+    equal size (convnet.py:714-726, 1137-1149)."""
+    return (x - x.dtype.type(image_mean)) * x.dtype.type(scale_factor)
+
+
+def one_hot_labels(y, num_classes, dtype=np.float32):
+    """convnet.py:441-449: NaN -> -1; cast int32; one_hot (out-of-range rows are all zero)."""
+    y = np.where(np.isnan(y), -1.0, y).astype(np.int32)
+    oh = np.zeros((y.shape[0], num_classes), dtype=dtype)
+    ok = (y >= 0) & (y < num_classes)
+    oh[np.nonzero(ok)[0], y[ok]] = 1
+    return oh
+
+
+# --------------------------------------------------------------------------------------------
+# loss  (convnet.py:528-607)
+# --------------------------------------------------------------------------------------------
+def softmax(logits):
+    z = logits - logits.max(axis=-1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0, loss_scale=1.0):
+    """pred = softmax(logits) (models/resnet_v1_5.py:78);
+    valid = |sum(Y) - 1| < 1e-5 (convnet.py:567-573); batch_w = sum(Y * w) (convnet.py:552);
+    labels = Y*(1-ls) + ls/C (convnet.py:603-607);
+    CE_i = -sum_c labels_ic * log_softmax_ic (softmax_cross_entropy_with_logits_v2, convnet.py:600);
+    softmax_loss = mean_i(batch_w_i * valid_i * CE_i) over ALL rows (convnet.py:594).
+    Returns pred, softmax_loss, per-sample CE, dlogits (= d(loss_scale*softmax_loss)/dlogits)."""
+    b, c = logits.shape
+    dt = logits.dtype
+    w = np.ones(c, dtype=dt) if class_weights is None else np.asarray(class_weights, dtype=dt)
+    bw = (onehot * w).sum(axis=-1)
+    sumy = onehot.sum(axis=-1)
+    valid = ((sumy > 1.0 - 1e-5) & (sumy < 1.0 + 1e-5)).astype(dt)
+    labels = onehot * (1.0 - label_smoothing) + label_smoothing / c if label_smoothing > 0 else onehot
+    z = logits - logits.max(axis=-1, keepdims=True)
+    lse = np.log(np.exp(z).sum(axis=-1, keepdims=True))
+    logsm = z - lse
+    pred = np.exp(logsm)
+    ce = -(labels * logsm).sum(axis=-1)
+    coef = bw * valid
+    loss = (coef * ce).mean()
+    dlogits = (pred * labels.sum(axis=-1, keepdims=True) - labels) * (coef * (loss_scale / b))[:, None]
+    return pred.astype(dt), dt.type(loss), ce.astype(dt), dlogits.astype(dt)
+
+
+def l2_reg_loss(weights, l2_factor=1e-4):
+    """l2_factor * sum_w tf.nn.l2_loss(w) = l2_factor * sum_w sum(w^2)/2 (convnet.py:560-563)."""
+    return l2_factor * sum(float((w.astype(np.float64) ** 2).sum()) / 2.0 for w in weights)
+
+
+# --------------------------------------------------------------------------------------------
+# optimizer  (optimizers.py:668-677 -> TF ApplyMomentum(use_nesterov=True); EMA convnet.py:183-184)
+# --------------------------------------------------------------------------------------------
+def ema_decay(decay, step):
+    """tf.train.ExponentialMovingAverage(decay, num_updates=step): min(decay, (1+t)/(10+t))."""
+    return min(decay, (1.0 + step) / (10.0 + step))
+
+
+def sgd_nesterov_step(w, g, accum, lr, momentum=0.9, l2=0.0, ema=None, ema_d=None, wd=0.0, grad_scale=1.0):
+    """One update of one tensor, in the reference's order:
+      1. EMA of the PRE-update value (update_ops are control dependencies of apply_gradients,
+         optimizers.py:159,175): ema <- d*ema + (1-d)*w
+      2. g_total = grad_scale*g + l2*w           (l2 term of the loss, convnet.py:563)
+      3. accum <- momentum*accum + g_total ; w <- w - lr*g_total - lr*momentum*accum
+      4. optional decoupled decay w <- w - wd*w  (optimizers.py:169)
+    Returns w, accum, ema."""
+    if ema is not None:
+        ema = ema_d * ema + (1.0 - ema_d) * w
+    gt = grad_scale * g + l2 * w
+    accum = momentum * accum + gt
+    w = w - lr * gt - lr * momentum * accum
+    if wd > 0.0:
+        w = w - wd * w
+    return w, accum, ema
+
+
+def lr_multiplier(curr_step, steps_per_epoch, num_epochs, warmup_epoch=1.0, decay_method=None,
+                  decay_params=(0.94, 2), curr_epoch=1):
+    """optimizers.py:608-632."""
+    warmup_steps = np.around(warmup_epoch * steps_per_epoch)
+    if curr_step < warmup_steps:
+        return (curr_step + 1) / warmup_steps
+    if decay_method is None:
+        return 1.0
+    m = decay_method.lower()
+    if m == 'step':
+        mult = 1.0
+        for n in range(len(decay_params) - 1):
+            mult *= np.power(decay_params[0], np.maximum(np.sign(curr_epoch - decay_params[n + 1]), 0.0))
+        return mult
+    if m == 'exponential':
+        return decay_params[0] ** ((curr_step - warmup_steps) / steps_per_epoch / decay_params[1])
+    total_steps = steps_per_epoch * num_epochs - warmup_steps
+    if m in ('poly', 'polynomial'):
+        power = decay_params[0] if isinstance(decay_params, (list, tuple)) else decay_params
+        return (1 - (curr_step - warmup_steps) / total_steps) ** power
+    anneal = decay_params[0] if isinstance(decay_params, (list, tuple)) else decay_params
+    anneal = 0 if anneal is None else int(anneal)
+    curr_prog = ((anneal + 1) * (curr_step - warmup_steps) / total_steps) % 1.0
+    return 0.5 * (1 + np.cos(curr_prog * np.pi))
+
+
+def accuracy_score(y_true_onehot, y_pred):
+    """evaluators.py:86-109 (classification case)."""
+    y_t = y_true_onehot.argmax(axis=-1)
+    valid = np.isclose(y_true_onehot.sum(axis=-1), 1)
+    y_p = y_pred.argmax(axis=-1)
+    right = np.equal(y_t, y_p) * valid
+    acc = np.where(valid, right, 1).astype(float)
+    return float(acc.mean())
