@@ -1,0 +1,198 @@
+/*
+ * mcn.h — C-ABI of libmcn_hip.so: the MI355X (gfx950 / CDNA4) implementation of MyConvNet's
+ * conv / batch-norm / ReLU / pooling / loss / momentum training hot path.
+ *
+ * The reference (dooyounggo/MyConvNet) is pure Python on TensorFlow 1.x and has no FFI of its
+ * own; its boundary for this path is the set of TensorFlow ops that convnet.py / optimizers.py
+ * call.  Each entry point below replaces exactly one of those call sites (cited as
+ * reference `file:line`) and is what a maintainer would bind from Python with ctypes
+ * (INTEGRATION.md shows the stub).  The ABI carries plain device pointers, integer sizes and
+ * a hipStream_t passed as void*; no torch / C++ types.
+ *
+ * Conventions
+ *   - activations NHWC (the reference's default layout, convnet.py:1619-1623; TF-1.x CPU conv
+ *     kernels accept only NHWC); MCN_NCHW is accepted by mcn_input_prep only.
+ *   - conv filters are the reference's fp32 master variables in HWIO order [KH][KW][Cin][Cout]
+ *     (convnet.py:1655); the library re-packs / casts them into caller-provided workspace on
+ *     every call, mirroring weight_variable()'s per-use cast (convnet.py:1421-1422).
+ *   - dtype = storage type of activations and activation gradients.  All accumulation,
+ *     batch-norm statistics, parameter gradients, loss and optimizer state are fp32.
+ *   - every function returns MCN_OK (0) or a negative status; the message is available from
+ *     mcn_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - the caller owns every buffer including workspaces; the library keeps no device memory and
+ *     no mutable global state, never synchronises the device, and orders work only by `stream`.
+ */
+#ifndef MCN_H_
+#define MCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCN_VERSION 100 /* 0.1.0 */
+
+typedef enum { MCN_F32 = 0, MCN_BF16 = 1, MCN_F16 = 2 /* reserved: MCN_E_UNSUPPORTED */ } mcn_dtype;
+typedef enum { MCN_NHWC = 0, MCN_NCHW = 1 } mcn_layout;
+typedef enum { MCN_OK = 0, MCN_E_BADARG = -1, MCN_E_UNSUPPORTED = -2, MCN_E_LAUNCH = -3, MCN_E_WORKSPACE = -4 } mcn_status;
+
+/* activation fused into a producer kernel */
+typedef enum { MCN_ACT_NONE = 0, MCN_ACT_RELU = 1 } mcn_act;
+
+int mcn_version(void);
+const char* mcn_last_error(void);
+
+/* ---- convolution ------------------------------------------------------------------------
+ * Geometry shared by the three conv entry points.  x:[N][H][W][x_cs] (x_cs = channel stride in
+ * elements, >= Cin; pass 0 for Cin), w:[KH][KW][Cin][Cout] fp32, y:[N][OH][OW][Cout] where
+ * OH/OW follow from the explicit pads: OH = (H + padT + padB - (KH-1)*DH - 1)/SH + 1.
+ * TF "SAME" pads are computed by the caller (asymmetric: before = total/2).           */
+typedef struct {
+    int32_t N, H, W, Cin, Cout;
+    int32_t KH, KW, SH, SW, DH, DW;
+    int32_t padT, padB, padL, padR;
+    int32_t x_cs; /* channel stride of x (0 => Cin).  Channels >= Cin must be finite (they meet zero weights) */
+} mcn_conv_geom;
+
+typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_conv_op;
+
+/* bytes of workspace the given op needs for this geometry/dtype (0 is a valid answer) */
+size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
+
+/* replaces tf.nn.conv2d (reference convnet.py:1659) [+ tf.nn.bias_add, convnet.py:1694, when
+ * bias != NULL]. */
+int mcn_conv2d_fwd(const void* x, const float* w_hwio, const float* bias, void* y, const mcn_conv_geom* g,
+                   mcn_dtype dtype, mcn_layout layout, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces Conv2DBackpropInput (autograd of convnet.py:1659 via optimizers.py:106).
+ * dx:[N][H][W][Cin] (dense, channel stride Cin).  accumulate != 0 => dx += result. */
+int mcn_conv2d_dgrad(const void* dy, const float* w_hwio, void* dx, const mcn_conv_geom* g, int accumulate,
+                     mcn_dtype dtype, mcn_layout layout, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces Conv2DBackpropFilter.  dw:[KH][KW][Cin][Cout] fp32 (overwritten; deterministic
+ * split-K through workspace slabs).  dbias (optional, fp32 [Cout]) = column sums of dy
+ * (BiasAddGrad). grad_scale multiplies both (loss un-scaling, optimizers.py:109-111). */
+int mcn_conv2d_wgrad(const void* x, const void* dy, float* dw_hwio, float* dbias, const mcn_conv_geom* g,
+                     float grad_scale, mcn_dtype dtype, mcn_layout layout, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ---- batch normalisation ----------------------------------------------------------------
+ * x,y:[M][C] (M = N*H*W).  replaces tf.nn.fused_batch_norm(is_training=True) and the running
+ * statistics update (reference convnet.py:1883-1888, 1898-1914):
+ *   mean = E[x], var = biased variance, y = act(gamma*(x-mean)/sqrt(var+eps) + beta [+ skip])
+ *   batch_mean = mean, batch_var = var * M/max(M-1,1)
+ *   if running_mean != NULL: running <- momentum*running + (1-momentum)*batch  (single tower)
+ * save_mean / save_invstd (fp32 [C]) are kept for the backward pass.  `skip` (same shape as y,
+ * may be NULL) is the residual branch of stochastic_depth(drop_rate=0) (convnet.py:2511) and
+ * `act` the following tf.nn.relu (convnet.py:2537), both fused.
+ * workspace: mcn_bn_workspace_bytes(M, C). */
+size_t mcn_bn_workspace_bytes(int64_t M, int32_t C);
+int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* skip, void* y,
+                     float* save_mean, float* save_invstd, float* batch_mean, float* batch_var,
+                     float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
+                     mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces tf.nn.fused_batch_norm(is_training=False) (convnet.py:1889-1896, 1916-1923) */
+int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
+                     const void* skip, void* y, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype,
+                     void* stream);
+
+/* replaces FusedBatchNormGrad [+ ReluGrad + the add's gradient fan-out].
+ * dy: gradient w.r.t. the (activated) output y.  If act == RELU the mask [y > 0] is applied
+ * first (y must then be the forward output).  dskip (may be NULL): receives the masked dy, i.e.
+ * the gradient of the residual branch.  dgamma/dbeta fp32 [C], multiplied by grad_scale. */
+int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+               const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale,
+               int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* per-channel affine y[m][c] = x[m][c]*scale[c] + shift[c] over [M][C] (the VGG input re-scaling,
+ * reference models/vggnet.py:25; also the apply pass of batch norm). scale/shift fp32 [C]. */
+int mcn_channel_affine(const void* x, const float* scale, const float* shift, void* y, int64_t M, int32_t C,
+                       mcn_dtype dtype, void* stream);
+
+/* ---- element-wise -----------------------------------------------------------------------
+ * tf.nn.relu / ReluGrad (convnet.py:2537); x + skip followed by relu (convnet.py:2511, 2537). */
+int mcn_relu_fwd(const void* x, void* y, int64_t n, mcn_dtype dtype, void* stream);
+int mcn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_dtype dtype, void* stream);
+int mcn_add_relu_fwd(const void* a, const void* b, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream);
+/* dx = dy * [y > 0] (written once; both branches of the add read it) */
+int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* stream);
+/* a += b (gradient accumulation at fan-out points) */
+int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void* stream);
+/* dtype conversion (tf.cast, convnet.py:469-471, 477-480) */
+int mcn_cast(const void* src, mcn_dtype src_dtype, void* dst, mcn_dtype dst_dtype, int64_t n, void* stream);
+
+/* input preparation (reference convnet.py:452-471): y = (x - image_mean) * scale_factor, cast to
+ * dtype, channels padded with zeros to out_cs (>= C), src layout NHWC or NCHW -> NHWC. x is fp32. */
+int mcn_input_prep(const float* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t out_cs,
+                   float image_mean, float scale_factor, mcn_layout src_layout, mcn_dtype dtype, void* stream);
+/* labels (fp32 class ids; NaN or out-of-range => all-zero row) -> one-hot fp32 [B][C] (convnet.py:441-449) */
+int mcn_one_hot(const float* labels, float* onehot, int32_t B, int32_t C, void* stream);
+
+/* ---- pooling -----------------------------------------------------------------------------
+ * tf.nn.max_pool (convnet.py:1509): padded cells never win; argmax (int8 window-local index of
+ * the first maximum in row-major window order) is stored for the backward pass. */
+int mcn_maxpool_fwd(const void* x, void* y, int8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH,
+                    int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW,
+                    mcn_dtype dtype, void* stream);
+int mcn_maxpool_bwd(const void* dy, const int8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                    int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH,
+                    int32_t OW, mcn_dtype dtype, void* stream);
+/* tf.nn.avg_pool (convnet.py:1548): SAME divides by the number of valid cells */
+int mcn_avgpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                    int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype,
+                    void* stream);
+int mcn_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                    int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype,
+                    void* stream);
+/* tf.reduce_mean(x, axis=[1,2]) (models/resnet_v1_5.py:72-73): [N][HW][C] -> [N][C] */
+int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream);
+int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream);
+
+/* ---- fully connected ----------------------------------------------------------------------
+ * tf.matmul(x, W) + b (convnet.py:1743): x:[B][In], w:[In][Out] fp32 master, y:[B][Out]. */
+size_t mcn_fc_workspace_bytes(int32_t B, int32_t In, int32_t Out, mcn_dtype dtype);
+int mcn_fc_fwd(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t In, int32_t Out,
+               mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+int mcn_fc_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias, float grad_scale,
+               int32_t B, int32_t In, int32_t Out, mcn_dtype dtype, void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* ---- loss ----------------------------------------------------------------------------------
+ * tf.nn.softmax (models/resnet_v1_5.py:78) + softmax_cross_entropy_with_logits_v2
+ * (convnet.py:600) + valid mask / class weights / label smoothing / mean over the batch
+ * (convnet.py:552-594).  logits fp32 [B][C]; labels fp32 [B][C] (one-hot or soft);
+ * class_w fp32 [C] or NULL.  Outputs: pred [B][C], ce [B] (per-sample cross-entropy),
+ * coef [B] (batch_weight*valid), dlogits [B][C] = loss_scale * d(mean(coef*ce))/dlogits,
+ * loss[1] = mean(coef*ce). */
+int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce,
+                             float* coef, float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing,
+                             float loss_scale, void* stream);
+/* l2_factor * sum tf.nn.l2_loss(w) over a flat range (convnet.py:560-563): out[0] += factor*sum(w^2)/2 */
+int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* workspace, size_t workspace_bytes,
+                void* stream);
+
+/* ---- optimizer -------------------------------------------------------------------------------
+ * tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True).apply_gradients (optimizers.py:676,
+ * 160, 176) fused with: gradient averaging scale (optimizers.py:138), the L2 term of the loss
+ * (convnet.py:563), ExponentialMovingAverage.apply on the PRE-update value (convnet.py:1401;
+ * control dependency optimizers.py:159,175) and the optional decoupled decay (optimizers.py:169):
+ *   ema <- d*ema + (1-d)*w                         (if ema != NULL)
+ *   g   <- grad_scale*g + l2*w
+ *   a   <- momentum*a + g ;  w <- w - lr*g - lr*momentum*a ;  w <- w - wd*w
+ * over n contiguous fp32 elements. */
+int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum,
+                           float l2, float wd, float ema_decay, float grad_scale, void* stream);
+/* shadow <- d*shadow + (1-d)*v (EMA of BN running statistics, convnet.py:1812,1826) */
+int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream);
+/* chained running-statistics update over `towers` ranks (convnet.py:1899-1909):
+ * running <- m*running + (1-m)*batch[k] for k = 0..towers-1; batch:[towers][n] */
+int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCN_H_ */

@@ -1,0 +1,11 @@
+"""myconvnet_amd — MI355X-native (gfx950) implementation of MyConvNet's conv / batch-norm / ReLU / pooling
+training hot path behind the reference's own Python surface.  See DESIGN.md and include/mcn.h."""
+from . import _ffi  # noqa: F401  (raises if libmcn_hip.so is missing: there is no CPU fallback)
+from .convnet import ConvNet, he_normal, ones, zeros  # noqa: F401
+from .dataset import DataSet, synthetic  # noqa: F401
+from .evaluators import AccuracyEvaluator  # noqa: F401
+from .optimizers import MomentumOptimizer, Optimizer  # noqa: F401
+from .resnet_v1_5 import ResNet18, ResNet34, ResNet50, ResNet101  # noqa: F401
+from .vggnet import VGG16, VGG19  # noqa: F401
+
+__version__ = '0.1.0'

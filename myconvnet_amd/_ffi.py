@@ -1,0 +1,95 @@
+"""ctypes binding of libmcn_hip.so (declared in include/mcn.h).
+
+The product path has no CPU fallback: if the shared library is missing, importing this module
+raises and every block method fails loudly.  Build with `python myconvnet_amd/build.py`.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmcn_hip.so')
+
+F32, BF16, F16 = 0, 1, 2
+NHWC, NCHW = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+OK, E_BADARG, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = 0, -1, -2, -3, -4
+
+
+class McnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('mcn error {}: {}'.format(code, msg))
+        self.code = code
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW', 'DH', 'DW',
+                                       'padT', 'padB', 'padL', 'padR', 'x_cs')]
+
+
+# name -> (restype, argtypes); every symbol include/mcn.h declares
+SIGNATURES = {
+    'mcn_version': (c_int, []),
+    'mcn_last_error': (c_char_p, []),
+    'mcn_conv2d_workspace_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
+    'mcn_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_bn_workspace_bytes': (c_size_t, [c_int64, c_int32]),
+    'mcn_bn_fwd_train': (c_int, [c_void_p] * 11 + [c_float, c_int64, c_int32, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_bn_fwd_infer': (c_int, [c_void_p] * 7 + [c_int64, c_int32, c_float, c_int, c_int, c_void_p]),
+    'mcn_bn_bwd': (c_int, [c_void_p] * 10 + [c_float, c_int64, c_int32, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_channel_affine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    'mcn_relu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'mcn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'mcn_add_relu_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mcn_add_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mcn_accumulate': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'mcn_cast': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    'mcn_input_prep': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int, c_int, c_void_p]),
+    'mcn_one_hot': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'mcn_maxpool_fwd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int32] * 12 + [c_int, c_void_p]),
+    'mcn_maxpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int32] * 12 + [c_int, c_void_p]),
+    'mcn_avgpool_fwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 12 + [c_int, c_void_p]),
+    'mcn_avgpool_bwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 12 + [c_int, c_void_p]),
+    'mcn_global_avgpool_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'mcn_global_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'mcn_fc_workspace_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int]),
+    'mcn_fc_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_fc_bwd': (c_int, [c_void_p] * 6 + [c_float, c_int32, c_int32, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_softmax_xent_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_float, c_float, c_void_p]),
+    'mcn_l2_loss': (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mcn_sgd_nesterov_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 6 + [c_void_p]),
+    'mcn_ema_update': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    'mcn_bn_running_chain': (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_void_p]),
+}
+
+
+def load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError('libmcn_hip.so not found at {} — the HIP extension is required (no CPU fallback); '
+                          'build it with `python myconvnet_amd/build.py`'.format(path))
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def last_error():
+    return lib.mcn_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != 0:
+        raise McnError(rc, last_error())
+
+
+def conv_geom(N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pads, x_cs=0):
+    pt, pb, pl, pr = pads
+    return ConvGeom(N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pt, pb, pl, pr, x_cs)

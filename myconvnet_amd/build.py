@@ -1,0 +1,60 @@
+"""Build recipe for libmcn_hip.so (gfx950 only).  hipcc cross-compiles without a GPU.
+
+    python myconvnet_amd/build.py [--force]     (run as a script: importing the package needs the built library)
+
+Objects are cached by mtime under myconvnet_amd/csrc/_obj; the shared library is written in-tree
+(myconvnet_amd/libmcn_hip.so) so that it travels with the repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(HERE, 'libmcn_hip.so')
+SOURCES = ['conv.hip', 'bn.hip', 'eltwise.hip', 'pool.hip', 'loss_optim.hip']
+HEADERS = ['common.h', 'conv_kernels.h', os.path.join('..', '..', 'include', 'mcn.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-Wno-unused-variable', '-ffp-contract=fast']
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = _newest([os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)])
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return cmd, r.returncode, r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for cmd, rc, out in ex.map(run, jobs):
+                if verbose and out.strip():
+                    print(out)
+                if rc != 0:
+                    raise RuntimeError('hipcc failed: {}\n{}'.format(' '.join(cmd), out))
+    if jobs or force or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd, rc, out = run(cmd)
+        if rc != 0:
+            raise RuntimeError('link failed: {}\n{}'.format(' '.join(cmd), out))
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

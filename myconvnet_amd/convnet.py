@@ -1,0 +1,586 @@
+"""ConvNet — host-side mirror of the reference's building-block surface (reference convnet.py:14-2577)
+for the conv / batch-norm / ReLU / pooling training path, executing on MI355X through libmcn_hip.
+
+Same constructor kwargs, hooks (`_init_params`, `_build_model` returning a dict with 'logits' and
+'pred') and block-method signatures as the reference, so a model file written against the
+reference's ConvNet needs only its `tf.*` calls swapped for the methods here.
+What differs by design: there is no TF session — `_build_model` records a static graph once, and
+`compile()` turns it into flat lists of HIP launches (graph.py / executor.py).
+
+Not built (raise NotImplementedError): depthwise conv, weight standardisation, group norms,
+augmentation, dropout rate > 0, transposed conv / upsampling (SURVEY.md §8f "next" rows).
+"""
+import math
+import os
+from abc import abstractmethod
+from contextlib import contextmanager, nullcontext
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .graph import FlatStore, Graph, Tensor, Variable, out_size, same_pads
+
+
+# ---- initializers (reference passes tf.initializers.* objects) -----------------------------------------
+def he_normal():
+    """tf.initializers.he_normal(): truncated normal (+-2 sigma), std = sqrt(2/fan_in)/0.87962566103423978."""
+    def init(shape, gen):
+        fan_in = int(np.prod(shape[:-1])) if len(shape) > 1 else int(shape[0])
+        std = math.sqrt(2.0 / max(fan_in, 1)) / 0.87962566103423978
+        t = torch.empty(shape, dtype=torch.float32)
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+        return t
+    return init
+
+
+def zeros():
+    return lambda shape, gen: torch.zeros(shape, dtype=torch.float32)
+
+
+def ones():
+    return lambda shape, gen: torch.ones(shape, dtype=torch.float32)
+
+
+def _pair(v):
+    if isinstance(v, (list, tuple)):
+        return [v[0], v[0]] if len(v) == 1 else [v[0], v[1]]
+    return [v, v]
+
+
+class ConvNet(object):
+    def __init__(self, input_shape, num_classes, loss_weights=None, session=None, model_scope=None,
+                 companion_networks=None, next_elements=None, backbone_only=False, auto_build=True, **kwargs):
+        """Arguments as reference convnet.py:15-28.  `session`, `next_elements` and `companion_networks` are TF
+        plumbing with no meaning here and are accepted and ignored."""
+        self._block_list = []
+        self.__dict__['_curr_block'] = None
+        self._custom_feed_dict = dict()
+        assert len(input_shape) == 3, 'input_size must contain 3D size'
+        self._input_size = list(input_shape)
+        self._num_classes = num_classes
+        self._loss_weights = loss_weights
+        self._model_scope = model_scope
+        self._backbone_only = backbone_only
+        self._parameters = kwargs
+
+        # reference: tf.float16 when half_precision (convnet.py:63); the MI355X build computes in bf16
+        self._dtype = 'bfloat16' if kwargs.get('half_precision', False) else 'float32'
+        self._channel_first = kwargs.get('channel_first', False)
+        self._argmax_output = kwargs.get('argmax_output', False)
+
+        self.rank = int(os.environ.get('RANK', 0))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', 0))
+        num_gpus = kwargs.get('num_gpus', None)
+        if num_gpus is None:
+            num_gpus = int(os.environ.get('WORLD_SIZE', 1))
+        # one process per GPU replaces the reference's in-graph towers (convnet.py:431-436)
+        self.world_size = max(int(num_gpus), 1)
+        self._num_devices = self.world_size
+        self._compute_device = 'gpu'
+        self._device_offset = 0
+        dev = kwargs.get('device', None)
+        if dev is None:
+            dev = 'cuda:{}'.format(self.local_rank) if torch.cuda.is_available() else 'cpu'
+        self.device = torch.device(dev)
+
+        total_batch = int(kwargs.get('batch_size', 16))            # reference default, dataset.py:101
+        assert total_batch % self.world_size == 0, 'batch_size must be divisible by the number of GPUs'
+        self.batch_size = total_batch
+        self.device_batch = total_batch // self.world_size          # dataset.py:113
+
+        self._dropout_weights = kwargs.get('dropout_weights', False)
+        self._dropout_features = kwargs.get('dropout_features', True)
+        self._blocks_to_train = kwargs.get('blocks_to_train', None)
+        self._update_batch_norm = kwargs.get('update_batch_norm', None)
+        self._moving_average_decay = kwargs.get('moving_average_momentum', kwargs.get('moving_average_decay', 0.99))
+        self._batch_norm_decay = kwargs.get('batch_norm_momentum', kwargs.get('batch_norm_decay', 0.99))
+
+        self._flops = 0
+        self._params = 0
+        self._nodes = 0
+        self._conv_macs = 0
+        self._layer_info = []
+        self._scope = []
+        self._collections = {}
+        self.variables = {}             # name -> Variable (trainables and BN statistics)
+        self._var_order = []
+        self.graph = None
+        self.compiled = False
+        self.seed = int(kwargs.get('seed', 0))
+        self.fuse = bool(kwargs.get('fuse', True))
+        if auto_build:
+            self.build()
+
+    # ---- properties the reference exposes ------------------------------------------------------------------
+    name = 'ConvNet'
+    input_size = property(lambda self: self._input_size)
+    num_classes = property(lambda self: self._num_classes)
+    loss_weights = property(lambda self: self._loss_weights)
+    model_scope = property(lambda self: self._model_scope)
+    backbone_only = property(lambda self: self._backbone_only)
+    dtype = property(lambda self: self._dtype)
+    channel_first = property(lambda self: self._channel_first)
+    argmax_output = property(lambda self: self._argmax_output)
+    num_devices = property(lambda self: self._num_devices)
+    compute_device = property(lambda self: self._compute_device)
+    device_offset = property(lambda self: self._device_offset)
+    dropout_weights = property(lambda self: self._dropout_weights)
+    dropout_features = property(lambda self: self._dropout_features)
+    blocks_to_train = property(lambda self: self._blocks_to_train)
+    update_batch_norm = property(lambda self: self._update_batch_norm)
+    moving_average_decay = property(lambda self: self._moving_average_decay)
+    batch_norm_decay = property(lambda self: self._batch_norm_decay)
+    block_list = property(lambda self: self._block_list)
+    num_blocks = property(lambda self: len(self._block_list))
+    flops = property(lambda self: self._flops)
+    params = property(lambda self: self._params)
+    nodes = property(lambda self: self._nodes)
+    conv_macs = property(lambda self: self._conv_macs)
+    layer_info = property(lambda self: self._layer_info)
+    custom_feed_dict = property(lambda self: self._custom_feed_dict)
+
+    def __setattr__(self, key, value):
+        if key == '_curr_block':                       # convnet.py:239-244
+            self.__dict__[key] = value
+            if value not in self._block_list:
+                self._block_list.append(value)
+        else:
+            super(ConvNet, self).__setattr__(key, value)
+
+    # ---- scopes / collections / variables -----------------------------------------------------------------------
+    @contextmanager
+    def variable_scope(self, name):
+        """Stand-in for tf.variable_scope: nests names as 'block_1/res_0/conv_0/...'."""
+        self._scope.append(str(name))
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def scope_name(self, leaf=None):
+        parts = list(self._scope) + ([leaf] if leaf else [])
+        return '/'.join(parts)
+
+    def add_to_collection(self, key, value):
+        self._collections.setdefault(key, []).append(value)
+
+    def get_collection(self, key):
+        return list(self._collections.get(key, []))
+
+    def _trainable_here(self):
+        return self._blocks_to_train is None or self._curr_block in self._blocks_to_train
+
+    def _new_variable(self, name, shape, kind, init, trainable):
+        full = self.scope_name(name)
+        if full in self.variables:
+            raise ValueError('variable {} already exists'.format(full))
+        if not isinstance(shape, (list, tuple)):
+            shape = [shape]
+        v = Variable(full, shape, kind, trainable, init, self._curr_block)
+        self.variables[full] = v
+        self._var_order.append(v)
+        self.add_to_collection('block_{}/variables'.format(self._curr_block), v)
+        return v
+
+    def weight_variable(self, shape, initializer=None, weight_standardization=False, paddings=((0, 0), (0, 0)), name='weights'):
+        """reference convnet.py:1382-1431 (fp32 master on the parameter device, EMA shadow, per-use cast)."""
+        if weight_standardization:
+            raise NotImplementedError('weight standardisation is outside the built path')
+        if any(p > 0 for pp in paddings for p in pp):
+            raise NotImplementedError('kernel_paddings are outside the built path')
+        if self._dropout_weights and self._parameters.get('dropout_rate', 0.0) > 0.0:
+            raise NotImplementedError('weight dropout is outside the built path')
+        v = self._new_variable(name, shape, 'weight', initializer or he_normal(), self._trainable_here())
+        self.add_to_collection('weight_variables', v)
+        self.add_to_collection('block_{}/weight_variables'.format(self._curr_block), v)
+        return v
+
+    def bias_variable(self, shape, initializer=None, name='biases'):
+        """reference convnet.py:1433-1462."""
+        v = self._new_variable(name, shape, 'bias', initializer or zeros(), self._trainable_here())
+        self.add_to_collection('bias_variables', v)
+        self.add_to_collection('block_{}/bias_variables'.format(self._curr_block), v)
+        return v
+
+    # ---- build -------------------------------------------------------------------------------------------------------
+    def build(self):
+        """reference convnet.py:134-237 (conditions, global step, EMA, _init_params, _init_model, report)."""
+        kwargs = self._parameters
+        self.global_step = 0
+        self.is_train = True
+        self.dropout_rate = kwargs.get('dropout_rate', 0.0)
+        self.dropout_rate_weights = self.dropout_rate if self._dropout_weights else 0.0
+        self.dropout_rate_features = self.dropout_rate if self._dropout_features else 0.0
+        self.image_mean = kwargs.get('image_mean', 0.5) if kwargs.get('zero_center', True) else 0.0
+        self.scale_factor = kwargs.get('scale_factor', 2.0)
+        self.graph = Graph(self.device, self._dtype)
+        with self.variable_scope(self._model_scope) if self._model_scope is not None else nullcontext():
+            self._init_params(**kwargs)
+            self._init_model(**kwargs)
+        self._flops, self._params, self._nodes = int(self._flops), int(self._params), int(self._nodes)
+        for blk in list(self._block_list):
+            if not self.get_collection('block_{}/variables'.format(blk)):
+                self._block_list.remove(blk)
+        if kwargs.get('verbose', False) and self.rank == 0:
+            print('\n# computing devices : {} {}(s)'.format(self.num_devices, self.compute_device))
+            print('# variable blocks : {} {}'.format(self.num_blocks, self.block_list))
+            print('\n# FLOPs : {:-15,}\n# Params: {:-15,}\n# Nodes : {:-15,}\n'.format(self.flops, self.params, self.nodes))
+        if kwargs.get('auto_compile', True) and self.device.type == 'cuda':
+            self.compile()
+
+    def _init_params(self, **kwargs):
+        pass
+
+    @abstractmethod
+    def _build_model(self):
+        """Must return a dict of tensors including 'logits' and 'pred' (reference convnet.py:257-264)."""
+
+    def _init_model(self, **kwargs):
+        """reference convnet.py:425-513 for one tower: labels, input preparation, model, loss."""
+        B = self.device_batch
+        H, W, C = self._input_size
+        g = self.graph
+        # X: prepared input; channels zero-padded to one 16-byte chunk so the stem conv takes the MFMA path
+        chunk = 8 if self._dtype == 'bfloat16' else 4
+        self.X = g.tensor((B, H, W, C), self._dtype, 'X', self._channel_first)
+        self.X.cs = (C + chunk - 1) // chunk * chunk
+        g.node('input', [], [self.X], image_mean=self.image_mean, scale_factor=self.scale_factor, src_nchw=self._channel_first)
+        if kwargs.get('zero_pad_ratio', 0.0) > 0.0 or kwargs.get('cutmix', False):
+            raise NotImplementedError('augmentation / zero padding are outside the built path')
+        self._curr_block = None
+        self.d = self._build_model()
+        if self._backbone_only:
+            self.logits = self.pred = self.loss_tensor = None
+            return
+        logits = self.d['logits']
+        if logits.dtype != 'float32':                                  # convnet.py:477-480
+            logits32 = g.tensor(logits.shape, 'float32', 'logits_fp32')
+            g.node('cast', [logits], [logits32])
+            logits = logits32
+            self.d['logits'] = logits
+        self.logits = logits
+        self._build_loss(**kwargs)
+
+    def _build_loss(self, **kwargs):
+        """reference convnet.py:528-597."""
+        if kwargs.get('l1_reg', 0.0) > 0.0 or kwargs.get('focal_loss_factor', 0.0) > 0.0 or kwargs.get('sigmoid_focal_loss_factor', 0.0) > 0.0:
+            raise NotImplementedError('l1 / focal losses are outside the built path')
+        if kwargs.get('bias_norm_decay', False):
+            raise NotImplementedError('bias_norm_decay is outside the built path')
+        g = self.graph
+        B, C = self.logits.shape
+        self.Y = g.tensor((B, C), 'float32', 'Y_onehot')
+        g.node('labels', [], [self.Y])
+        self.pred = g.tensor((B, C), 'float32', 'pred')
+        self.d['pred'] = self.pred
+        self._loss_node = g.node('loss', [self.logits, self.Y], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
+                                 label_smoothing=float(kwargs.get('label_smoothing', 0.0)))
+
+    # ---- compile: storage + launch lists -----------------------------------------------------------------------------------
+    def compile(self, loss_scale=1.0):
+        from .executor import Lowering
+        if self.device.type != 'cuda':
+            raise RuntimeError('ConvNet.compile() needs an MI355X (cuda device); the HIP path has no CPU fallback')
+        g = self.graph
+        if self.fuse and not getattr(self, '_fused', False):
+            g.fuse()
+            self._fused = True
+        B = self.device_batch
+        H, W, C = self._input_size
+        dev = self.device
+        self.X_in = torch.zeros((B, C, H, W) if self._channel_first else (B, H, W, C), dtype=torch.float32, device=dev)
+        self.Y_in = torch.zeros((B,), dtype=torch.float32, device=dev)
+        # flat storage: [conv/fc weights | biases, gammas, betas] so the L2 term covers one contiguous range
+        trainables = [v for v in self._var_order if v.kind in ('weight', 'bias', 'gamma', 'beta')]
+        ordered = [v for v in trainables if v.kind == 'weight'] + [v for v in trainables if v.kind != 'weight']
+        self.store = FlatStore(ordered, dev, with_grad=True)
+        nw = [v for v in ordered if v.kind == 'weight']
+        self.n_l2_elems = (nw[-1].offset + (nw[-1].size + 3) // 4 * 4) if nw else 0
+        self.stats = FlatStore([v for v in self._var_order if v.kind in ('mu', 'sigma')], dev, with_grad=False)
+        # per-step batch statistics in the same order as `stats` (for the cross-rank chain, convnet.py:1899-1909)
+        self.batch_stats = torch.zeros(max(self.stats.size, 4), dtype=torch.float32, device=dev)
+        self.initialize_variables()
+        for n in g.nodes:
+            if n.op == 'bn':
+                a = n.attrs
+                c = n.inputs[0].shape[-1]
+                mu, sg = a['mu'], a['sigma']
+                a['saved'] = dict(mean=torch.zeros(c, dtype=torch.float32, device=dev), invstd=torch.zeros(c, dtype=torch.float32, device=dev),
+                                  bmean=self.batch_stats[mu.offset:mu.offset + c], bvar=self.batch_stats[sg.offset:sg.offset + c])
+            elif n.op == 'loss':
+                a = n.attrs
+                a['pred'] = self.pred
+                a['ce'] = torch.zeros(B, dtype=torch.float32, device=dev)
+                a['coef'] = torch.zeros(B, dtype=torch.float32, device=dev)
+                a['loss'] = torch.zeros(4, dtype=torch.float32, device=dev)
+                a['class_w'] = None if self._loss_weights is None else torch.tensor(np.asarray(self._loss_weights, dtype=np.float32), device=dev)
+                self.loss_buf = a['loss']
+                self.valid_coef = a['coef']
+        g.allocate(training=True)
+        self.loss_scale = float(loss_scale)
+        self._train_low = Lowering(g, self, 'train', loss_scale).lower()
+        self._eval_low = Lowering(g, self, 'eval', 1.0).lower()
+        self.compiled = True
+        return self
+
+    def initialize_variables(self, seed=None):
+        """Fill every variable from its initializer (torch.Generator seeded per SURVEY §8d), EMA shadows start at the
+        initial value (tf.train.ExponentialMovingAverage semantics)."""
+        gen = torch.Generator().manual_seed(self.seed if seed is None else seed)
+        for v in self._var_order:
+            v.data.copy_(v.init(v.shape, gen).to(self.device))
+        self.store.ema.copy_(self.store.data)
+        self.stats.ema.copy_(self.stats.data)
+        self.store.accum.zero_()
+        self.store.grad.zero_()
+        self.global_step = 0
+
+    def set_variables(self, values, reset_state=True):
+        """Inject explicit values {name: ndarray} (parity tests always do: the TF RNG stream is not reproducible)."""
+        for k, a in values.items():
+            v = self.variables[k]
+            v.data.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)).view(v.shape).to(self.device))
+        if reset_state:
+            self.store.ema.copy_(self.store.data)
+            self.stats.ema.copy_(self.stats.data)
+            self.store.accum.zero_()
+            self.global_step = 0
+
+    def get_variables(self, which='data'):
+        return {k: getattr(v, which).detach().float().cpu().numpy().copy() for k, v in self.variables.items()
+                if which in ('data', 'ema') or v.kind in ('weight', 'bias', 'gamma', 'beta')}
+
+    # ---- running ----------------------------------------------------------------------------------------------------------------
+    def feed(self, X, Y=None):
+        """Copy one device batch into the static input buffers (non-blocking for pinned / device sources)."""
+        self.X_in.copy_(torch.as_tensor(X).to(self.X_in.dtype), non_blocking=True)
+        if Y is not None:
+            self.Y_in.copy_(torch.as_tensor(Y).to(self.Y_in.dtype), non_blocking=True)
+
+    def stream_ptr(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self, train=True):
+        low = self._train_low if train else self._eval_low
+        low.fwd.run(self.stream_ptr())
+
+    def backward(self, hooks=None):
+        self._train_low.bwd.run(self.stream_ptr(), hooks)
+
+    def fetch(self, tensor):
+        """Materialised value of a graph tensor as numpy (API layout)."""
+        t = tensor
+        while t.alias_of is not None and t.buf is None:
+            raise KeyError('{} was fused away; build the model with fuse=False to fetch it'.format(tensor.name))
+        a = t.buf[..., :t.shape[-1]].float().cpu().numpy()
+        if len(t.shape) == 4 and self._channel_first:
+            a = a.transpose(0, 3, 1, 2)
+        return a
+
+    def predict(self, dataset, verbose=False, return_images=True, max_examples=None, run_init_ops=True, **kwargs):
+        """reference convnet.py:609-665: forward-only loop with is_train=False (EMA weights + EMA running statistics)."""
+        batch = self.device_batch
+        pred_size = dataset.num_examples if max_examples is None else min(max_examples, dataset.num_examples)
+        num_steps = int(np.ceil(pred_size / batch))
+        _X = np.zeros([pred_size] + list(self._input_size), dtype=np.float32) if return_images else np.zeros([pred_size, 4, 4, 3], np.float32)
+        _Y_true = np.zeros([pred_size, self._num_classes], dtype=np.float32)
+        _Y_pred = np.zeros([pred_size, self._num_classes], dtype=np.float32)
+        _loss = np.zeros(num_steps, dtype=np.float32)
+        dataset.initialize()
+        for i in range(num_steps):
+            X, Y = dataset.next_batch(batch)
+            self.feed(X, Y)
+            self.forward(train=False)
+            s, e = i * batch, min((i + 1) * batch, pred_size)
+            if return_images:
+                xin = self.X_in.cpu().numpy()
+                _X[s:e] = (xin.transpose(0, 2, 3, 1) if self._channel_first else xin)[:e - s]
+            _Y_true[s:e] = self.Y.buf.cpu().numpy()[:e - s]
+            _Y_pred[s:e] = self.pred.buf.cpu().numpy()[:e - s]
+            _loss[i] = float(self.loss_buf[0].item())
+        return _X, _Y_true, _Y_pred, float(np.mean(_loss))
+
+    # ---- layers -----------------------------------------------------------------------------------------------------------------------
+    def _log_layer(self, name, shape, flops, params, nodes):
+        self._flops += flops
+        self._nodes += nodes
+        self._params += params
+        self._layer_info.append({'name': name, 'shape': shape, 'flops': int(flops), 'params': int(params), 'nodes': int(nodes)})
+
+    def conv_layer(self, x, kernel, stride, out_channels=None, padding='SAME', biased=True, depthwise=False, scope=None,
+                   dilation=(1, 1), ws=False, kernel_paddings=((0, 0), (0, 0)), weight_initializer=None, bias_initializer=None,
+                   verbose=False):
+        """reference convnet.py:1597-1706 -> tf.nn.conv2d (:1659) [+ tf.nn.bias_add (:1694)]."""
+        if depthwise:
+            raise NotImplementedError('depthwise convolution is a SURVEY §8f-2 row, not built yet')
+        kernel, stride, dilation = _pair(kernel), _pair(stride), _pair(dilation)
+        n, h, w, cin = x.shape
+        if out_channels is None:
+            out_channels = cin
+        oh = out_size(h, kernel[0], stride[0], padding, dilation[0])
+        ow = out_size(w, kernel[1], stride[1], padding, dilation[1])
+        if padding.upper() == 'SAME':
+            pt, pb = same_pads(h, kernel[0], stride[0], dilation[0])
+            pl, pr = same_pads(w, kernel[1], stride[1], dilation[1])
+        else:
+            pt = pb = pl = pr = 0
+        with self.variable_scope(scope) if scope is not None else nullcontext():
+            wv = self.weight_variable([kernel[0], kernel[1], cin, out_channels], initializer=weight_initializer,
+                                      weight_standardization=ws, paddings=kernel_paddings)
+            bv = self.bias_variable(out_channels, initializer=bias_initializer) if biased else None
+            name = self.scope_name()
+        y = self.graph.tensor((n, oh, ow, out_channels), x.dtype, name + '/conv', self._channel_first)
+        geom = _ffi.conv_geom(n, h, w, cin, out_channels, kernel[0], kernel[1], stride[0], stride[1], dilation[0], dilation[1],
+                              (pt, pb, pl, pr), x.cs)
+        self.graph.node('conv', [x], [y], scope=name, geom=geom, w=wv, b=bv, has_params=True)
+        # the reference's report uses np.ceil on floats for out_size; identical for integer inputs (convnet.py:1626-1664)
+        flops = oh * ow * kernel[0] * kernel[1] * cin * out_channels
+        params = kernel[0] * kernel[1] * cin * out_channels
+        self._conv_macs += flops
+        if biased:
+            flops += oh * ow * out_channels
+            params += out_channels
+        self._log_layer(name, [None, oh, ow, out_channels], flops, params, oh * ow * out_channels)
+        return y
+
+    def conv_bn_act(self, x, kernel, stride, out_channels=None, padding='SAME', biased=False, depthwise=False, scope=None,
+                    dilation=(1, 1), ws=False, kernel_paddings=((0, 0), (0, 0)), weight_initializer=None, bias_initializer=None,
+                    scale=True, shift=True, zero_scale_init=False, epsilon=1e-3, act_type='relu', act_params=None, verbose=False):
+        """reference convnet.py:1550-1595."""
+        with self.variable_scope(scope) if scope is not None else nullcontext():
+            x = self.conv_layer(x, kernel, stride, out_channels, padding=padding, biased=biased, depthwise=depthwise, dilation=dilation,
+                                ws=ws, kernel_paddings=kernel_paddings, weight_initializer=weight_initializer,
+                                bias_initializer=bias_initializer)
+            x = self.batch_norm(x, scale=scale, shift=shift, zero_scale_init=zero_scale_init, epsilon=epsilon)
+            x = self.activation(x, activation_type=act_type, params=act_params)
+        return x
+
+    def fc_layer(self, x, out_dim, biased=True, scope=None, ws=False, weight_initializer=None, bias_initializer=None, verbose=False):
+        """reference convnet.py:1708-1755 -> tf.matmul(x, W) + b."""
+        in_dim = int(x.shape[-1])
+        with self.variable_scope(scope) if scope is not None else nullcontext():
+            wv = self.weight_variable([in_dim, out_dim], initializer=weight_initializer, weight_standardization=ws)
+            bv = self.bias_variable(out_dim, initializer=bias_initializer) if biased else None
+            name = self.scope_name()
+        y = self.graph.tensor((x.shape[0], out_dim), x.dtype, name + '/fc')
+        self.graph.node('fc', [x], [y], scope=name, w=wv, b=bv, has_params=True)
+        flops = in_dim * out_dim + (out_dim if biased else 0)
+        self._log_layer(name, [None, out_dim], flops, flops, out_dim)
+        return y
+
+    def normalization(self, x, norm_type='batch', norm_param=None, scale=True, shift=True, zero_scale_init=False, epsilon=1e-3,
+                      scope='norm'):
+        """reference convnet.py:1757-1778."""
+        if norm_type is None:
+            return x
+        if norm_type.lower() == 'batch':
+            return self.batch_norm(x, scale=scale, shift=shift, zero_scale_init=zero_scale_init, epsilon=epsilon, scope=scope)
+        raise NotImplementedError('normalization type {} is outside the built path (supported: batch)'.format(norm_type))
+
+    def batch_norm(self, x, scale=True, shift=True, zero_scale_init=False, epsilon=1e-3, scope='bn'):
+        """reference convnet.py:1780-1926 -> tf.nn.fused_batch_norm + running-statistics update."""
+        if isinstance(self._update_batch_norm, bool):
+            update = self._update_batch_norm
+        else:
+            update = self._trainable_here()
+        trainable = self._trainable_here()
+        c = x.shape[-1]
+        with self.variable_scope(scope):
+            mu = self._new_variable('mu', c, 'mu', zeros(), False)
+            sigma = self._new_variable('sigma', c, 'sigma', ones(), False)       # running VARIANCE despite the name
+            for v in (mu, sigma):
+                self.add_to_collection('norm_statistics', v)
+                self.add_to_collection('block_{}/norm_statistics'.format(self._curr_block), v)
+            gamma = beta = None
+            if scale:
+                gamma = self._new_variable('gamma', c, 'gamma', zeros() if zero_scale_init else ones(), trainable)
+                self._params += c
+            if shift:
+                beta = self._new_variable('beta', c, 'beta', zeros(), trainable)
+                self._params += c
+                self._flops += x.shape[1] * x.shape[2] * c if len(x.shape) == 4 else c
+            for v in (gamma, beta):
+                if v is not None:
+                    self.add_to_collection('norm_variables', v)
+                    self.add_to_collection('block_{}/norm_variables'.format(self._curr_block), v)
+            name = self.scope_name()
+        y = self.graph.tensor(x.shape, x.dtype, name, self._channel_first)
+        self.graph.node('bn', [x], [y], scope=name, gamma=gamma, beta=beta, mu=mu, sigma=sigma, eps=epsilon,
+                        momentum=self._batch_norm_decay, update=update, has_params=True)
+        return y
+
+    def _pool(self, op, x, side_l, stride, padding):
+        side_l, stride = _pair(side_l), _pair(stride)
+        n, h, w, c = x.shape
+        oh = out_size(h, side_l[0], stride[0], padding)
+        ow = out_size(w, side_l[1], stride[1], padding)
+        if padding.upper() == 'SAME':
+            pt, _ = same_pads(h, side_l[0], stride[0])
+            pl, _ = same_pads(w, side_l[1], stride[1])
+        else:
+            pt = pl = 0
+        name = self.scope_name(op)
+        y = self.graph.tensor((n, oh, ow, c), x.dtype, name, self._channel_first)
+        self.graph.node(op, [x], [y], scope=name, kh=side_l[0], kw=side_l[1], sh=stride[0], sw=stride[1], pt=pt, pl=pl)
+        self._flops += side_l[0] * side_l[1] * oh * ow * c
+        self._nodes += oh * ow * c
+        self._layer_info.append({'name': name, 'shape': [None, oh, ow, c], 'flops': int(side_l[0] * side_l[1] * oh * ow * c), 'params': 0,
+                                 'nodes': int(oh * ow * c)})
+        return y
+
+    def max_pool(self, x, side_l, stride, padding='SAME'):
+        """reference convnet.py:1472-1509 -> tf.nn.max_pool."""
+        return self._pool('maxpool', x, side_l, stride, padding)
+
+    def avg_pool(self, x, side_l, stride, padding='SAME'):
+        """reference convnet.py:1511-1548 -> tf.nn.avg_pool."""
+        return self._pool('avgpool', x, side_l, stride, padding)
+
+    def pooling_layer(self, x, kernel, stride, padding='SAME', pooling_type='AVG'):
+        """reference convnet.py:1464-1470."""
+        if pooling_type.lower() == 'avg':
+            return self.avg_pool(x, kernel, stride, padding=padding)
+        if pooling_type.lower() == 'max':
+            return self.max_pool(x, kernel, stride, padding=padding)
+        raise ValueError('Pooling type of {} is not supported'.format(pooling_type))
+
+    def global_avg_pool(self, x):
+        """Stand-in for tf.reduce_mean(x, axis=[1, 2]) at models/resnet_v1_5.py:72-73."""
+        n, h, w, c = x.shape
+        y = self.graph.tensor((n, c), x.dtype, self.scope_name('avgpool'))
+        self.graph.node('gap', [x], [y], scope=self.scope_name())
+        return y
+
+    def dropout(self, x, rate):
+        """Stand-in for tf.nn.dropout at models/resnet_v1_5.py:75; rate 0 (the default) is the identity."""
+        if rate and rate > 0.0:
+            raise NotImplementedError('dropout with rate > 0 is not built yet (SURVEY §8f-4)')
+        return x
+
+    def softmax(self, x):
+        """Stand-in for tf.nn.softmax at models/resnet_v1_5.py:78: `pred` is produced by the fused loss kernel."""
+        return x
+
+    def stochastic_depth(self, x, skip, drop_rate=0.0, name='drop'):
+        """reference convnet.py:2500-2512; drop_rate 0 -> x + skip."""
+        if drop_rate > 0.0:
+            raise NotImplementedError('stochastic depth with drop_rate > 0 is a SURVEY §8f-2 row')
+        assert x.shape == skip.shape, 'residual shapes differ: {} vs {}'.format(x.shape, skip.shape)
+        y = self.graph.tensor(x.shape, x.dtype, self.scope_name('add'), self._channel_first)
+        self.graph.node('add', [x, skip], [y], scope=self.scope_name())
+        return y
+
+    def activation(self, x, activation_type='relu', params=None):
+        """reference convnet.py:2514-2534."""
+        if activation_type is None:
+            return x
+        if activation_type.lower() == 'relu':
+            return self.relu(x, name=activation_type)
+        raise NotImplementedError('activation {} is outside the built path (supported: relu)'.format(activation_type))
+
+    def relu(self, x, name='relu'):
+        """reference convnet.py:2536-2537 -> tf.nn.relu."""
+        y = self.graph.tensor(x.shape, x.dtype, self.scope_name(name), self._channel_first)
+        self.graph.node('relu', [x], [y], scope=self.scope_name())
+        return y

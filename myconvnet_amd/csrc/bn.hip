@@ -1,0 +1,467 @@
+// bn.hip — batch normalisation (tf.nn.fused_batch_norm semantics) on [M][C] NHWC activations.
+//
+// HBM-bound.  Every kernel uses one column layout: a thread owns one 16-byte channel chunk
+// (8 bf16 / 4 fp32 channels) and walks rows, so loads are coalesced along C, per-channel
+// parameters live in registers, and reductions over M are per-thread sums (shifted by a
+// per-channel pivot x[0][c] to avoid E[x^2]-E[x]^2 cancellation) folded across the block through
+// LDS, then across blocks by a deterministic second-stage kernel in double precision.
+//   fwd : stats (1 read of x) -> finalize -> apply (1 read of x [+skip], 1 write of y), ReLU and
+//         the residual add fused into apply.
+//   bwd : reduce (reads dy, x [, y]) -> finalize -> apply (reads dy, x [, y]; writes dx [, dskip]).
+#include "common.h"
+
+template <typename T, int VEC>
+__device__ __forceinline__ void ldv(const T* p, float (&o)[VEC]) {
+    if constexpr (VEC == 1) {
+        o[0] = to_f32(p[0]);
+    } else {
+        const Chunk<T> c = load_chunk<T>(p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = c.get(i);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void stv(T* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 1) {
+        p[0] = from_f32<T>(v[0]);
+    } else {
+        Chunk<T> c;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) c.set(i, v[i]);
+        store_chunk<T>(p, c);
+    }
+}
+
+struct ColLayout {
+    int cols;   // number of VEC-wide columns = C / VEC
+    int TX;     // columns per block
+    int TY;     // row lanes per block
+    int gx;     // column blocks
+    int gy;     // row blocks
+    long rpb;   // rows per row-block
+};
+static ColLayout make_layout(long M, int C, int vec, int target_blocks) {
+    ColLayout L;
+    L.cols = C / vec;
+    L.TX = L.cols < 256 ? L.cols : 256;
+    L.TY = 256 / L.TX;
+    L.gx = (L.cols + L.TX - 1) / L.TX;
+    long gy = target_blocks / L.gx;
+    const long maxgy = (M + (long)L.TY * 8 - 1) / ((long)L.TY * 8);   // at least ~8 rows per thread
+    if (gy > maxgy) gy = maxgy;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    L.rpb = (M + gy - 1) / gy;
+    L.rpb = (L.rpb + L.TY - 1) / L.TY * L.TY;
+    if (L.rpb < 1) L.rpb = L.TY;
+    L.gy = (int)((M + L.rpb - 1) / L.rpb);
+    if (L.gy < 1) L.gy = 1;
+    return L;
+}
+
+// ---- forward statistics --------------------------------------------------------------------------
+// part[(rb*2 + {0,1})*C + c] = sum over the block's rows of (x - pivot), (x - pivot)^2
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C, int TX, int TY,
+                                                       long rpb) {
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const bool active = ty < TY && col * VEC < C;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float piv[VEC];
+        ldv<T, VEC>(x + (long)col * VEC, piv);
+        const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+        for (long r = r0 + ty; r < r1; r += TY) {
+            float v[VEC];
+            ldv<T, VEC>(x + r * C + (long)col * VEC, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float d = v[i] - piv[i];
+                s1[i] += d;
+                s2[i] = fmaf(d, d, s2[i]);
+            }
+        }
+    }
+    // fold the TY row lanes
+    float* r1p = red;                       // [TY][TX*VEC]
+    float* r2p = red + 256 * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            r1p[(ty * TX + tx) * VEC + i] = s1[i];
+            r2p[(ty * TX + tx) * VEC + i] = s2[i];
+        }
+    }
+    __syncthreads();
+    if (ty == 0 && col * VEC < C) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < TY; ++k) {
+                a += r1p[(k * TX + tx) * VEC + i];
+                b += r2p[(k * TX + tx) * VEC + i];
+            }
+            part[((long)blockIdx.y * 2 + 0) * C + col * VEC + i] = a;
+            part[((long)blockIdx.y * 2 + 1) * C + col * VEC + i] = b;
+        }
+    }
+}
+
+// scale/shift for the apply pass + saved statistics + running-statistics update
+template <typename T>
+__global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ part, int nparts, long M, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ batch_mean,
+                                       float* __restrict__ batch_var, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                       float momentum, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nparts; ++k) {
+        a += (double)part[((long)k * 2 + 0) * C + c];
+        b += (double)part[((long)k * 2 + 1) * C + c];
+    }
+    const double piv = (double)to_f32(x[c]);
+    const double inv_m = 1.0 / (double)M;
+    const double dm = a * inv_m;
+    const double mean = piv + dm;
+    double var = b * inv_m - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float fmean = (float)mean, finv = (float)invstd;
+    save_mean[c] = fmean;
+    save_invstd[c] = finv;
+    const double ub = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+    if (batch_mean) batch_mean[c] = fmean;
+    if (batch_var) batch_var[c] = (float)ub;
+    if (running_mean) running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * fmean;
+    if (running_var) running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)ub;
+    const float sc = g * finv;
+    scale[c] = sc;
+    shift[c] = bt - fmean * sc;
+}
+
+// y = act(x*scale + shift [+ skip])
+template <typename T, int VEC, bool SKIP, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, long M, int C,
+                                                       int TX, int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sc[i] = scale[col * VEC + i];
+        sh[i] = shift[col * VEC + i];
+    }
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float v[VEC];
+        ldv<T, VEC>(x + off, v);
+        float s[VEC];
+        if (SKIP) ldv<T, VEC>(skip + off, s);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float o = fmaf(v[i], sc[i], sh[i]);
+            if (SKIP) o += s[i];
+            if (RELU) o = fmaxf(o, 0.f);
+            v[i] = o;
+        }
+        stv<T, VEC>(y + off, v);
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------------------
+// part[(rb*2+0)*C + c] = sum dy', part[(rb*2+1)*C + c] = sum dy' * xhat   (dy' = dy*[y>0] if RELU)
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ part, long M, int C, int TX, int TY, long rpb) {
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const bool active = ty < TY && col * VEC < C;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], is[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            mu[i] = mean[col * VEC + i];
+            is[i] = invstd[col * VEC + i];
+        }
+        const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+        for (long r = r0 + ty; r < r1; r += TY) {
+            const long off = r * C + (long)col * VEC;
+            float g[VEC], v[VEC], o[VEC];
+            ldv<T, VEC>(dy + off, g);
+            ldv<T, VEC>(x + off, v);
+            if (RELU) ldv<T, VEC>(y + off, o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float gg = g[i];
+                if (RELU) gg = o[i] > 0.f ? gg : 0.f;
+                s1[i] += gg;
+                s2[i] = fmaf(gg, (v[i] - mu[i]) * is[i], s2[i]);
+            }
+        }
+    }
+    float* r1p = red;
+    float* r2p = red + 256 * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            r1p[(ty * TX + tx) * VEC + i] = s1[i];
+            r2p[(ty * TX + tx) * VEC + i] = s2[i];
+        }
+    }
+    __syncthreads();
+    if (ty == 0 && col * VEC < C) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < TY; ++k) {
+                a += r1p[(k * TX + tx) * VEC + i];
+                b += r2p[(k * TX + tx) * VEC + i];
+            }
+            part[((long)blockIdx.y * 2 + 0) * C + col * VEC + i] = a;
+            part[((long)blockIdx.y * 2 + 1) * C + col * VEC + i] = b;
+        }
+    }
+}
+
+// coef[0][c] = gamma*invstd, coef[1][c] = dbeta/M, coef[2][c] = dgamma/M
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, long M, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float grad_scale, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nparts; ++k) {
+        a += (double)part[((long)k * 2 + 0) * C + c];
+        b += (double)part[((long)k * 2 + 1) * C + c];
+    }
+    if (dbeta) dbeta[c] = (float)a * grad_scale;
+    if (dgamma) dgamma[c] = (float)b * grad_scale;
+    coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[C + c] = (float)(a / (double)M);
+    coef[2 * C + c] = (float)(b / (double)M);
+}
+
+template <typename T, int VEC, bool RELU, bool DSKIP>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dskip,
+                                                           long M, int C, int TX, int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        mu[i] = mean[col * VEC + i];
+        is[i] = invstd[col * VEC + i];
+        ca[i] = coef[col * VEC + i];
+        cb[i] = coef[C + col * VEC + i];
+        cc[i] = coef[2 * C + col * VEC + i];
+    }
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float g[VEC], v[VEC], o[VEC];
+        ldv<T, VEC>(dy + off, g);
+        ldv<T, VEC>(x + off, v);
+        if (RELU) ldv<T, VEC>(y + off, o);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            if (RELU) g[i] = o[i] > 0.f ? g[i] : 0.f;
+            const float xh = (v[i] - mu[i]) * is[i];
+            v[i] = ca[i] * (g[i] - cb[i] - xh * cc[i]);
+        }
+        stv<T, VEC>(dx + off, v);
+        if (DSKIP) stv<T, VEC>(dskip + off, g);
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+#define BN_TARGET_BLOCKS 2048
+static size_t bn_parts_bytes(long M, int C) {
+    // worst case over vector widths: gy <= BN_TARGET_BLOCKS
+    return align_up((size_t)BN_TARGET_BLOCKS * 2 * C * sizeof(float), 256);
+}
+extern "C" size_t mcn_bn_workspace_bytes(int64_t M, int32_t C) {
+    if (M < 0 || C <= 0) return 0;
+    return bn_parts_bytes(M, C) + align_up((size_t)3 * C * sizeof(float), 256);
+}
+
+template <typename T, int VEC>
+static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* skip, void* y, float* save_mean,
+                          float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
+                          float momentum, long M, int C, float eps, mcn_act act, void* ws, hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    float* part = (float*)ws;
+    float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
+    float* shift = scale + C;
+    const dim3 grid(L.gx, L.gy), block(256);
+    hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)x, part, M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_fwd_finalize_kernel<T>), dim3((C + 255) / 256), block, 0, st, (const T*)x, (const float*)part, L.gy, M, C, gamma,
+                       beta, eps, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
+    MCN_CHECK_LAUNCH();
+    const bool relu = act == MCN_ACT_RELU;
+#define BN_APPLY(SK, RL)                                                                                                   \
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, (const float*)scale, \
+                       (const float*)shift, M, C, L.TX, L.TY, L.rpb)
+    if (skip) { if (relu) BN_APPLY(true, true); else BN_APPLY(true, false); }
+    else { if (relu) BN_APPLY(false, true); else BN_APPLY(false, false); }
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* skip, void* y, float* save_mean,
+                                float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
+                                float momentum, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (!x || !y || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train: bad argument (M=%ld C=%d)", (long)M, C);
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        return bn_fwd_train_t<float, 1>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+    }
+    if (dtype == MCN_BF16) {
+        if (C % 8 == 0) return bn_fwd_train_t<bf16_t, 8>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        return bn_fwd_train_t<bf16_t, 1>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+    }
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train: dtype %d unsupported", (int)dtype);
+}
+
+
+template <typename T, int VEC>
+static int channel_affine_t(const void* x, const float* scale, const float* shift, void* y, long M, int C, hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const dim3 grid(L.gx, L.gy), block(256);
+    const void* skip = nullptr;
+    BN_APPLY(false, false);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+#undef BN_APPLY
+extern "C" int mcn_channel_affine(const void* x, const float* scale, const float* shift, void* y, int64_t M, int32_t C, mcn_dtype dtype,
+                                  void* stream) {
+    if (!x || !y || !scale || !shift || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_affine: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return C % 4 == 0 ? channel_affine_t<float, 4>(x, scale, shift, y, M, C, st) : channel_affine_t<float, 1>(x, scale, shift, y, M, C, st);
+    if (dtype == MCN_BF16) return C % 8 == 0 ? channel_affine_t<bf16_t, 8>(x, scale, shift, y, M, C, st) : channel_affine_t<bf16_t, 1>(x, scale, shift, y, M, C, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "channel_affine: dtype %d unsupported", (int)dtype);
+}
+
+// inference: the caller owns all memory and passes no workspace, so the per-channel scale/shift are
+// computed in the kernel prologue (registers) instead of a separate finalize launch.
+template <typename T, int VEC, bool SKIP, bool RELU>
+__global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ var, float eps, long M,
+                                                       int C, int TX, int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int c = col * VEC + i;
+        const float inv = 1.f / sqrtf(var[c] + eps);
+        sc[i] = (gamma ? gamma[c] : 1.f) * inv;
+        sh[i] = (beta ? beta[c] : 0.f) - mean[c] * sc[i];
+    }
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float v[VEC], s[VEC];
+        ldv<T, VEC>(x + off, v);
+        if (SKIP) ldv<T, VEC>(skip + off, s);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float o = fmaf(v[i], sc[i], sh[i]);
+            if (SKIP) o += s[i];
+            if (RELU) o = fmaxf(o, 0.f);
+            v[i] = o;
+        }
+        stv<T, VEC>(y + off, v);
+    }
+}
+template <typename T, int VEC>
+static int bn_infer_t(const void* x, const float* gamma, const float* beta, const float* mean, const float* var, const void* skip, void* y,
+                      long M, int C, float eps, mcn_act act, hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const dim3 grid(L.gx, L.gy), block(256);
+    const bool relu = act == MCN_ACT_RELU;
+#define BN_INFER(SK, RL)                                                                                                     \
+    hipLaunchKernelGGL((bn_infer_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, gamma, beta, mean, var, \
+                       eps, M, C, L.TX, L.TY, L.rpb)
+    if (skip) { if (relu) BN_INFER(true, true); else BN_INFER(true, false); }
+    else { if (relu) BN_INFER(false, true); else BN_INFER(false, false); }
+#undef BN_INFER
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const float* mean, const float* var, const void* skip,
+                                void* y, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* stream) {
+    if (!x || !y || !mean || !var || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_infer: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return C % 4 == 0 ? bn_infer_t<float, 4>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st)
+                                            : bn_infer_t<float, 1>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st);
+    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_infer_t<bf16_t, 8>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st)
+                                             : bn_infer_t<bf16_t, 1>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_infer: dtype %d unsupported", (int)dtype);
+}
+
+template <typename T, int VEC>
+static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_invstd,
+                    void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, long M, int C, mcn_act act, void* ws,
+                    hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    float* part = (float*)ws;
+    float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
+    const dim3 grid(L.gx, L.gy), block(256);
+    const bool relu = act == MCN_ACT_RELU;
+    if (relu)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, true>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x,
+                           (const T*)y, save_mean, save_invstd, part, M, C, L.TX, L.TY, L.rpb);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, false>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x,
+                           (const T*)y, save_mean, save_invstd, part, M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), block, 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
+                       dbeta, grad_scale, coef);
+    MCN_CHECK_LAUNCH();
+#define BN_BWD_APPLY(RL, DS)                                                                                                    \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, RL, DS>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, \
+                       save_invstd, (const float*)coef, (T*)dx, (T*)dskip, M, C, L.TX, L.TY, L.rpb)
+    if (relu) { if (dskip) BN_BWD_APPLY(true, true); else BN_BWD_APPLY(true, false); }
+    else { if (dskip) BN_BWD_APPLY(false, true); else BN_BWD_APPLY(false, false); }
+#undef BN_BWD_APPLY
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                          const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, int64_t M,
+                          int32_t C, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !dx || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd: bad argument");
+    if (act == MCN_ACT_RELU && !y) MCN_FAIL(MCN_E_BADARG, "bn_bwd: act=RELU needs the forward output y");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                            : bn_bwd_t<float, 1>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                             : bn_bwd_t<bf16_t, 1>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
+}

@@ -1,0 +1,103 @@
+// common.h — shared device/host helpers for libmcn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/mcn.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+#define MCN_WAVE 64
+
+// ---- error plumbing (host) ---------------------------------------------------------------
+void mcn_set_error(const char* fmt, ...);
+#define MCN_FAIL(code, ...)        \
+    do {                           \
+        mcn_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+#define MCN_CHECK_LAUNCH()                                                         \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t mcn_dtype_size(mcn_dtype t) { return t == MCN_F32 ? 4 : 2; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device helpers ----------------------------------------------------------------------
+template <typename T>
+struct VecTraits;
+template <>
+struct VecTraits<float> {
+    static constexpr int CE = 4;  // elements per 16-byte chunk
+};
+template <>
+struct VecTraits<bf16_t> {
+    static constexpr int CE = 8;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte chunk <-> fp32 lanes
+template <typename T>
+struct Chunk;
+template <>
+struct Chunk<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = f; }
+};
+template <>
+struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+template <typename T>
+__device__ __forceinline__ Chunk<T> load_chunk(const T* p) {
+    Chunk<T> c;
+    *reinterpret_cast<i32x4*>(&c.v) = *reinterpret_cast<const i32x4*>(p);
+    return c;
+}
+template <typename T>
+__device__ __forceinline__ void store_chunk(T* p, const Chunk<T>& c) {
+    *reinterpret_cast<i32x4*>(p) = *reinterpret_cast<const i32x4*>(&c.v);
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD a contiguous range of logical tiles (operand panels stay in its L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

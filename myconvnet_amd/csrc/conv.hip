@@ -1,0 +1,448 @@
+// conv.hip — host side of mcn_conv2d_{fwd,dgrad,wgrad} and mcn_fc_*: geometry -> tap tables,
+// weight packing into caller workspace, kernel selection and launch.  No device allocation, no sync.
+#include "conv_kernels.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// ---- error string ------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void mcn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mcn_last_error(void) { return g_err; }
+extern "C" int mcn_version(void) { return MCN_VERSION; }
+
+static bool force_naive() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MCN_FORCE_NAIVE");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+// ---- geometry helpers ----------------------------------------------------------------------------
+struct Geo {
+    int N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pT, pB, pL, pR, xcs, OH, OW;
+};
+static int geo_from(const mcn_conv_geom* g, Geo* o) {
+    if (!g) MCN_FAIL(MCN_E_BADARG, "conv: null geometry");
+    o->N = g->N; o->H = g->H; o->W = g->W; o->Cin = g->Cin; o->Cout = g->Cout;
+    o->KH = g->KH; o->KW = g->KW; o->SH = g->SH; o->SW = g->SW; o->DH = g->DH; o->DW = g->DW;
+    o->pT = g->padT; o->pB = g->padB; o->pL = g->padL; o->pR = g->padR;
+    o->xcs = g->x_cs > 0 ? g->x_cs : g->Cin;
+    if (o->N < 0 || o->H <= 0 || o->W <= 0 || o->Cin <= 0 || o->Cout <= 0 || o->KH <= 0 || o->KW <= 0 || o->SH <= 0 ||
+        o->SW <= 0 || o->DH <= 0 || o->DW <= 0 || o->pT < 0 || o->pB < 0 || o->pL < 0 || o->pR < 0 || o->xcs < o->Cin)
+        MCN_FAIL(MCN_E_BADARG, "conv: bad geometry N=%d H=%d W=%d Cin=%d Cout=%d K=%dx%d S=%dx%d D=%dx%d x_cs=%d", o->N, o->H,
+                 o->W, o->Cin, o->Cout, o->KH, o->KW, o->SH, o->SW, o->DH, o->DW, o->xcs);
+    const int eh = (o->KH - 1) * o->DH + 1, ew = (o->KW - 1) * o->DW + 1;
+    if (o->H + o->pT + o->pB < eh || o->W + o->pL + o->pR < ew) MCN_FAIL(MCN_E_BADARG, "conv: filter larger than padded input");
+    o->OH = (o->H + o->pT + o->pB - eh) / o->SH + 1;
+    o->OW = (o->W + o->pL + o->pR - ew) / o->SW + 1;
+    return MCN_OK;
+}
+static inline int ce_of(mcn_dtype t) { return t == MCN_F32 ? 4 : 8; }
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static bool mfma_path_ok(const Geo& g, mcn_dtype dt) {
+    if (force_naive()) return false;
+    const int ce = ce_of(dt);
+    const size_t es = mcn_dtype_size(dt);
+    if (g.KH * g.KW > MCN_MAX_TAPS) return false;
+    if ((g.KH - 1) * g.DH + g.pT > 127 || (g.KW - 1) * g.DW + g.pL > 127) return false;
+    if (g.xcs % ce) return false;                       // 16-byte chunks of x
+    if (round_up(g.Cin, ce) > g.xcs) return false;
+    if (g.Cout % ce) return false;                      // 16-byte chunks of dy, vector epilogue
+    if (g.Cin % 4) {
+        if (g.xcs == g.Cin) return false;
+    }
+    if ((size_t)g.N * g.H * g.W * g.xcs * es >= 0x7fffffffull) return false;
+    if ((size_t)g.N * g.OH * g.OW * g.Cout * es >= 0x7fffffffull) return false;
+    return true;
+}
+// dgrad writes dx with channel stride Cin through the vector epilogue
+static bool mfma_dgrad_ok(const Geo& g, mcn_dtype dt) { return mfma_path_ok(g, dt) && g.Cin % 4 == 0 && g.xcs == g.Cin; }
+
+static size_t fwd_pack_bytes(const Geo& g, mcn_dtype dt) {
+    return align_up((size_t)g.Cout * g.KH * g.KW * round_up(g.Cin, ce_of(dt)) * mcn_dtype_size(dt), 256);
+}
+static size_t dgrad_pack_bytes(const Geo& g, mcn_dtype dt) {
+    return align_up((size_t)g.Cin * g.KH * g.KW * round_up(g.Cout, ce_of(dt)) * mcn_dtype_size(dt), 256) + 256 * (size_t)g.SH * g.SW;
+}
+static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_out) {
+    const int KP = dt == MCN_F32 ? 32 : 64;
+    const long M = (long)g.N * g.OH * g.OW;
+    const int nsteps = (int)((M + KP - 1) / KP);
+    const int rows = g.KH * g.KW * round_up(g.Cin, ce_of(dt));
+    const int BN = g.Cout <= 64 ? 64 : 128;
+    const int tiles = ((rows + 127) / 128) * ((g.Cout + BN - 1) / BN);
+    int splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU in total
+    if (splits > nsteps) splits = nsteps;
+    if (splits > 512) splits = 512;
+    if (splits < 1) splits = 1;
+    int sps = (nsteps + splits - 1) / splits;
+    if (sps < 1) sps = 1;
+    splits = (nsteps + sps - 1) / sps;
+    if (splits < 1) splits = 1;
+    if (nsteps_out) *nsteps_out = nsteps;
+    if (sps_out) *sps_out = sps;
+    return splits;
+}
+static size_t colsum_parts(long M) {
+    long parts = (M + 511) / 512;
+    if (parts > 256) parts = 256;
+    if (parts < 1) parts = 1;
+    return (size_t)parts;
+}
+static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
+    size_t b = 0;
+    if (mfma_path_ok(g, dt)) {
+        const int splits = wgrad_splits(g, dt, nullptr, nullptr);
+        const size_t rows = (size_t)g.KH * g.KW * round_up(g.Cin, ce_of(dt));
+        b += align_up((size_t)splits * rows * g.Cout * 4, 256);
+    }
+    b += align_up(colsum_parts((long)g.N * g.OH * g.OW) * g.Cout * 4, 256);
+    return b;
+}
+
+extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
+    Geo g;
+    if (geo_from(gg, &g) != MCN_OK) return 0;
+    if (dtype != MCN_F32 && dtype != MCN_BF16) return 0;
+    switch (op) {
+        case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) : 0;
+        case MCN_CONV_DGRAD: return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) : 0;
+        case MCN_CONV_WGRAD: return wgrad_ws_bytes(g, dtype);
+    }
+    return 0;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------
+template <typename K>
+static void allow_lds(K kernel, int bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <typename T>
+static int launch_nt(const GemmNTParams& p, bool taps, hipStream_t st) {
+    const int BN = p.Nn <= 64 ? 64 : 128;
+    const int BM = 128;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Nn + BN - 1) / BN;
+    if (ntm <= 0 || ntn <= 0) return MCN_OK;
+    const int lds = 2 * (BM + BN) * 128;
+    const dim3 grid(ntm * ntn), block(256);
+#define MCN_LAUNCH_NT(BNV, TAPSV)                                                    \
+    do {                                                                             \
+        static bool once = (allow_lds(conv_gemm_nt<T, 128, BNV, TAPSV>, 2 * (128 + BNV) * 128), true); \
+        (void)once;                                                                  \
+        hipLaunchKernelGGL((conv_gemm_nt<T, 128, BNV, TAPSV>), grid, block, lds, st, p); \
+    } while (0)
+    if (BN == 128) {
+        if (taps) MCN_LAUNCH_NT(128, true); else MCN_LAUNCH_NT(128, false);
+    } else {
+        if (taps) MCN_LAUNCH_NT(64, true); else MCN_LAUNCH_NT(64, false);
+    }
+#undef MCN_LAUNCH_NT
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+template <typename T>
+static int launch_tn(const GemmTNParams& p, bool linear, int splits, hipStream_t st) {
+    const int BN = p.Nn <= 64 ? 64 : 128;
+    const int tiles = ((p.rows + 127) / 128) * ((p.Nn + BN - 1) / BN);
+    const dim3 grid(tiles, splits), block(256);
+    const int KP = sizeof(T) == 4 ? 32 : 64;
+#define MCN_LAUNCH_TN(BNV, LINV)                                                     \
+    do {                                                                             \
+        const int lds = 2 * (KP * 128 * (int)sizeof(T) + KP * BNV * (int)sizeof(T)); \
+        static bool once = (allow_lds(conv_gemm_tn<T, BNV, LINV>, 2 * (64 * 128 * 4 + 64 * BNV * 4)), true); \
+        (void)once;                                                                  \
+        hipLaunchKernelGGL((conv_gemm_tn<T, BNV, LINV>), grid, block, lds, st, p);   \
+    } while (0)
+    if (BN == 128) {
+        if (linear) MCN_LAUNCH_TN(128, true); else MCN_LAUNCH_TN(128, false);
+    } else {
+        if (linear) MCN_LAUNCH_TN(64, true); else MCN_LAUNCH_TN(64, false);
+    }
+#undef MCN_LAUNCH_TN
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+template <typename T>
+static int launch_pack(const PackParams& p, hipStream_t st) {
+    const long total = (long)p.rows * p.ntaps * p.Cp;
+    if (total <= 0) return MCN_OK;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+static NaiveConvParams naive_params(const Geo& g) {
+    NaiveConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.KH = g.KH; p.KW = g.KW; p.SH = g.SH; p.SW = g.SW;
+    p.DH = g.DH; p.DW = g.DW; p.padT = g.pT; p.padL = g.pL; p.OH = g.OH; p.OW = g.OW; p.x_cs = g.xcs;
+    p.scale = 1.f;
+    return p;
+}
+static inline unsigned nblocks(long total, int cap = 8192) {
+    long b = (total + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---- forward -------------------------------------------------------------------------------------------
+template <typename T>
+static int conv_fwd_t(const void* x, const float* w, const float* bias, void* y, const Geo& g, mcn_dtype dt, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    const long M = (long)g.N * g.OH * g.OW;
+    if (M == 0) return MCN_OK;
+    if (!mfma_path_ok(g, dt)) {
+        NaiveConvParams p = naive_params(g);
+        p.x = x; p.w = w; p.y = y; p.bias = bias;
+        hipLaunchKernelGGL((naive_conv_fwd<T>), dim3(nblocks(M * g.Cout)), dim3(256), 0, st, p);
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
+    const size_t need = fwd_pack_bytes(g, dt);
+    if (!ws || ws_bytes < need) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+    const int ce = ce_of(dt), Cp = round_up(g.Cin, ce), ntaps = g.KH * g.KW;
+    PackParams pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.w = w; pk.out = ws; pk.KW = g.KW; pk.Cin = g.Cin; pk.Cout = g.Cout; pk.rows = g.Cout; pk.Cp = Cp; pk.ntaps = ntaps; pk.mode = 0;
+    GemmNTParams p;
+    memset(&p, 0, sizeof(p));
+    for (int r = 0; r < g.KH; ++r)
+        for (int s = 0; s < g.KW; ++s) {
+            const int t = r * g.KW + s;
+            pk.tr[t] = (signed char)r; pk.ts[t] = (signed char)s;
+            p.tdy[t] = (signed char)(r * g.DH - g.pT);
+            p.tdx[t] = (signed char)(s * g.DW - g.pL);
+        }
+    int rc = launch_pack<T>(pk, st);
+    if (rc) return rc;
+    p.in = x; p.wt = ws; p.out = y; p.bias = bias;
+    p.M = (int)M; p.OH = g.OH; p.OW = g.OW; p.IH = g.H; p.IW = g.W; p.Cs = g.xcs;
+    p.cpt = Cp / ce; p.ntaps = ntaps; p.nchunks = ntaps * p.cpt; p.sy = g.SH; p.sx = g.SW; p.Nn = g.Cout;
+    p.OHf = g.OH; p.OWf = g.OW; p.ldo = g.Cout; p.osy = 1; p.osx = 1; p.oy0 = 0; p.ox0 = 0; p.accumulate = 0;
+    p.in_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(T));
+    p.wt_bytes = (unsigned)((size_t)g.Cout * ntaps * Cp * sizeof(T));
+    const bool linear = ntaps == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
+    return launch_nt<T>(p, !linear, st);
+}
+
+extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const float* bias, void* y, const mcn_conv_geom* gg, mcn_dtype dtype,
+                              mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd: only NHWC activations (convert with mcn_input_prep)");
+    if (!x || !w || !y) MCN_FAIL(MCN_E_BADARG, "conv2d_fwd: null pointer");
+    if (bias && g.Cout % 4) {
+        if (mfma_path_ok(g, dtype)) MCN_FAIL(MCN_E_BADARG, "conv2d_fwd: internal: bias with Cout%%4");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, bias, y, g, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, bias, y, g, dtype, ws, ws_bytes, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd: dtype %d unsupported (fp16 reserved; use bf16)", (int)dtype);
+}
+
+// ---- dgrad -----------------------------------------------------------------------------------------------
+static inline int pos_mod(int a, int m) { return ((a % m) + m) % m; }
+
+template <typename T>
+static int conv_dgrad_t(const void* dy, const float* w, void* dx, const Geo& g, int accumulate, mcn_dtype dt, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
+    const long Min = (long)g.N * g.H * g.W;
+    if (Min == 0) return MCN_OK;
+    if (!mfma_dgrad_ok(g, dt)) {
+        NaiveConvParams p = naive_params(g);
+        p.dy = dy; p.w = w; p.dx = dx; p.accumulate = accumulate;
+        hipLaunchKernelGGL((naive_conv_dgrad<T>), dim3(nblocks(Min * g.Cin)), dim3(256), 0, st, p);
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
+    const size_t need = dgrad_pack_bytes(g, dt);
+    if (!ws || ws_bytes < need) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, need);
+    const int ce = ce_of(dt), Cp = round_up(g.Cout, ce);
+
+    // one exact sub-convolution per stride-parity class of dx
+    struct Cls { int py, px, nt; signed char r[MCN_MAX_TAPS], s[MCN_MAX_TAPS], dy[MCN_MAX_TAPS], dx[MCN_MAX_TAPS]; };
+    bool any_empty = false;
+    Cls* cls = (Cls*)alloca(sizeof(Cls) * g.SH * g.SW);
+    int ncls = 0;
+    for (int py = 0; py < g.SH; ++py)
+        for (int px = 0; px < g.SW; ++px) {
+            if (py >= g.H || px >= g.W) continue;
+            Cls& c = cls[ncls];
+            c.py = py; c.px = px; c.nt = 0;
+            for (int r = 0; r < g.KH; ++r) {
+                const int ty = py + g.pT - r * g.DH;
+                if (pos_mod(ty, g.SH)) continue;
+                for (int s = 0; s < g.KW; ++s) {
+                    const int tx = px + g.pL - s * g.DW;
+                    if (pos_mod(tx, g.SW)) continue;
+                    c.r[c.nt] = (signed char)r; c.s[c.nt] = (signed char)s;
+                    c.dy[c.nt] = (signed char)(ty / g.SH); c.dx[c.nt] = (signed char)(tx / g.SW);
+                    c.nt++;
+                }
+            }
+            if (c.nt == 0) any_empty = true; else ncls++;
+        }
+    if (any_empty && !accumulate) {
+        if (hipMemsetAsync(dx, 0, (size_t)Min * g.Cin * sizeof(T), st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "conv2d_dgrad: memset failed");
+    }
+    char* wsp = (char*)ws;
+    for (int k = 0; k < ncls; ++k) {
+        const Cls& c = cls[k];
+        const int OHs = (g.H - c.py + g.SH - 1) / g.SH, OWs = (g.W - c.px + g.SW - 1) / g.SW;
+        PackParams pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.w = w; pk.out = wsp; pk.KW = g.KW; pk.Cin = g.Cin; pk.Cout = g.Cout; pk.rows = g.Cin; pk.Cp = Cp; pk.ntaps = c.nt; pk.mode = 1;
+        GemmNTParams p;
+        memset(&p, 0, sizeof(p));
+        bool zero_off = true;
+        for (int t = 0; t < c.nt; ++t) {
+            pk.tr[t] = c.r[t]; pk.ts[t] = c.s[t];
+            p.tdy[t] = c.dy[t]; p.tdx[t] = c.dx[t];
+            if (c.dy[t] || c.dx[t]) zero_off = false;
+        }
+        int rc = launch_pack<T>(pk, st);
+        if (rc) return rc;
+        p.in = dy; p.wt = wsp; p.out = dx; p.bias = nullptr;
+        p.M = g.N * OHs * OWs; p.OH = OHs; p.OW = OWs; p.IH = g.OH; p.IW = g.OW; p.Cs = g.Cout;
+        p.cpt = Cp / ce; p.ntaps = c.nt; p.nchunks = c.nt * p.cpt; p.sy = 1; p.sx = 1; p.Nn = g.Cin;
+        p.OHf = g.H; p.OWf = g.W; p.ldo = g.Cin; p.osy = g.SH; p.osx = g.SW; p.oy0 = c.py; p.ox0 = c.px; p.accumulate = accumulate;
+        p.in_bytes = (unsigned)((size_t)g.N * g.OH * g.OW * g.Cout * sizeof(T));
+        p.wt_bytes = (unsigned)((size_t)g.Cin * c.nt * Cp * sizeof(T));
+        const bool linear = c.nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
+        rc = launch_nt<T>(p, !linear, st);
+        if (rc) return rc;
+        wsp += align_up((size_t)g.Cin * c.nt * Cp * sizeof(T), 256);
+    }
+    return MCN_OK;
+}
+
+extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, void* dx, const mcn_conv_geom* gg, int accumulate, mcn_dtype dtype,
+                                mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: only NHWC activations");
+    if (!dy || !w || !dx) MCN_FAIL(MCN_E_BADARG, "conv2d_dgrad: null pointer");
+    if (g.xcs != g.Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: dx must be dense (x_cs == Cin)");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, dx, g, accumulate, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_BF16) return conv_dgrad_t<bf16_t>(dy, w, dx, g, accumulate, dtype, ws, ws_bytes, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: dtype %d unsupported", (int)dtype);
+}
+
+// ---- wgrad -----------------------------------------------------------------------------------------------
+template <typename T>
+static int colsum_t(const void* x, float* out, long M, int C, float scale, void* ws, hipStream_t st) {
+    const int parts = (int)colsum_parts(M);
+    const int rpb = (int)((M + parts - 1) / parts);
+    float* part = (float*)ws;
+    const dim3 grid((C + 255) / 256, parts);
+    hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, st, (const T*)x, part, M, C, rpb);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part, out, parts, C, scale);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+template <typename T>
+static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, const Geo& g, float scale, mcn_dtype dt, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
+    const long M = (long)g.N * g.OH * g.OW;
+    const size_t need = wgrad_ws_bytes(g, dt);
+    if (need && (!ws || ws_bytes < need)) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    char* wsp = (char*)ws;
+    if (!mfma_path_ok(g, dt)) {
+        NaiveConvParams p = naive_params(g);
+        p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
+        hipLaunchKernelGGL((naive_conv_wgrad<T>), dim3(nblocks((long)g.KH * g.KW * g.Cin * g.Cout)), dim3(256), 0, st, p);
+        MCN_CHECK_LAUNCH();
+    } else {
+        int nsteps, sps;
+        const int splits = wgrad_splits(g, dt, &nsteps, &sps);
+        const int ce = ce_of(dt), Cp = round_up(g.Cin, ce), ntaps = g.KH * g.KW;
+        GemmTNParams p;
+        memset(&p, 0, sizeof(p));
+        for (int r = 0; r < g.KH; ++r)
+            for (int s = 0; s < g.KW; ++s) {
+                p.tdy[r * g.KW + s] = (signed char)(r * g.DH - g.pT);
+                p.tdx[r * g.KW + s] = (signed char)(s * g.DW - g.pL);
+            }
+        p.x = x; p.dy = dy; p.slab = (float*)wsp;
+        p.M = (int)M; p.OH = g.OH; p.OW = g.OW; p.IH = g.H; p.IW = g.W; p.Cs = g.xcs; p.Cp = Cp; p.ntaps = ntaps; p.rows = ntaps * Cp;
+        p.sy = g.SH; p.sx = g.SW; p.Nn = g.Cout; p.ldy = g.Cout; p.nsteps = nsteps; p.steps_per_split = sps;
+        p.x_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(T));
+        p.dy_bytes = (unsigned)((size_t)M * g.Cout * sizeof(T));
+        const bool linear = ntaps == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
+        if (M > 0) {
+            int rc = launch_tn<T>(p, linear, splits, st);
+            if (rc) return rc;
+        }
+        const long total = (long)ntaps * g.Cin * g.Cout;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks(total, 2048)), dim3(256), 0, st, (const float*)wsp, dw, M > 0 ? splits : 0, ntaps,
+                           Cp, g.Cin, g.Cout, scale);
+        MCN_CHECK_LAUNCH();
+        wsp += align_up((size_t)splits * p.rows * g.Cout * 4, 256);
+    }
+    if (dbias) return colsum_t<T>(dy, dbias, M, g.Cout, scale, wsp, st);
+    return MCN_OK;
+}
+
+extern "C" int mcn_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, const mcn_conv_geom* gg, float grad_scale,
+                                mcn_dtype dtype, mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_wgrad: only NHWC activations");
+    if (!x || !dy || !dw) MCN_FAIL(MCN_E_BADARG, "conv2d_wgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_wgrad_t<float>(x, dy, dw, dbias, g, grad_scale, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_BF16) return conv_wgrad_t<bf16_t>(x, dy, dw, dbias, g, grad_scale, dtype, ws, ws_bytes, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_wgrad: dtype %d unsupported", (int)dtype);
+}
+
+// ---- fully connected = 1x1 convolution on a [B][1][1][In] tensor ------------------------------------------
+static mcn_conv_geom fc_geom(int B, int In, int Out) {
+    mcn_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = B; g.H = 1; g.W = 1; g.Cin = In; g.Cout = Out; g.KH = g.KW = g.SH = g.SW = g.DH = g.DW = 1;
+    return g;
+}
+extern "C" size_t mcn_fc_workspace_bytes(int32_t B, int32_t In, int32_t Out, mcn_dtype dtype) {
+    const mcn_conv_geom g = fc_geom(B, In, Out);
+    size_t a = mcn_conv2d_workspace_bytes(MCN_CONV_FWD, &g, dtype);
+    size_t b = mcn_conv2d_workspace_bytes(MCN_CONV_DGRAD, &g, dtype);
+    size_t c = mcn_conv2d_workspace_bytes(MCN_CONV_WGRAD, &g, dtype);
+    size_t m = a > b ? a : b;
+    return m > c ? m : c;
+}
+extern "C" int mcn_fc_fwd(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t In, int32_t Out, mcn_dtype dtype,
+                          void* ws, size_t ws_bytes, void* stream) {
+    const mcn_conv_geom g = fc_geom(B, In, Out);
+    return mcn_conv2d_fwd(x, w, bias, y, &g, dtype, MCN_NHWC, ws, ws_bytes, stream);
+}
+extern "C" int mcn_fc_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias, float grad_scale, int32_t B,
+                          int32_t In, int32_t Out, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    const mcn_conv_geom g = fc_geom(B, In, Out);
+    int rc = MCN_OK;
+    if (dx) rc = mcn_conv2d_dgrad(dy, w, dx, &g, 0, dtype, MCN_NHWC, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (dw) rc = mcn_conv2d_wgrad(x, dy, dw, dbias, &g, grad_scale, dtype, MCN_NHWC, ws, ws_bytes, stream);
+    return rc;
+}

@@ -1,0 +1,705 @@
+// conv_kernels.h — device kernels for conv2d fwd / dgrad / wgrad on gfx950.
+//
+// Two MFMA kernels cover every convolution of the path:
+//
+//  * conv_gemm_nt : OUT[m][n] (+)= sum_k A[m][k] * Bt[n][k]
+//      m = output pixel of a (sub-)grid, k = (tap, channel), A gathered on the fly from an NHWC
+//      tensor through a per-tap (dy,dx) table with hardware bounds-checked buffer loads (padding
+//      = out-of-range => 0), Bt = weights pre-packed K-contiguous.  Used for the forward pass
+//      (A = x, taps = filter taps) and for dgrad (A = dy, taps = the filter taps that reach one
+//      stride-parity class of dx; stride-2 dgrad is 4 exact sub-convolutions, no wasted MACs).
+//  * conv_gemm_tn : DW[(tap,c)][n] = sum_m X[pix(m,tap)][c] * DY[m][n]   (split over m)
+//      both operands are pixel-major in memory, i.e. the reduction index is the slow one; bf16
+//      fragments come from LDS through ds_read_b64_tr_b16, fp32 through conflict-free b32 reads.
+//
+// Tiles are staged as 16-byte chunks (8 bf16 / 4 fp32) into XOR-swizzled LDS images with
+// register prefetch of the next K-step (global loads in flight under the MFMAs) and a
+// double-buffered LDS so one barrier per K-step suffices.  bf16 uses v_mfma_f32_16x16x32_bf16,
+// fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32; no TF32 on gfx950).  Operand order is
+// (weights, activations) so that each lane ends with 4 consecutive output channels of one pixel
+// => 8/16-byte epilogue stores.
+#pragma once
+#include "common.h"
+
+#define MCN_MAX_TAPS 64
+#define MCN_OOB 0x80000000u
+
+struct GemmNTParams {
+    const void* in;
+    const void* wt;
+    void* out;
+    const float* bias;
+    int M, OH, OW;          // GEMM rows = N*OH*OW of the (sub-)grid
+    int IH, IW, Cs;         // gathered tensor: spatial dims, channel stride (elements)
+    int cpt;                // 16-byte chunks per tap
+    int ntaps;
+    int nchunks;            // ntaps*cpt
+    int sy, sx;             // gathered-tensor step per grid step
+    int Nn;                 // GEMM N
+    int OWf, OHf, ldo;      // full output grid (pixels) and channel stride
+    int osy, osx, oy0, ox0; // scatter of the sub-grid into the full output grid
+    int accumulate;
+    unsigned in_bytes, wt_bytes;
+    signed char tdy[MCN_MAX_TAPS];
+    signed char tdx[MCN_MAX_TAPS];
+};
+
+struct GemmTNParams {
+    const void* x;
+    const void* dy;
+    float* slab;            // [splits][rows][Nn]
+    int M, OH, OW;
+    int IH, IW, Cs;
+    int Cp;                 // channels per tap (padded to chunk)
+    int ntaps;
+    int rows;               // ntaps*Cp
+    int sy, sx;
+    int Nn, ldy;
+    int nsteps, steps_per_split;
+    unsigned x_bytes, dy_bytes;
+    signed char tdy[MCN_MAX_TAPS];
+    signed char tdx[MCN_MAX_TAPS];
+};
+
+__device__ __forceinline__ i32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA policies
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct MmaNT;
+
+// bf16: 16x16x32, K-step = 64 elements = 2 slabs; fragment = one 16-byte chunk
+template <>
+struct MmaNT<bf16_t> {
+    static constexpr int MT = 16;       // tile edge
+    static constexpr int SLABS = 2;     // per 128-byte K-step
+    static constexpr int CPS = 4;       // chunks per slab
+    typedef f32x4 Acc;
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int frag_chunk(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ void mma(Acc& acc, const Frag& w, const Frag& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+    }
+};
+// fp32: 32x32x2; a 16-byte fragment (4 consecutive k) feeds 4 MFMAs (k pairs {e, 4+e})
+template <>
+struct MmaNT<float> {
+    static constexpr int MT = 32;
+    static constexpr int SLABS = 4;
+    static constexpr int CPS = 2;
+    typedef f32x16 Acc;
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int frag_chunk(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ void mma(Acc& acc, const Frag& w, const Frag& x) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+    }
+};
+
+// LDS image of an NT tile: rows of 128 bytes, 16-byte chunk c of row r at r*128 + ((c ^ ((r>>1)&7))<<4)
+__device__ __forceinline__ int nt_lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_nt
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, bool TAPS>
+__global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
+    typedef MmaNT<T> MM;
+    constexpr int CE = VecTraits<T>::CE;
+    constexpr int AR = BM / 32, BR = BN / 32;          // staged chunks per thread
+    constexpr int WTM = BM / 2, WTN = BN / 2;          // wave tile (2x2 waves)
+    constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ signed char s_tdy[MCN_MAX_TAPS], s_tdx[MCN_MAX_TAPS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (L / ntn) * BM, n0 = (L % ntn) * BN;
+
+    if (TAPS) {
+        if (tid < MCN_MAX_TAPS) {
+            s_tdy[tid] = p.tdy[tid];
+            s_tdx[tid] = p.tdx[tid];
+        }
+        __syncthreads();
+    }
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
+
+    const int crow = tid >> 3, cid = tid & 7;
+    // per-thread A rows
+    int a_base[AR], a_y[AR], a_x[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + crow + 32 * i;
+        if (m < p.M) {
+            if (TAPS) {
+                const int hw = p.OH * p.OW;
+                const int img = m / hw, rem = m - img * hw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                a_base[i] = img * p.IH * p.IW;
+                a_y[i] = oy * p.sy;
+                a_x[i] = ox * p.sx;
+            } else {
+                a_base[i] = m;   // plain [M][Cs] matrix (1x1, stride folded by the host)
+                a_y[i] = 0;
+                a_x[i] = 0;
+            }
+        } else {
+            a_base[i] = -1;
+            a_y[i] = 0;
+            a_x[i] = 0;
+        }
+    }
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + crow + 32 * i;
+        b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u : MCN_OOB;
+    }
+    const int wr_off = crow * 128 + ((cid ^ ((crow >> 1) & 7)) << 4);
+
+    i32x4 ra[AR], rb[BR];
+    auto issue = [&](int ks) {
+        const int j = ks * 8 + cid;
+        const bool kv = j < p.nchunks;
+        int tap = 0, cc = j;
+        int dy = 0, dx = 0;
+        if (TAPS) {
+            tap = j / p.cpt;
+            cc = j - tap * p.cpt;
+            const int tt = kv ? tap : 0;
+            dy = s_tdy[tt];
+            dx = s_tdx[tt];
+        }
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            unsigned off = MCN_OOB;
+            if (TAPS) {
+                const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                const bool ok = kv && a_base[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+                if (ok) off = ((unsigned)(a_base[i] + iy * p.IW + ix) * (unsigned)p.Cs + (unsigned)cc * CE) * (unsigned)sizeof(T);
+            } else {
+                if (kv && a_base[i] >= 0) off = ((unsigned)a_base[i] * (unsigned)p.Cs + (unsigned)cc * CE) * (unsigned)sizeof(T);
+            }
+            ra[i] = buf_load16(rsA, off);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const unsigned off = (kv && b_off[i] != MCN_OOB) ? b_off[i] + (unsigned)j * 16u : MCN_OOB;
+            rb[i] = buf_load16(rsB, off);
+        }
+    };
+    auto commit = [&](int buf) {
+        char* a = smem + buf * TILE_BYTES;
+        char* b = a + BM * 128;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<i32x4*>(a + wr_off + i * 32 * 128) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<i32x4*>(b + wr_off + i * 32 * 128) = rb[i];
+    };
+
+    typename MM::Acc acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < (int)(sizeof(typename MM::Acc) / 4); ++e) acc[j][i][e] = 0.f;
+
+    const int fr = MM::frag_row(lane), fc = MM::frag_chunk(lane);
+    const int fsw = (fr >> 1) & 7;   // tile rows start at multiples of 16 => swizzle key depends on the lane only
+    const int a_rd = (wm * WTM + fr) * 128;
+    const int b_rd = BM * 128 + (wn * WTN + fr) * 128;
+
+    const int nk = (p.nchunks + 7) >> 3;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) issue(ks + 1);
+        const char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < MM::SLABS; ++s) {
+            const int coff = (((s * MM::CPS + fc) ^ fsw) << 4);
+            typename MM::Frag xa[TM], wb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const typename MM::Frag*>(base + a_rd + i * MM::MT * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const typename MM::Frag*>(base + b_rd + j * MM::MT * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[j], xa[i]);
+        }
+        if (ks + 1 < nk) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds 4 consecutive output channels of one pixel per register group ----
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * MM::MT + fr;
+        if (m >= p.M) continue;
+        long pix;
+        if (TAPS || p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf) {
+            const int hw = p.OH * p.OW;
+            const int img = m / hw, rem = m - img * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            pix = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
+        } else {
+            pix = m;
+        }
+        T* orow = out + pix * p.ldo;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
+                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                const int n = n0 + wn * WTN + j * MM::MT + nl;
+                if (n >= p.Nn) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e];
+                if (p.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                if (sizeof(T) == 4) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(orow + n);
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) {
+                        const f32x4 old = *dst;
+                        o += old;
+                    }
+                    *dst = o;
+                } else {
+                    bf16x4* dst = reinterpret_cast<bf16x4*>(orow + n);
+                    if (p.accumulate) {
+                        const bf16x4 old = *dst;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+                    }
+                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *dst = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_tn (wgrad): tile = 128 rows of (tap,c) x BN columns (cout), reduction over pixels
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct TNCfg;
+template <>
+struct TNCfg<bf16_t> {
+    static constexpr int KP = 64;       // pixels per K-step
+    static constexpr int MT = 16;
+};
+template <>
+struct TNCfg<float> {
+    static constexpr int KP = 32;
+    static constexpr int MT = 32;
+};
+
+// bf16 pixel-major tile: row stride RS bytes, 32-byte granule g of pixel row p stored at granule g ^ key(p)
+__device__ __forceinline__ int tn_key(int p) { return (p & 3) | (((p >> 3) & 1) << 2); }
+
+template <typename T, int BN, bool LINEAR>
+__global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
+    typedef TNCfg<T> CF;
+    constexpr int CE = VecTraits<T>::CE;
+    constexpr int BR = 128;
+    constexpr int KP = CF::KP;
+    constexpr int XRS = BR * (int)sizeof(T);           // X tile row stride (bytes): 256 / 512
+    constexpr int DRS = BN * (int)sizeof(T);
+    constexpr int XCPR = BR / CE, DCPR = BN / CE;      // chunks per pixel row
+    constexpr int XPR = 256 / XCPR, DPR = 256 / DCPR;  // pixel rows per staging pass
+    constexpr int XN = KP / XPR, DN = KP / DPR;        // chunks per thread
+    constexpr int XBYTES = KP * XRS, DBYTES = KP * DRS;
+    constexpr int TILE_BYTES = XBYTES + DBYTES;
+    constexpr int WTR = 64, WTN = BN / 2;
+    constexpr int TR = WTR / CF::MT, TNn = WTN / CF::MT;
+    constexpr int DGM = (DRS / 32) - 1;                // granule mask of the D tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int r0 = (blockIdx.x / ntn) * BR, n0 = (blockIdx.x % ntn) * BN;
+    const int split = blockIdx.y;
+    const int ks0 = split * p.steps_per_split;
+    const int ks1 = min(p.nsteps, ks0 + p.steps_per_split);
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+    // ---- X staging: fixed column (tap, c) per thread, XN pixel rows -------------------------
+    const int xcc = tid % XCPR, xpr = tid / XCPR;
+    const int gcol = r0 + xcc * CE;
+    const bool xcol_ok = gcol < p.rows;
+    int xt = 0, xc = gcol;
+    if (!LINEAR && xcol_ok) {
+        xt = gcol / p.Cp;
+        xc = gcol - xt * p.Cp;
+    }
+    const int tdy = p.tdy[xt], tdx = p.tdx[xt];
+    int px[XN], py[XN], pimg[XN];
+    int dKx = 0, dKy = 0, dKi = 0;
+    if (!LINEAR) {
+        const int hw = p.OH * p.OW;
+        dKi = KP / hw;
+        const int rem = KP - dKi * hw;
+        dKy = rem / p.OW;
+        dKx = rem - dKy * p.OW;
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int m = ks0 * KP + xpr + XPR * i;
+            const int img = m / hw, r = m - img * hw;
+            pimg[i] = img;
+            py[i] = r / p.OW;
+            px[i] = r - py[i] * p.OW;
+        }
+    }
+    // ---- D staging ---------------------------------------------------------------------------
+    const int dcc = tid % DCPR, dpr = tid / DCPR;
+    const int dn = n0 + dcc * CE;
+    const bool dcol_ok = dn < p.Nn;
+
+    i32x4 rx[XN], rd[DN];
+    auto issue = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int m = ks * KP + xpr + XPR * i;
+            unsigned off = MCN_OOB;
+            if (LINEAR) {
+                if (xcol_ok && m < p.M) off = ((unsigned)m * (unsigned)p.Cs + (unsigned)xc) * (unsigned)sizeof(T);
+            } else {
+                const int iy = py[i] * p.sy + tdy, ix = px[i] * p.sx + tdx;
+                if (xcol_ok && m < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+                    off = ((unsigned)((pimg[i] * p.IH + iy) * p.IW + ix) * (unsigned)p.Cs + (unsigned)xc) * (unsigned)sizeof(T);
+                // advance this row's pixel coordinates by KP for the next step
+                px[i] += dKx;
+                if (px[i] >= p.OW) { px[i] -= p.OW; py[i] += 1; }
+                py[i] += dKy;
+                if (py[i] >= p.OH) { py[i] -= p.OH; pimg[i] += 1; }
+                pimg[i] += dKi;
+            }
+            rx[i] = buf_load16(rsX, off);
+        }
+#pragma unroll
+        for (int i = 0; i < DN; ++i) {
+            const int m = ks * KP + dpr + DPR * i;
+            unsigned off = MCN_OOB;
+            if (dcol_ok && m < p.M) off = ((unsigned)m * (unsigned)p.ldy + (unsigned)dn) * (unsigned)sizeof(T);
+            rd[i] = buf_load16(rsD, off);
+        }
+    };
+    auto commit = [&](int buf) {
+        char* xs = smem + buf * TILE_BYTES;
+        char* ds = xs + XBYTES;
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int pr = xpr + XPR * i;
+            int off;
+            if (sizeof(T) == 2) off = pr * XRS + ((((xcc >> 1) ^ tn_key(pr))) << 5) + ((xcc & 1) << 4);
+            else off = pr * XRS + xcc * 16;
+            *reinterpret_cast<i32x4*>(xs + off) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < DN; ++i) {
+            const int pr = dpr + DPR * i;
+            int off;
+            if (sizeof(T) == 2) off = pr * DRS + ((((dcc >> 1) ^ (tn_key(pr) & DGM))) << 5) + ((dcc & 1) << 4);
+            else off = pr * DRS + dcc * 16;
+            *reinterpret_cast<i32x4*>(ds + off) = rd[i];
+        }
+    };
+
+    constexpr int ACCN = CF::MT == 16 ? 4 : 16;
+    float acc[TR][TNn][ACCN];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TNn; ++j)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) acc[i][j][e] = 0.f;
+
+    if (ks0 < ks1) {
+        issue(ks0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int buf = (ks - ks0) & 1;
+        if (ks + 1 < ks1) issue(ks + 1);
+        const char* xs = smem + buf * TILE_BYTES;
+        const char* ds = xs + XBYTES;
+        if constexpr (sizeof(T) == 2) {
+            // bf16: 16x16x32; operand rows come from transposing reads of the pixel-major tiles
+            const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+#pragma unroll
+            for (int s = 0; s < KP / 32; ++s) {
+                bf16x8 xa[TR], db[TNn];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pix = 32 * s + 8 * g + 4 * h + q;
+                    const int key = tn_key(pix);
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {
+                        const int gran = wr * 4 + i;
+                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(xs + pix * XRS + ((gran ^ key) << 5) + 8 * pp));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xa[i][4 * h + e] = __builtin_bit_cast(bf16_t, v[e]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TNn; ++j) {
+                        const int gran = wc * (WTN / 16) + j;
+                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(ds + pix * DRS + ((gran ^ (key & DGM)) << 5) + 8 * pp));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) db[j][4 * h + e] = __builtin_bit_cast(bf16_t, v[e]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNn; ++j) {
+                        f32x4 a = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], db[j], a, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] = a[e];
+                    }
+            }
+        } else {
+            // fp32: 32x32x2; lane (i = lane&31, k = lane>>5) reads one float per operand
+            const int li = lane & 31, kh = lane >> 5;
+#pragma unroll 4
+            for (int pp = 0; pp < KP / 2; ++pp) {
+                const int pix = 2 * pp + kh;
+                float xa[TR], db[TNn];
+#pragma unroll
+                for (int i = 0; i < TR; ++i) xa[i] = *reinterpret_cast<const float*>(xs + pix * XRS + (wr * WTR + i * 32 + li) * 4);
+#pragma unroll
+                for (int j = 0; j < TNn; ++j) db[j] = *reinterpret_cast<const float*>(ds + pix * DRS + (wc * WTN + j * 32 + li) * 4);
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNn; ++j) {
+                        f32x16 a;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) a[e] = acc[i][j][e];
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], db[j], a, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = a[e];
+                    }
+            }
+        }
+        if (ks + 1 < ks1) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- store the partial tile to this split's slab (row-major [rows][Nn]) --------------------
+    float* slab = p.slab + (size_t)split * p.rows * p.Nn;
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TNn; ++j)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
+                int row, col;
+                if (CF::MT == 16) {
+                    row = (lane >> 4) * 4 + e;
+                    col = lane & 15;
+                } else {
+                    row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    col = lane & 31;
+                }
+                const int r = r0 + wr * WTR + i * CF::MT + row;
+                const int n = n0 + wc * WTN + j * CF::MT + col;
+                if (r < p.rows && n < p.Nn) slab[(size_t)r * p.Nn + n] = acc[i][j][e];
+            }
+}
+
+// dw[t][c][n] = scale * sum_split slab[split][t*Cp + c][n]   (c < Cin)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int ntaps, int Cp,
+                                    int Cin, int Nn, float scale) {
+    const long total = (long)ntaps * Cin * Nn;
+    const long rowsNn = (long)ntaps * Cp * Nn;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % Nn);
+        const long tc = idx / Nn;
+        const int c = (int)(tc % Cin), t = (int)(tc / Cin);
+        const long src = ((long)t * Cp + c) * Nn + n;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(long)k * rowsNn + src];
+        dw[idx] = s * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 HWIO master -> K-contiguous operand in the compute dtype
+//   mode 0 (fwd)  : out[n][t*Cp + c] = w[r_t][s_t][c][n]      rows = Cout, per-tap width Cp >= Cin
+//   mode 1 (dgrad): out[c][t*Cp + k] = w[r_t][s_t][c][k]      rows = Cin,  per-tap width Cp >= Cout
+// ------------------------------------------------------------------------------------------------
+struct PackParams {
+    const float* w;
+    void* out;
+    int KW, Cin, Cout, rows, Cp, ntaps, mode;
+    signed char tr[MCN_MAX_TAPS], ts[MCN_MAX_TAPS];
+};
+template <typename T>
+__global__ void pack_weights_kernel(const PackParams p) {
+    const long total = (long)p.rows * p.ntaps * p.Cp;
+    T* out = reinterpret_cast<T*>(p.out);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % p.Cp);
+        const long rt = idx / p.Cp;
+        const int t = (int)(rt % p.ntaps), row = (int)(rt / p.ntaps);
+        const int r = p.tr[t], s = p.ts[t];
+        float v = 0.f;
+        if (p.mode == 0) {
+            if (col < p.Cin) v = p.w[(((long)r * p.KW + s) * p.Cin + col) * p.Cout + row];
+        } else {
+            if (col < p.Cout) v = p.w[(((long)r * p.KW + s) * p.Cin + row) * p.Cout + col];
+        }
+        out[idx] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// naive fallbacks (any channel count; also an in-library cross-check of the MFMA path)
+// ------------------------------------------------------------------------------------------------
+struct NaiveConvParams {
+    const void* x;
+    const float* w;
+    const void* dy;
+    void* y;
+    void* dx;
+    float* dw;
+    const float* bias;
+    int N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, padT, padL, OH, OW, x_cs;
+    int accumulate;
+    float scale;
+};
+template <typename T>
+__global__ void naive_conv_fwd(const NaiveConvParams p) {
+    const long total = (long)p.N * p.OH * p.OW * p.Cout;
+    const T* x = reinterpret_cast<const T*>(p.x);
+    T* y = reinterpret_cast<T*>(p.y);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % p.Cout);
+        long r = idx / p.Cout;
+        const int ox = (int)(r % p.OW);
+        r /= p.OW;
+        const int oy = (int)(r % p.OH), n = (int)(r / p.OH);
+        float acc = 0.f;
+        for (int kr = 0; kr < p.KH; ++kr) {
+            const int iy = oy * p.SH + kr * p.DH - p.padT;
+            if (iy < 0 || iy >= p.H) continue;
+            for (int ks = 0; ks < p.KW; ++ks) {
+                const int ix = ox * p.SW + ks * p.DW - p.padL;
+                if (ix < 0 || ix >= p.W) continue;
+                const T* xp = x + (((long)n * p.H + iy) * p.W + ix) * p.x_cs;
+                const float* wp = p.w + ((long)(kr * p.KW + ks) * p.Cin) * p.Cout + k;
+                for (int c = 0; c < p.Cin; ++c) acc = fmaf(to_f32(xp[c]), to_f32(from_f32<T>(wp[(long)c * p.Cout])), acc);
+            }
+        }
+        if (p.bias) acc += p.bias[k];
+        y[idx] = from_f32<T>(acc);
+    }
+}
+template <typename T>
+__global__ void naive_conv_dgrad(const NaiveConvParams p) {
+    const long total = (long)p.N * p.H * p.W * p.Cin;
+    const T* dy = reinterpret_cast<const T*>(p.dy);
+    T* dx = reinterpret_cast<T*>(p.dx);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % p.Cin);
+        long r = idx / p.Cin;
+        const int ix = (int)(r % p.W);
+        r /= p.W;
+        const int iy = (int)(r % p.H), n = (int)(r / p.H);
+        float acc = 0.f;
+        for (int kr = 0; kr < p.KH; ++kr) {
+            const int ty = iy + p.padT - kr * p.DH;
+            if (ty < 0 || ty % p.SH) continue;
+            const int oy = ty / p.SH;
+            if (oy >= p.OH) continue;
+            for (int ks = 0; ks < p.KW; ++ks) {
+                const int tx = ix + p.padL - ks * p.DW;
+                if (tx < 0 || tx % p.SW) continue;
+                const int ox = tx / p.SW;
+                if (ox >= p.OW) continue;
+                const T* dp = dy + (((long)n * p.OH + oy) * p.OW + ox) * p.Cout;
+                const float* wp = p.w + ((long)(kr * p.KW + ks) * p.Cin + c) * p.Cout;
+                for (int k = 0; k < p.Cout; ++k) acc = fmaf(to_f32(dp[k]), to_f32(from_f32<T>(wp[k])), acc);
+            }
+        }
+        if (p.accumulate) acc += to_f32(dx[idx]);
+        dx[idx] = from_f32<T>(acc);
+    }
+}
+template <typename T>
+__global__ void naive_conv_wgrad(const NaiveConvParams p) {
+    const long total = (long)p.KH * p.KW * p.Cin * p.Cout;
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* dy = reinterpret_cast<const T*>(p.dy);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % p.Cout);
+        long r = idx / p.Cout;
+        const int c = (int)(r % p.Cin);
+        r /= p.Cin;
+        const int ks = (int)(r % p.KW), kr = (int)(r / p.KW);
+        float acc = 0.f;
+        for (int n = 0; n < p.N; ++n)
+            for (int oy = 0; oy < p.OH; ++oy) {
+                const int iy = oy * p.SH + kr * p.DH - p.padT;
+                if (iy < 0 || iy >= p.H) continue;
+                for (int ox = 0; ox < p.OW; ++ox) {
+                    const int ix = ox * p.SW + ks * p.DW - p.padL;
+                    if (ix < 0 || ix >= p.W) continue;
+                    acc = fmaf(to_f32(x[(((long)n * p.H + iy) * p.W + ix) * p.x_cs + c]),
+                               to_f32(dy[(((long)n * p.OH + oy) * p.OW + ox) * p.Cout + k]), acc);
+                }
+            }
+        p.dw[idx] = acc * p.scale;
+    }
+}
+
+// column sums of a [M][C] matrix -> fp32 [C] (bias gradient); two-stage, deterministic
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C, int rows_per_block) {
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += to_f32(x[r * C + c]);
+        part[(long)blockIdx.y * C + c] = s;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C, float scale) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nparts; ++k) s += part[(long)k * C + c];
+        out[c] = s * scale;
+    }
+}

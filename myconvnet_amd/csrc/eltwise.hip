@@ -1,0 +1,174 @@
+// eltwise.hip — HBM-bound element-wise kernels: ReLU, residual add(+ReLU), gradient accumulation,
+// casts, input preparation, one-hot labels.  16-byte vector accesses (8 bf16 / 4 fp32 per lane),
+// grid-stride loops capped at 256 CUs x 8 blocks.
+#include "common.h"
+
+static inline unsigned ew_blocks(long nvec) {
+    long b = (nvec + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+enum { EW_RELU = 0, EW_RELU_BWD = 1, EW_ADD = 2, EW_ADD_RELU = 3, EW_ACC = 4 };
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n) {
+    constexpr int CE = VecTraits<T>::CE;
+    const long nvec = n / CE;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        Chunk<T> ca = load_chunk<T>(a + i * CE), cb, co;
+        if (OP != EW_RELU) cb = load_chunk<T>(b + i * CE);
+#pragma unroll
+        for (int k = 0; k < CE; ++k) {
+            const float va = ca.get(k);
+            float o;
+            if (OP == EW_RELU) o = fmaxf(va, 0.f);
+            else if (OP == EW_RELU_BWD) o = cb.get(k) > 0.f ? va : 0.f;       // a = dy, b = y
+            else if (OP == EW_ADD || OP == EW_ACC) o = va + cb.get(k);
+            else o = fmaxf(va + cb.get(k), 0.f);
+            co.set(k, o);
+        }
+        store_chunk<T>(y + i * CE, co);
+    }
+    // scalar tail
+    const long t0 = nvec * CE;
+    for (long i = t0 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float va = to_f32(a[i]);
+        float o;
+        if (OP == EW_RELU) o = fmaxf(va, 0.f);
+        else if (OP == EW_RELU_BWD) o = to_f32(b[i]) > 0.f ? va : 0.f;
+        else if (OP == EW_ADD || OP == EW_ACC) o = va + to_f32(b[i]);
+        else o = fmaxf(va + to_f32(b[i]), 0.f);
+        y[i] = from_f32<T>(o);
+    }
+}
+
+template <int OP>
+static int ew_dispatch(const void* a, const void* b, void* y, long n, mcn_dtype dt, hipStream_t st, const char* name) {
+    if (n < 0 || !a || !y) MCN_FAIL(MCN_E_BADARG, "%s: bad argument", name);
+    if (n == 0) return MCN_OK;
+    if (dt == MCN_F32)
+        hipLaunchKernelGGL((ew_kernel<float, OP>), dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, n);
+    else if (dt == MCN_BF16)
+        hipLaunchKernelGGL((ew_kernel<bf16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+    else
+        MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", name, (int)dt);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+extern "C" int mcn_relu_fwd(const void* x, void* y, int64_t n, mcn_dtype dtype, void* stream) {
+    return ew_dispatch<EW_RELU>(x, nullptr, y, n, dtype, (hipStream_t)stream, "relu_fwd");
+}
+extern "C" int mcn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_dtype dtype, void* stream) {
+    if (!y) MCN_FAIL(MCN_E_BADARG, "relu_bwd: null y");
+    return ew_dispatch<EW_RELU_BWD>(dy, y, dx, n, dtype, (hipStream_t)stream, "relu_bwd");
+}
+extern "C" int mcn_add_relu_fwd(const void* a, const void* b, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+    if (!b) MCN_FAIL(MCN_E_BADARG, "add_relu_fwd: null b");
+    if (act == MCN_ACT_RELU) return ew_dispatch<EW_ADD_RELU>(a, b, y, n, dtype, (hipStream_t)stream, "add_relu_fwd");
+    return ew_dispatch<EW_ADD>(a, b, y, n, dtype, (hipStream_t)stream, "add_relu_fwd");
+}
+extern "C" int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+    if (act == MCN_ACT_RELU) {
+        if (!y) MCN_FAIL(MCN_E_BADARG, "add_relu_bwd: null y");
+        return ew_dispatch<EW_RELU_BWD>(dy, y, dx, n, dtype, (hipStream_t)stream, "add_relu_bwd");
+    }
+    if (dx != dy) {
+        if (hipMemcpyAsync(dx, dy, (size_t)n * mcn_dtype_size(dtype), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            MCN_FAIL(MCN_E_LAUNCH, "add_relu_bwd: copy failed");
+    }
+    return MCN_OK;
+}
+extern "C" int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void* stream) {
+    if (!b) MCN_FAIL(MCN_E_BADARG, "accumulate: null b");
+    return ew_dispatch<EW_ACC>(a, b, a, n, dtype, (hipStream_t)stream, "accumulate");
+}
+
+// ---- cast ---------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = to_f32(s[i * 4 + k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[i * 4 + k] = from_f32<D>(v[k]);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = from_f32<D>(to_f32(s[i]));
+}
+extern "C" int mcn_cast(const void* src, mcn_dtype sd, void* dst, mcn_dtype dd, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) MCN_FAIL(MCN_E_BADARG, "cast: bad argument");
+    if (n == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ew_blocks(n / 4 + 1)), block(256);
+    if (sd == MCN_F32 && dd == MCN_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, st, (const float*)src, (bf16_t*)dst, (long)n);
+    else if (sd == MCN_BF16 && dd == MCN_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, (float*)dst, (long)n);
+    else if (sd == dd && (sd == MCN_F32 || sd == MCN_BF16)) {
+        if (hipMemcpyAsync(dst, src, (size_t)n * mcn_dtype_size(sd), hipMemcpyDeviceToDevice, st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "cast: copy failed");
+        return MCN_OK;
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "cast: %d -> %d unsupported", (int)sd, (int)dd);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// ---- input preparation ------------------------------------------------------------------------------------
+// one thread per output pixel: reads C fp32 channels (NHWC: contiguous; NCHW: plane-strided), writes
+// out_cs channels of the compute dtype, zero padded.
+template <typename T, bool NCHW>
+__global__ __launch_bounds__(256) void input_prep_kernel(const float* __restrict__ x, T* __restrict__ y, long npix, int HW, int C, int out_cs,
+                                                         float mean, float scale) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        T* o = y + p * out_cs;
+        const long n = p / HW, r = p - n * HW;
+        for (int c = 0; c < out_cs; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                const float in = NCHW ? x[(n * C + c) * HW + r] : x[p * C + c];
+                v = (in - mean) * scale;
+            }
+            o[c] = from_f32<T>(v);
+        }
+    }
+}
+extern "C" int mcn_input_prep(const float* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t out_cs, float image_mean,
+                              float scale_factor, mcn_layout src_layout, mcn_dtype dtype, void* stream) {
+    if (!x || !y || N < 0 || H <= 0 || W <= 0 || C <= 0 || out_cs < C) MCN_FAIL(MCN_E_BADARG, "input_prep: bad argument");
+    const long npix = (long)N * H * W;
+    if (npix == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ew_blocks(npix)), block(256);
+    const bool nchw = src_layout == MCN_NCHW;
+    if (dtype == MCN_F32) {
+        if (nchw) hipLaunchKernelGGL((input_prep_kernel<float, true>), grid, block, 0, st, x, (float*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
+        else hipLaunchKernelGGL((input_prep_kernel<float, false>), grid, block, 0, st, x, (float*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
+    } else if (dtype == MCN_BF16) {
+        if (nchw) hipLaunchKernelGGL((input_prep_kernel<bf16_t, true>), grid, block, 0, st, x, (bf16_t*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
+        else hipLaunchKernelGGL((input_prep_kernel<bf16_t, false>), grid, block, 0, st, x, (bf16_t*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "input_prep: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+__global__ void one_hot_kernel(const float* __restrict__ labels, float* __restrict__ onehot, int B, int C) {
+    const long total = (long)B * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / C), c = (int)(i - (long)b * C);
+        float l = labels[b];
+        if (l != l) l = -1.f;                 // NaN -> -1 (convnet.py:441-443)
+        const int li = (int)l;                // tf.cast(float -> int32) truncates toward zero
+        onehot[i] = (li == c && l > -1.f) ? 1.f : 0.f;
+    }
+}
+extern "C" int mcn_one_hot(const float* labels, float* onehot, int32_t B, int32_t C, void* stream) {
+    if (!labels || !onehot || B < 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "one_hot: bad argument");
+    if (B == 0) return MCN_OK;
+    hipLaunchKernelGGL(one_hot_kernel, dim3(ew_blocks((long)B * C)), dim3(256), 0, (hipStream_t)stream, labels, onehot, B, C);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}

@@ -1,0 +1,211 @@
+// loss_optim.hip — softmax cross-entropy (fused forward + gradient), L2 regulariser value,
+// fused Nesterov-momentum + L2 + EMA update, EMA / running-statistics helpers.  All fp32.
+#include "common.h"
+
+// one 256-thread block per row; wave shuffles + a 4-entry LDS stage for the row reductions
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+    v = wave_reduce_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+    v = wave_reduce_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, sh[i]);
+    return t;
+}
+
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                           const float* __restrict__ class_w, float* __restrict__ pred,
+                                                           float* __restrict__ ce, float* __restrict__ coef, float* __restrict__ dlogits,
+                                                           int B, int C, float ls, float loss_scale) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    const float* z = logits + (long)b * C;
+    const float* yv = labels + (long)b * C;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, z[c]);
+    mx = block_reduce_max(mx, sh);
+    float se = 0.f, sy = 0.f, bw = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        se += expf(z[c] - mx);
+        const float y = yv[c];
+        sy += y;
+        bw += y * (class_w ? class_w[c] : 1.f);
+    }
+    se = block_reduce_sum(se, sh);
+    sy = block_reduce_sum(sy, sh);
+    bw = block_reduce_sum(bw, sh);
+    const float lse = logf(se);
+    const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
+    const float cf = bw * valid;
+    // smoothed labels: y*(1-ls) + ls/C ; their sum = sy*(1-ls) + ls
+    const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
+    const float gscale = cf * loss_scale / (float)B;
+    float cel = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float lsm = z[c] - mx - lse;
+        const float p = expf(lsm);
+        const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+        cel -= lab * lsm;
+        if (pred) pred[(long)b * C + c] = p;
+        if (dlogits) dlogits[(long)b * C + c] = (p * lab_sum - lab) * gscale;
+    }
+    cel = block_reduce_sum(cel, sh);
+    if (threadIdx.x == 0) {
+        ce[b] = cel;
+        coef[b] = cf;
+    }
+}
+__global__ __launch_bounds__(256) void xent_mean_kernel(const float* __restrict__ ce, const float* __restrict__ coef, float* __restrict__ loss, int B) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) s += ce[i] * coef[i];
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
+}
+extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
+                                        float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing, float loss_scale,
+                                        void* stream) {
+    if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "softmax_xent: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(B), dim3(256), 0, st, logits, labels, class_w, pred, ce, coef, dlogits, B, C, label_smoothing,
+                       loss_scale);
+    MCN_CHECK_LAUNCH();
+    if (loss) {
+        hipLaunchKernelGGL(xent_mean_kernel, dim3(1), dim3(256), 0, st, (const float*)ce, (const float*)coef, loss, B);
+        MCN_CHECK_LAUNCH();
+    }
+    return MCN_OK;
+}
+
+// ---- L2 regulariser value ---------------------------------------------------------------------------------
+#define L2_BLOCKS 1024
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ w, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long n4 = n / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += w[i] * w[i];
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void l2_final_kernel(const float* __restrict__ part, int nparts, float factor, float* __restrict__ out) {
+    __shared__ double shd[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += (double)part[i];
+    shd[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += (float)(0.5 * (double)factor * shd[0]);
+}
+extern "C" int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !out || n < 0) MCN_FAIL(MCN_E_BADARG, "l2_loss: bad argument");
+    if (!ws || ws_bytes < L2_BLOCKS * sizeof(float)) MCN_FAIL(MCN_E_WORKSPACE, "l2_loss: workspace needs %zu bytes", (size_t)L2_BLOCKS * sizeof(float));
+    if (((uintptr_t)w & 15) != 0) MCN_FAIL(MCN_E_BADARG, "l2_loss: w must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, w, (long)n, (float*)ws);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l2_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, L2_BLOCKS, factor, out);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// ---- fused Nesterov momentum + L2 + EMA + decoupled decay ----------------------------------------------------
+template <bool EMA>
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ a,
+                                                           float* __restrict__ ema, long n, float lr, float mom, float l2, float wd,
+                                                           float d, float gs) {
+    const long n4 = n / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 wv = *reinterpret_cast<f32x4*>(w + i * 4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+        f32x4 av = *reinterpret_cast<f32x4*>(a + i * 4);
+        if (EMA) {
+            f32x4 ev = *reinterpret_cast<f32x4*>(ema + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ev[k] = d * ev[k] + (1.f - d) * wv[k];
+            *reinterpret_cast<f32x4*>(ema + i * 4) = ev;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gt = gs * gv[k] + l2 * wv[k];
+            av[k] = mom * av[k] + gt;
+            float nw = wv[k] - lr * gt - lr * mom * av[k];
+            if (wd > 0.f) nw -= wd * nw;
+            wv[k] = nw;
+        }
+        *reinterpret_cast<f32x4*>(w + i * 4) = wv;
+        *reinterpret_cast<f32x4*>(a + i * 4) = av;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float wv = w[i];
+        if (EMA) ema[i] = d * ema[i] + (1.f - d) * wv;
+        const float gt = gs * g[i] + l2 * wv;
+        const float av = mom * a[i] + gt;
+        float nw = wv - lr * gt - lr * mom * av;
+        if (wd > 0.f) nw -= wd * nw;
+        w[i] = nw;
+        a[i] = av;
+    }
+}
+extern "C" int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum, float l2,
+                                      float wd, float ema_decay, float grad_scale, void* stream) {
+    if (!w || !g || !accum || n < 0) MCN_FAIL(MCN_E_BADARG, "sgd_nesterov_fused: bad argument");
+    if (n == 0) return MCN_OK;
+    if ((((uintptr_t)w | (uintptr_t)g | (uintptr_t)accum | (uintptr_t)ema) & 15) != 0) MCN_FAIL(MCN_E_BADARG, "sgd_nesterov_fused: buffers must be 16-byte aligned");
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (ema) hipLaunchKernelGGL((sgd_nesterov_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, w, g, accum, ema, (long)n, lr, momentum, l2, wd, ema_decay, grad_scale);
+    else hipLaunchKernelGGL((sgd_nesterov_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, w, g, accum, ema, (long)n, lr, momentum, l2, wd, ema_decay, grad_scale);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+__global__ void ema_kernel(float* __restrict__ s, const float* __restrict__ v, long n, float d) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s[i] = d * s[i] + (1.f - d) * v[i];
+}
+extern "C" int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream) {
+    if (!shadow || !v || n < 0) MCN_FAIL(MCN_E_BADARG, "ema_update: bad argument");
+    if (n == 0) return MCN_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shadow, v, (long)n, decay);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+__global__ void bn_chain_kernel(float* __restrict__ run, const float* __restrict__ batch, int towers, long n, float m) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float r = run[i];
+        for (int k = 0; k < towers; ++k) r = m * r + (1.f - m) * batch[(long)k * n + i];
+        run[i] = r;
+    }
+}
+extern "C" int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* stream) {
+    if (!running || !batch || towers < 0 || n < 0) MCN_FAIL(MCN_E_BADARG, "bn_running_chain: bad argument");
+    if (n == 0 || towers == 0) return MCN_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bn_chain_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, running, batch, towers, (long)n, momentum);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}

@@ -1,0 +1,346 @@
+// pool.hip — max / average / global-average pooling on NHWC activations (HBM-bound).
+// One thread per (output pixel, VEC channels): 16-byte coalesced accesses along C.
+#include "common.h"
+
+template <typename T, int VEC>
+__device__ __forceinline__ void pld(const T* p, float (&o)[VEC]) {
+    if constexpr (VEC == 1) o[0] = to_f32(p[0]);
+    else {
+        const Chunk<T> c = load_chunk<T>(p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = c.get(i);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void pst(T* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 1) p[0] = from_f32<T>(v[0]);
+    else {
+        Chunk<T> c;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) c.set(i, v[i]);
+        store_chunk<T>(p, c);
+    }
+}
+
+struct PoolParams {
+    int N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW;
+};
+static inline unsigned pool_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, PoolParams p) {
+    const int cv = p.C / VEC;
+    const long total = (long)p.N * p.OH * p.OW * cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * VEC;
+        long r = idx / cv;
+        const int ox = (int)(r % p.OW);
+        r /= p.OW;
+        const int oy = (int)(r % p.OH), n = (int)(r / p.OH);
+        float best[VEC];
+        int bi[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+        for (int kr = 0; kr < p.KH; ++kr) {
+            const int iy = oy * p.SH + kr - p.padT;
+            if (iy < 0 || iy >= p.H) continue;
+            for (int ks = 0; ks < p.KW; ++ks) {
+                const int ix = ox * p.SW + ks - p.padL;
+                if (ix < 0 || ix >= p.W) continue;
+                float v[VEC];
+                pld<T, VEC>(x + (((long)n * p.H + iy) * p.W + ix) * p.C + c, v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (v[i] > best[i]) { best[i] = v[i]; bi[i] = kr * p.KW + ks; }   // strict '>' : first maximum wins
+            }
+        }
+        const long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
+        pst<T, VEC>(y + o, best);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) arg[o + i] = (int8_t)bi[i];
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ arg, T* __restrict__ dx, PoolParams p) {
+    const int cv = p.C / VEC;
+    const long total = (long)p.N * p.H * p.W * cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * VEC;
+        long r = idx / cv;
+        const int ix = (int)(r % p.W);
+        r /= p.W;
+        const int iy = (int)(r % p.H), n = (int)(r / p.H);
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int kr = 0; kr < p.KH; ++kr) {
+            const int ty = iy + p.padT - kr;
+            if (ty < 0 || ty % p.SH) continue;
+            const int oy = ty / p.SH;
+            if (oy >= p.OH) continue;
+            for (int ks = 0; ks < p.KW; ++ks) {
+                const int tx = ix + p.padL - ks;
+                if (tx < 0 || tx % p.SW) continue;
+                const int ox = tx / p.SW;
+                if (ox >= p.OW) continue;
+                const long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
+                float g[VEC];
+                pld<T, VEC>(dy + o, g);
+                const int code = kr * p.KW + ks;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (arg[o + i] == code) acc[i] += g[i];
+            }
+        }
+        pst<T, VEC>(dx + (((long)n * p.H + iy) * p.W + ix) * p.C + c, acc);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p) {
+    const int cv = p.C / VEC;
+    const long total = (long)p.N * p.OH * p.OW * cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * VEC;
+        long r = idx / cv;
+        const int ox = (int)(r % p.OW);
+        r /= p.OW;
+        const int oy = (int)(r % p.OH), n = (int)(r / p.OH);
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        int cnt = 0;
+        for (int kr = 0; kr < p.KH; ++kr) {
+            const int iy = oy * p.SH + kr - p.padT;
+            if (iy < 0 || iy >= p.H) continue;
+            for (int ks = 0; ks < p.KW; ++ks) {
+                const int ix = ox * p.SW + ks - p.padL;
+                if (ix < 0 || ix >= p.W) continue;
+                float v[VEC];
+                pld<T, VEC>(x + (((long)n * p.H + iy) * p.W + ix) * p.C + c, v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+                ++cnt;
+            }
+        }
+        const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] *= inv;
+        pst<T, VEC>(y + (((long)n * p.OH + oy) * p.OW + ox) * p.C + c, acc);
+    }
+}
+
+__device__ __forceinline__ int valid_count(int o, int S, int K, int pad, int L) {
+    int lo = o * S - pad, hi = lo + K;
+    if (lo < 0) lo = 0;
+    if (hi > L) hi = L;
+    return hi - lo;
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, PoolParams p) {
+    const int cv = p.C / VEC;
+    const long total = (long)p.N * p.H * p.W * cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * VEC;
+        long r = idx / cv;
+        const int ix = (int)(r % p.W);
+        r /= p.W;
+        const int iy = (int)(r % p.H), n = (int)(r / p.H);
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int kr = 0; kr < p.KH; ++kr) {
+            const int ty = iy + p.padT - kr;
+            if (ty < 0 || ty % p.SH) continue;
+            const int oy = ty / p.SH;
+            if (oy >= p.OH) continue;
+            for (int ks = 0; ks < p.KW; ++ks) {
+                const int tx = ix + p.padL - ks;
+                if (tx < 0 || tx % p.SW) continue;
+                const int ox = tx / p.SW;
+                if (ox >= p.OW) continue;
+                const int cnt = valid_count(oy, p.SH, p.KH, p.padT, p.H) * valid_count(ox, p.SW, p.KW, p.padL, p.W);
+                float g[VEC];
+                pld<T, VEC>(dy + (((long)n * p.OH + oy) * p.OW + ox) * p.C + c, g);
+                const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += g[i] * inv;
+            }
+        }
+        pst<T, VEC>(dx + (((long)n * p.H + iy) * p.W + ix) * p.C + c, acc);
+    }
+}
+
+// global average over HW: [N][HW][C] -> [N][C]
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+    const int cv = C / VEC;
+    const long total = (long)N * cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * VEC;
+        const long n = idx / cv;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int q = 0; q < HW; ++q) {
+            float v[VEC];
+            pld<T, VEC>(x + (n * HW + q) * C + c, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] *= inv;
+        pst<T, VEC>(y + n * C + c, acc);
+    }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int HW, int C) {
+    const int cv = C / VEC;
+    const long total = (long)N * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * VEC;
+        const long pq = idx / cv;
+        const long n = pq / HW;
+        float g[VEC];
+        pld<T, VEC>(dy + n * C + c, g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] *= inv;
+        pst<T, VEC>(dx + pq * C + c, g);
+    }
+}
+
+// ---- host --------------------------------------------------------------------------------------------------
+static int pool_check(const void* a, const void* b, int N, int H, int W, int C, int KH, int KW, int SH, int SW, int padT, int padL, int OH,
+                      int OW, const char* name) {
+    if (!a || !b || N < 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || SH <= 0 || SW <= 0 || padT < 0 || padL < 0 || OH <= 0 || OW <= 0 ||
+        KH * KW > 127)
+        MCN_FAIL(MCN_E_BADARG, "%s: bad argument", name);
+    return MCN_OK;
+}
+#define POOL_DISPATCH(KERNEL, TOTAL, ...)                                                                        \
+    do {                                                                                                         \
+        if (dtype == MCN_F32) {                                                                                  \
+            if (C % 4 == 0) hipLaunchKernelGGL((KERNEL<float, 4>), dim3(pool_blocks((TOTAL) / 4)), dim3(256), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<float, 1>), dim3(pool_blocks(TOTAL)), dim3(256), 0, st, __VA_ARGS__);  \
+        } else if (dtype == MCN_BF16) {                                                                          \
+            if (C % 8 == 0) hipLaunchKernelGGL((KERNEL<bf16_t, 8>), dim3(pool_blocks((TOTAL) / 8)), dim3(256), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<bf16_t, 1>), dim3(pool_blocks(TOTAL)), dim3(256), 0, st, __VA_ARGS__); \
+        } else MCN_FAIL(MCN_E_UNSUPPORTED, "pool: dtype %d unsupported", (int)dtype);                            \
+        MCN_CHECK_LAUNCH();                                                                                      \
+    } while (0)
+
+template <typename T> static const T* cp(const void* p) { return (const T*)p; }
+
+extern "C" int mcn_maxpool_fwd(const void* x, void* y, int8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                               int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype, void* stream) {
+    int rc = pool_check(x, y, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, "maxpool_fwd");
+    if (rc) return rc;
+    if (!argmax) MCN_FAIL(MCN_E_BADARG, "maxpool_fwd: null argmax");
+    if (N == 0) return MCN_OK;
+    const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * OH * OW * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_fwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_maxpool_bwd(const void* dy, const int8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH,
+                               int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype,
+                               void* stream) {
+    int rc = pool_check(dy, dx, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, "maxpool_bwd");
+    if (rc) return rc;
+    if (!argmax) MCN_FAIL(MCN_E_BADARG, "maxpool_bwd: null argmax");
+    if (N == 0) return MCN_OK;
+    const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * H * W * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
+        else hipLaunchKernelGGL((maxpool_bwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+        else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_avgpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t SH,
+                               int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype, void* stream) {
+    int rc = pool_check(x, y, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, "avgpool_fwd");
+    if (rc) return rc;
+    if (N == 0) return MCN_OK;
+    const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * OH * OW * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((avgpool_fwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+        else hipLaunchKernelGGL((avgpool_fwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+        else hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "avgpool_fwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t SH,
+                               int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype, void* stream) {
+    int rc = pool_check(dy, dx, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, "avgpool_bwd");
+    if (rc) return rc;
+    if (N == 0) return MCN_OK;
+    const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * H * W * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((avgpool_bwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, (float*)dx, p);
+        else hipLaunchKernelGGL((avgpool_bwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, p);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p);
+        else hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "avgpool_bwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream) {
+    if (!x || !y || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "global_avgpool_fwd: bad argument");
+    if (N == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((gap_fwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, N, HW, C);
+        else hipLaunchKernelGGL((gap_fwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, N, HW, C);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((gap_fwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
+        else hipLaunchKernelGGL((gap_fwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_fwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream) {
+    if (!dy || !dx || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "global_avgpool_bwd: bad argument");
+    if (N == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * HW * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((gap_bwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, (float*)dx, N, HW, C);
+        else hipLaunchKernelGGL((gap_bwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, N, HW, C);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+        else hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_bwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}

@@ -1,0 +1,126 @@
+"""Data parallelism: one process per GPU, RCCL over xGMI (torch.distributed 'nccl' backend IS RCCL on ROCm).
+
+Replaces the reference's in-graph tower replication with parameter-server averaging (convnet.py:431-436,
+optimizers.py:121-147):
+  * gradients: all-reduce(sum) of contiguous ranges of the flat fp32 gradient buffer, bucketed in reverse layer
+    order and enqueued as soon as the last wgrad of a bucket has been launched, so the collective runs beside the
+    remaining backward kernels; the 1/N of the tower mean is folded into the optimizer kernel's grad_scale;
+  * BN running statistics: one all-gather of every rank's (batch_mean, batch_var) and the reference's chained
+    update running <- m*running + (1-m)*batch[k], k = 0..N-1 (convnet.py:1899-1909), identical on every rank;
+  * loss: mean of the per-rank losses (convnet.py:510), for reporting only.
+The bucket planner works on plain tensors so it is covered by gloo tests on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group(device=None):
+    """Idempotent init from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    if dist.is_initialized():
+        return
+    backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    kw = {}
+    if backend == 'nccl':
+        kw['device_id'] = torch.device(device)
+    dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', 0)), world_size=int(os.environ.get('WORLD_SIZE', 1)), **kw)
+
+
+def plan_buckets(variables, ready_index, bucket_bytes):
+    """variables: [(name, offset, padded_size)] of ONE flat buffer; ready_index: name -> backward call index after
+    which the gradient is final.  Returns [(launch_index, [(start, end), ...])]: element ranges to all-reduce once
+    the call at launch_index-1 has been enqueued.  Variables are grouped in completion order; each bucket's
+    variables are merged into maximal contiguous ranges."""
+    order = sorted(variables, key=lambda v: ready_index[v[0]])
+    buckets, cur, cur_bytes = [], [], 0
+    for v in order:
+        cur.append(v)
+        cur_bytes += v[2] * 4
+        if cur_bytes >= bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+    if cur:
+        buckets.append(cur)
+    out = []
+    for b in buckets:
+        idx = max(ready_index[v[0]] for v in b)
+        spans = sorted((v[1], v[1] + v[2]) for v in b)
+        merged = []
+        for s, e in spans:
+            if merged and merged[-1][1] == s:
+                merged[-1][1] = e
+            else:
+                merged.append([s, e])
+        out.append((idx, [tuple(m) for m in merged]))
+    return out
+
+
+class GradientReducer(object):
+    """Bucketed, overlapped all-reduce of a flat gradient tensor."""
+
+    def __init__(self, flat_grad, variables, ready_index, bucket_mb=25.0, group=None):
+        self.flat = flat_grad
+        self.group = group
+        self.plan = plan_buckets(variables, ready_index, int(bucket_mb * 1024 * 1024))
+        self.works = []
+        self._hooks = {}
+        for idx, spans in self.plan:
+            self._hooks.setdefault(idx, []).extend(spans)
+
+    def hooks(self):
+        def make(spans):
+            def fire():
+                for s, e in spans:
+                    self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return fire
+        return {idx: make(spans) for idx, spans in self._hooks.items()}
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def covered_elements(self):
+        return sum(e - s for _, spans in self.plan for s, e in spans)
+
+
+class DataParallel(object):
+    def __init__(self, model, bucket_mb=25.0):
+        self.model = model
+        init_process_group(model.device)
+        self.world = dist.get_world_size()
+        assert self.world == model.world_size, 'WORLD_SIZE {} != num_gpus {}'.format(self.world, model.world_size)
+        marks = model._train_low.bwd.marks
+        ready = {}
+        for label, idx in marks.items():
+            if isinstance(label, tuple) and label[0] == 'grad_ready':
+                for name in label[1]:
+                    ready[name] = idx
+        st = model.store
+        variables = [(v.name, v.offset, (v.size + 3) // 4 * 4) for v in st.variables]
+        missing = [v[0] for v in variables if v[0] not in ready]
+        assert not missing, 'no backward completion point for {}'.format(missing[:3])
+        self.reducer = GradientReducer(st.grad, variables, ready, bucket_mb)
+        assert self.reducer.covered_elements() == st.size
+        self.gathered_stats = torch.zeros((self.world, model.batch_stats.numel()), dtype=torch.float32, device=model.device)
+        self._loss_tmp = torch.zeros(1, dtype=torch.float32, device=model.device)
+        # identical initial state on every rank
+        for t in (st.data, st.ema, st.accum, model.stats.data, model.stats.ema):
+            dist.broadcast(t, src=0)
+
+    def hooks(self):
+        return self.reducer.hooks()
+
+    def finish(self):
+        self.reducer.finish()
+
+    def gather_bn_stats(self):
+        dist.all_gather_into_tensor(self.gathered_stats.view(-1), self.model.batch_stats)
+
+    def mean_scalar(self, t):
+        self._loss_tmp.copy_(t.reshape(1))
+        dist.all_reduce(self._loss_tmp, op=dist.ReduceOp.SUM)
+        return float(self._loss_tmp.item()) / self.world

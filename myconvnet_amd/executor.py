@@ -1,0 +1,309 @@
+"""Lowering of graph Nodes to C-ABI launch lists (forward, backward) — the only place that calls
+libmcn_hip.  Every emit_* function cites the reference op it stands for in include/mcn.h."""
+import ctypes
+
+import torch
+
+from . import _ffi
+from ._ffi import lib
+from .graph import MCN_DT, TORCH_DT, Program, ptr
+
+
+class Lowering(object):
+    """Emits the launch lists of one graph for one mode ('train' or 'eval')."""
+
+    def __init__(self, graph, model, mode, loss_scale=1.0):
+        self.g = graph
+        self.model = model
+        self.mode = mode
+        self.train = mode == 'train'
+        self.dt = MCN_DT[graph.dtype]
+        self.loss_scale = float(loss_scale)
+        self.fwd = Program()
+        self.bwd = Program()
+        self.ws = None
+        self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
+        self.written = set()           # tensor ids whose .grad already holds a contribution
+        self.scratch = {}
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def vptr(self, var):
+        """Pointer to a variable's value: master in training, EMA shadow in evaluation
+        (reference convnet.py:1406-1408, 1456-1458, 1872-1876)."""
+        if var is None:
+            return 0
+        return var.data.data_ptr() if self.train else var.ema.data_ptr()
+
+    def workspace_bytes(self):
+        need = 4096
+        for n in self.g.nodes:
+            if n.op == 'conv':
+                gm = n.attrs['geom']
+                for op in (_ffi.CONV_FWD, _ffi.CONV_DGRAD, _ffi.CONV_WGRAD):
+                    need = max(need, lib.mcn_conv2d_workspace_bytes(op, ctypes.byref(gm), self.dt))
+            elif n.op == 'bn':
+                x = n.inputs[0]
+                need = max(need, lib.mcn_bn_workspace_bytes(x.numel // x.shape[-1], x.shape[-1]))
+            elif n.op == 'fc':
+                x = n.inputs[0]
+                need = max(need, lib.mcn_fc_workspace_bytes(x.shape[0], x.shape[1], n.outputs[0].shape[1], self.dt))
+        return int(need)
+
+    def scratch_like(self, t, key):
+        k = (key, t.shape, t.dtype)
+        if k not in self.scratch:
+            self.scratch[k] = torch.zeros(t.shape, dtype=TORCH_DT[t.dtype], device=self.g.device)
+        return self.scratch[k]
+
+    def contribute(self, t, produce):
+        """Route a gradient contribution into t.grad.  `produce(dst_ptr, accumulate)` emits the launches;
+        ops that cannot accumulate natively call contribute_via_scratch instead."""
+        if not t.needs_grad:
+            return
+        first = t.id not in self.written
+        self.written.add(t.id)
+        produce(t.grad.data_ptr(), 0 if first else 1)
+
+    def contribute_via_scratch(self, t, produce_write):
+        """For ops that can only overwrite: first contribution writes t.grad directly, later ones go through
+        a scratch buffer + mcn_accumulate."""
+        if not t.needs_grad:
+            return
+        if t.id not in self.written:
+            self.written.add(t.id)
+            produce_write(t.grad.data_ptr())
+        else:
+            s = self.scratch_like(t, 'acc')
+            produce_write(s.data_ptr())
+            self.bwd.add(lib.mcn_accumulate, t.grad.data_ptr(), s.data_ptr(), t.grad.numel(), MCN_DT[t.dtype])
+
+    # ---- driver ---------------------------------------------------------------------------------------
+    def lower(self):
+        ws_bytes = self.workspace_bytes()
+        self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=self.g.device)
+        self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel() * 4
+        for n in self.g.nodes:
+            getattr(self, 'fwd_' + n.op)(n)
+        if self.train:
+            for n in reversed(self.g.nodes):
+                f = getattr(self, 'bwd_' + n.op, None)
+                if f is not None:
+                    f(n)
+        return self
+
+    # ---- input / labels ---------------------------------------------------------------------------------
+    def fwd_input(self, n):
+        y = n.outputs[0]
+        N, H, W, C = y.shape
+        m = self.model
+        src_layout = _ffi.NCHW if n.attrs['src_nchw'] else _ffi.NHWC
+        self.fwd.add(lib.mcn_input_prep, m.X_in.data_ptr(), y.buf.data_ptr(), N, H, W, C, y.cs, float(n.attrs['image_mean']),
+                     float(n.attrs['scale_factor']), src_layout, MCN_DT[y.dtype])
+
+    def fwd_labels(self, n):
+        y = n.outputs[0]
+        self.fwd.add(lib.mcn_one_hot, self.model.Y_in.data_ptr(), y.buf.data_ptr(), y.shape[0], y.shape[1])
+
+    # ---- conv -----------------------------------------------------------------------------------------------
+    def fwd_conv(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        gm = n.attrs['geom']
+        self.keep.append(gm)
+        self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
+                     ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+
+    def bwd_conv(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        gm = n.attrs['geom']
+        w, b = n.attrs['w'], n.attrs.get('b')
+        gs = 1.0 / self.loss_scale
+        if w.trainable:
+            self.bwd.add(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(),
+                         b.grad.data_ptr() if b is not None else 0, ctypes.byref(gm), gs, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+            self.bwd.mark(('grad_ready', tuple(v.name for v in (w, b) if v is not None)))
+        if x.needs_grad:
+            self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), dst,
+                                                             ctypes.byref(gm), acc, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes))
+
+    # ---- batch norm --------------------------------------------------------------------------------------------
+    def fwd_bn(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        a = n.attrs
+        C = x.shape[-1]
+        M = x.numel // C
+        skip = a.get('skip')
+        if self.train and a['update']:
+            st = a['saved']
+            single = self.model.world_size == 1
+            self.fwd.add(lib.mcn_bn_fwd_train, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
+                         y.buf.data_ptr(), st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
+                         a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
+                         float(a['momentum']), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+        else:
+            mu, sg = a['mu'], a['sigma']
+            mp = mu.data.data_ptr() if self.train else mu.ema.data_ptr()
+            sp = sg.data.data_ptr() if self.train else sg.ema.data_ptr()
+            self.fwd.add(lib.mcn_bn_fwd_infer, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), mp, sp,
+                         ptr(skip.buf) if skip else 0, y.buf.data_ptr(), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype])
+
+    def bwd_bn(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        a = n.attrs
+        if not a['update']:
+            raise NotImplementedError('backward through a frozen batch norm (update_batch_norm=False) is not built yet')
+        C = x.shape[-1]
+        M = x.numel // C
+        skip = a.get('skip')
+        st = a['saved']
+        gs = 1.0 / self.loss_scale
+        dskip_ptr, post = 0, None
+        if skip is not None and skip.needs_grad:
+            if skip.id not in self.written:
+                self.written.add(skip.id)
+                dskip_ptr = skip.grad.data_ptr()
+            else:
+                s = self.scratch_like(skip, 'bn_dskip')
+                dskip_ptr = s.data_ptr()
+                post = (skip.grad.data_ptr(), s.data_ptr(), skip.grad.numel(), MCN_DT[skip.dtype])
+        g, b = a['gamma'], a['beta']
+
+        def emit(dst):
+            self.bwd.add(lib.mcn_bn_bwd, y.grad.data_ptr(), x.buf.data_ptr(), y.buf.data_ptr(), self.vptr(g), st['mean'].data_ptr(),
+                         st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
+                         b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, a.get('act', 0), MCN_DT[x.dtype],
+                         self.ws_ptr, self.ws_bytes)
+        self.contribute_via_scratch(x, emit)
+        if post:
+            self.bwd.add(lib.mcn_accumulate, *post)
+        self.bwd.mark(('grad_ready', tuple(v.name for v in (g, b) if v is not None and v.trainable)))
+
+    # ---- element-wise ----------------------------------------------------------------------------------------------
+    def fwd_affine(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        if 'dev' not in n.attrs:
+            n.attrs['dev'] = (torch.tensor(n.attrs['scale'], dtype=torch.float32, device=self.g.device),
+                              torch.tensor(n.attrs['shift'], dtype=torch.float32, device=self.g.device))
+        sc, sh = n.attrs['dev']
+        self.fwd.add(lib.mcn_channel_affine, x.buf.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.buf.data_ptr(), x.numel // x.cs, x.cs,
+                     MCN_DT[x.dtype])
+
+    def fwd_relu(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.fwd.add(lib.mcn_relu_fwd, x.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel(), MCN_DT[x.dtype])
+
+    def bwd_relu(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_relu_bwd, y.grad.data_ptr(), y.buf.data_ptr(), dst, y.buf.numel(),
+                                                                MCN_DT[x.dtype]))
+
+    def fwd_add(self, n):
+        a, b, y = n.inputs[0], n.inputs[1], n.outputs[0]
+        self.fwd.add(lib.mcn_add_relu_fwd, a.buf.data_ptr(), b.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel(), n.attrs.get('act', 0),
+                     MCN_DT[y.dtype])
+
+    def bwd_add(self, n):
+        y = n.outputs[0]
+        act = n.attrs.get('act', 0)
+        dt = MCN_DT[y.dtype]
+        if act:
+            g = self.scratch_like(y, 'add_mask')
+            self.bwd.add(lib.mcn_add_relu_bwd, y.grad.data_ptr(), y.buf.data_ptr(), g.data_ptr(), y.buf.numel(), act, dt)
+            gp = g.data_ptr()
+        else:
+            gp = y.grad.data_ptr()
+        for t in n.inputs[:2]:
+            if not t.needs_grad:
+                continue
+            if t.id not in self.written:
+                self.written.add(t.id)
+                self.bwd.add(lib.mcn_cast, gp, dt, t.grad.data_ptr(), dt, y.buf.numel())
+            else:
+                self.bwd.add(lib.mcn_accumulate, t.grad.data_ptr(), gp, y.buf.numel(), dt)
+
+    def fwd_cast(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.fwd.add(lib.mcn_cast, x.buf.data_ptr(), MCN_DT[x.dtype], y.buf.data_ptr(), MCN_DT[y.dtype], y.buf.numel())
+
+    def bwd_cast(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        if not x.needs_grad:
+            return
+        if x.id in self.written:
+            raise NotImplementedError('cast backward into an already-written gradient')
+        self.written.add(x.id)
+        self.bwd.add(lib.mcn_cast, y.grad.data_ptr(), MCN_DT[y.dtype], x.grad.data_ptr(), MCN_DT[x.dtype], y.buf.numel())
+
+    # ---- pooling ---------------------------------------------------------------------------------------------------------
+    def _pool_args(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        a = n.attrs
+        N, H, W, C = x.shape
+        return [N, H, W, C, a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl'], y.shape[1], y.shape[2]]
+
+    def fwd_maxpool(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        if 'argmax' not in n.attrs:
+            n.attrs['argmax'] = torch.zeros(y.shape, dtype=torch.int8, device=self.g.device)
+        self.fwd.add(lib.mcn_maxpool_fwd, x.buf.data_ptr(), y.buf.data_ptr(), n.attrs['argmax'].data_ptr(), *(self._pool_args(n) + [MCN_DT[x.dtype]]))
+
+    def bwd_maxpool(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_maxpool_bwd, y.grad.data_ptr(), n.attrs['argmax'].data_ptr(), dst,
+                                                                *(self._pool_args(n) + [MCN_DT[x.dtype]])))
+
+    def fwd_avgpool(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.fwd.add(lib.mcn_avgpool_fwd, x.buf.data_ptr(), y.buf.data_ptr(), *(self._pool_args(n) + [MCN_DT[x.dtype]]))
+
+    def bwd_avgpool(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_avgpool_bwd, y.grad.data_ptr(), dst, *(self._pool_args(n) + [MCN_DT[x.dtype]])))
+
+    def fwd_gap(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        N, H, W, C = x.shape
+        self.fwd.add(lib.mcn_global_avgpool_fwd, x.buf.data_ptr(), y.buf.data_ptr(), N, H * W, C, MCN_DT[x.dtype])
+
+    def bwd_gap(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        N, H, W, C = x.shape
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_global_avgpool_bwd, y.grad.data_ptr(), dst, N, H * W, C, MCN_DT[x.dtype]))
+
+    # ---- fc -------------------------------------------------------------------------------------------------------------------
+    def fwd_fc(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        B, In = x.shape
+        Out = y.shape[1]
+        self.fwd.add(lib.mcn_fc_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.vptr(n.attrs.get('b')), y.buf.data_ptr(), B, In, Out,
+                     MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+
+    def bwd_fc(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        B, In = x.shape
+        Out = y.shape[1]
+        w, b = n.attrs['w'], n.attrs.get('b')
+        gs = 1.0 / self.loss_scale
+        dt = MCN_DT[x.dtype]
+        if w.trainable:
+            self.bwd.add(lib.mcn_fc_bwd, y.grad.data_ptr(), x.buf.data_ptr(), w.data.data_ptr(), 0, w.grad.data_ptr(),
+                         b.grad.data_ptr() if b is not None else 0, gs, B, In, Out, dt, self.ws_ptr, self.ws_bytes)
+            self.bwd.mark(('grad_ready', tuple(v.name for v in (w, b) if v is not None)))
+        if x.needs_grad:
+            self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_fc_bwd, y.grad.data_ptr(), x.buf.data_ptr(), w.data.data_ptr(), dst,
+                                                                    0, 0, gs, B, In, Out, dt, self.ws_ptr, self.ws_bytes))
+
+    # ---- softmax / loss ------------------------------------------------------------------------------------------------------------
+    def fwd_loss(self, n):
+        logits, onehot = n.inputs[0], n.inputs[1]
+        a = n.attrs
+        B, C = logits.shape
+        m = self.model
+        dl = logits.grad.data_ptr() if (self.train and logits.needs_grad) else 0
+        if dl:
+            self.written.add(logits.id)
+        self.fwd.add(lib.mcn_softmax_xent_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
+                     a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale)
+        nw = m.n_l2_elems
+        if a['l2_reg'] > 0.0 and nw > 0:
+            # the regulariser always reads the master variables (collection 'weight_variables', convnet.py:535)
+            self.fwd.add(lib.mcn_l2_loss, m.store.data.data_ptr(), nw, float(a['l2_reg']), a['loss'].data_ptr(), self.ws_ptr, self.ws_bytes)

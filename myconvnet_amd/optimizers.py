@@ -1,0 +1,237 @@
+"""Optimizer — host-side mirror of reference optimizers.py (Optimizer.__init__ :19-63, _optimize_and_update
+:89-177, train :179-563, _step :565-606, _update_learning_rate :608-632, MomentumOptimizer :668-677).
+
+What is MI355X-native here: the parameter-server tower averaging (optimizers.py:121-147) is replaced by an RCCL
+all-reduce of the flat gradient buffer, bucketed in reverse layer order and launched on a side stream while the
+remaining backward kernels run (dist.py); Nesterov momentum, the L2 term, the EMA shadows and the optional
+decoupled decay are one fused kernel over the flat parameter buffer; the per-step device->host copy of
+Y_all / pred (optimizers.py:590-594) is optional (`fetch=False`) so the training loop never synchronises.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import lib
+from .graph import Program
+
+
+class Optimizer(object):
+    def __init__(self, model, train_set, evaluator, val_set=None, **kwargs):
+        self.model = model
+        self.train_set = train_set
+        self.evaluator = evaluator
+        self.val_set = val_set
+        if train_set is not None:
+            assert model.compute_device == train_set.compute_device, 'Device mismatch between the model and dataset'
+            assert model.num_devices == train_set.num_shards, 'Number of devices mismatch between the model and dataset'
+            assert model.device_offset == train_set.device_offset, 'Device offset mismatch between the model and dataset'
+            self.batch_size = train_set.batch_size
+        else:
+            self.batch_size = model.batch_size
+        self.num_epochs = kwargs.get('num_epochs', 100)
+        self.monte_carlo = kwargs.get('monte_carlo', False)
+        self.augment_train = kwargs.get('augment_train', False)
+        self.init_learning_rate = kwargs.get('base_learning_rate', 0.1) * self.batch_size / 256
+        self.gradient_threshold = kwargs.get('gradient_threshold', None)
+        if self.gradient_threshold is not None:
+            raise NotImplementedError('gradient clipping is a SURVEY §8f-4 row, not built yet')
+        self.warmup_epoch = kwargs.get('learning_warmup_epochs', kwargs.get('learning_warmup_epoch', 1.0))
+        self.decay_method = kwargs.get('learning_rate_decay_method', None)
+        self.decay_params = kwargs.get('learning_rate_decay_params', (0.94, 2))
+        self.update_vars = [v for v in model.store.variables if v.trainable]
+        self.optimization_operation = self._optimize_and_update(self._optimizer(**kwargs), **kwargs)
+        self._reset()
+        self.steps_per_epoch = kwargs.get('steps_per_epoch', None)
+        if self.steps_per_epoch is None and train_set is not None:
+            self.steps_per_epoch = int(np.ceil(train_set.num_examples / self.batch_size))
+        self.total_steps = (self.steps_per_epoch or 1) * self.num_epochs
+
+    def _reset(self):
+        self.curr_step = 0
+        self.curr_epoch = 1
+        self.best_score = self.evaluator.worst_score if self.evaluator is not None else 0.0
+        self.learning_rate_update = 0
+        self.curr_multiplier = 1.0
+
+    name = 'Optimizer'
+
+    def _optimizer(self, **kwargs):
+        raise NotImplementedError
+
+    # ---- update program ------------------------------------------------------------------------------------------------
+    def _optimize_and_update(self, optimizer, **kwargs):
+        """reference optimizers.py:89-177.  Returns the update Program; gradients come from the model's backward
+        launch list (compute_gradients), averaged over ranks by the all-reduce (mean over towers, :138)."""
+        m = self.model
+        self.loss_scaling_factor = float(kwargs.get('loss_scaling_factor', 1.0))
+        if self.loss_scaling_factor != m.loss_scale:
+            m.compile(loss_scale=self.loss_scaling_factor)
+        self.weight_decay = kwargs.get('base_weight_decay', 0.0) * self.batch_size / 256
+        self.weight_decay_scheduling = kwargs.get('weight_decay_scheduling', True)
+        if kwargs.get('l1_weight_decay', False) or kwargs.get('huber_decay_delta', None) is not None:
+            raise NotImplementedError('l1 / huber weight decay are outside the built path')
+        if any(not v.trainable for v in m.store.variables):
+            raise NotImplementedError('blocks_to_train (frozen variables) is not built yet')
+        self.momentum = optimizer['momentum']
+        self.l2_reg = float(m._parameters.get('l2_reg', 1e-4))
+        self.use_ema = bool(kwargs.get('update_ema', True))
+        st = m.store
+        nw, n = m.n_l2_elems, st.size
+        P = Program()
+        ema_w = st.ema.data_ptr() if self.use_ema else 0
+        # args: w, g, accum, ema, n, lr, momentum, l2, wd, ema_decay, grad_scale
+        if nw > 0:
+            P.add(lib.mcn_sgd_nesterov_fused, st.data.data_ptr(), st.grad.data_ptr(), st.accum.data_ptr(), ema_w, nw, 0.0, self.momentum,
+                  self.l2_reg, 0.0, 0.0, 1.0)
+        if n > nw:
+            off = nw * 4
+            P.add(lib.mcn_sgd_nesterov_fused, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
+                  (ema_w + off) if ema_w else 0, n - nw, 0.0, self.momentum, 0.0, 0.0, 0.0, 1.0)
+        self._sgd_calls = [args for _, args in P.calls]
+        # EMA of the BN running statistics (pre-assign value), launched before the forward pass
+        self._pre = Program()
+        if self.use_ema and m.stats.size > 0:
+            self._pre.add(lib.mcn_ema_update, m.stats.ema.data_ptr(), m.stats.data.data_ptr(), m.stats.size, 0.0)
+        # cross-rank running-statistics chain (convnet.py:1899-1909)
+        self._post_fwd = Program()
+        self.dp = None
+        if m.world_size > 1:
+            from .dist import DataParallel
+            self.dp = DataParallel(m, bucket_mb=float(kwargs.get('allreduce_bucket_mb', 25.0)))
+            self._post_fwd.add(lib.mcn_bn_running_chain, m.stats.data.data_ptr(), self.dp.gathered_stats.data_ptr(), m.world_size,
+                               m.stats.size, float(m.batch_norm_decay))
+        return P
+
+    def _set_hyper(self):
+        m = self.model
+        lr = self.init_learning_rate * self.curr_multiplier
+        d = min(m.moving_average_decay, (1.0 + m.global_step) / (10.0 + m.global_step))     # tf EMA num_updates rule
+        wd = self.weight_decay * (self.curr_multiplier if self.weight_decay_scheduling else 1.0)
+        gscale = 1.0 / m.world_size                                                          # tower mean, optimizers.py:138
+        for i, args in enumerate(self._sgd_calls):
+            args[5] = lr
+            args[9] = d
+            args[10] = gscale
+            args[8] = wd if (i == 0 and m.n_l2_elems > 0) else 0.0
+        if len(self._pre):
+            self._pre.calls[0][1][3] = d
+        return lr
+
+    # ---- one step ---------------------------------------------------------------------------------------------------------------
+    def _step(self, handles=None, merged=None, writer=None, summary=False, log_trace=False, fetch=True):
+        """reference optimizers.py:565-606: one optimisation step on the batch currently in the model's input buffers.
+        Returns (loss, Y_true, Y_pred) as numpy when fetch=True (the reference's behaviour), else device tensors
+        without synchronising."""
+        m = self.model
+        self._set_hyper()
+        sp = m.stream_ptr()
+        self._pre.run(sp)
+        m.forward(train=True)
+        if self.dp is not None:
+            self.dp.gather_bn_stats()
+            self._post_fwd.run(sp)
+            m.backward(self.dp.hooks())
+            self.dp.finish()
+        else:
+            m.backward()
+        self.optimization_operation.run(sp)
+        m.global_step += 1
+        if fetch:
+            loss = self._mean_loss()
+            return loss, m.Y.buf.cpu().numpy(), m.pred.buf.cpu().numpy()
+        return m.loss_buf, m.Y.buf, m.pred.buf
+
+    def _mean_loss(self):
+        m = self.model
+        if self.dp is not None:
+            return self.dp.mean_scalar(m.loss_buf[0])
+        return float(m.loss_buf[0].item())
+
+    def _update_learning_rate(self):
+        """reference optimizers.py:608-632."""
+        warmup_steps = np.around(self.warmup_epoch * self.steps_per_epoch)
+        if self.curr_step < warmup_steps:
+            self.curr_multiplier = (self.curr_step + 1) / warmup_steps
+        elif self.decay_method is not None:
+            method = self.decay_method.lower()
+            if method == 'step':
+                self.curr_multiplier = 1.0
+                for n in range(len(self.decay_params) - 1):
+                    self.curr_multiplier *= np.power(self.decay_params[0], np.maximum(np.sign(self.curr_epoch - self.decay_params[n + 1]), 0.0))
+            elif method == 'exponential':
+                self.curr_multiplier = self.decay_params[0] ** ((self.curr_step - warmup_steps) / self.steps_per_epoch / self.decay_params[1])
+            elif method in ('poly', 'polynomial'):
+                power = self.decay_params[0] if isinstance(self.decay_params, (list, tuple)) else self.decay_params
+                total_steps = self.steps_per_epoch * self.num_epochs - warmup_steps
+                self.curr_multiplier = (1 - (self.curr_step - warmup_steps) / total_steps) ** power
+            else:  # cosine
+                anneal = self.decay_params[0] if isinstance(self.decay_params, (list, tuple)) else self.decay_params
+                anneal = 0 if anneal is None else int(anneal)
+                total_steps = self.steps_per_epoch * self.num_epochs - warmup_steps
+                curr_prog = ((anneal + 1) * (self.curr_step - warmup_steps) / total_steps) % 1.0
+                self.curr_multiplier = 0.5 * (1 + np.cos(curr_prog * np.pi))
+
+    # ---- training loop ----------------------------------------------------------------------------------------------------------------
+    def train(self, save_dir='./tmp', transfer_dir=None, details=False, verbose=True, show_each_step=False, show_percentage=True,
+              **kwargs):
+        """reference optimizers.py:179-563 without checkpoint files, TensorBoard and plots (out of scope)."""
+        if transfer_dir is not None:
+            raise NotImplementedError('transfer learning / checkpoint restore is out of scope')
+        m = self.model
+        train_size = self.train_set.num_examples
+        self.steps_per_epoch = int(np.ceil(train_size / self.batch_size))
+        num_steps = self.steps_per_epoch * self.num_epochs
+        self.total_steps = num_steps
+        validation_frequency = kwargs.get('validation_frequency', None) or self.steps_per_epoch
+        train_losses, train_scores, eval_losses, eval_scores = [], [], [], []
+        step_losses, step_scores = 0.0, 0.0
+        self.train_set.initialize()
+        start_time = time.time()
+        for i in range(num_steps):
+            self._update_learning_rate()
+            X, Y = self.train_set.next_batch(m.device_batch, shard=m.rank)
+            m.feed(X, Y)
+            step_loss, step_Y_true, step_Y_pred = self._step(None)
+            step_score = self.evaluator.score(step_Y_true, step_Y_pred)
+            step_losses += step_loss
+            step_scores += step_score
+            self.curr_step += 1
+            if (i + 1) % validation_frequency == 0:
+                if self.val_set is not None:
+                    _, eval_Y_true, eval_Y_pred, eval_loss = m.predict(self.val_set, verbose=False, return_images=False, **kwargs)
+                    eval_score = self.evaluator.score(eval_Y_true, eval_Y_pred)
+                    eval_scores.append(eval_score)
+                    eval_losses.append(eval_loss)
+                    curr_score = eval_score
+                else:
+                    curr_score = step_scores / validation_frequency
+                if self.evaluator.is_better(curr_score, self.best_score, **kwargs):
+                    self.best_score = curr_score
+                train_losses.append(step_losses / validation_frequency)
+                train_scores.append(step_scores / validation_frequency)
+                step_losses, step_scores = 0.0, 0.0
+            if (i + 1) % self.steps_per_epoch == 0:
+                self.train_set.initialize()
+                if verbose and m.rank == 0:
+                    msg = '[epoch {}/{}]\tTrain loss: {:.5f}  |Train score: {:.5f}'.format(self.curr_epoch, self.num_epochs,
+                                                                                          train_losses[-1] if train_losses else step_loss,
+                                                                                          train_scores[-1] if train_scores else step_score)
+                    if eval_losses:
+                        msg += '  |Eval loss: {:.5f}  |Eval score: {:.5f}'.format(eval_losses[-1], eval_scores[-1])
+                    msg += '  |LR: {:.7f}  |Elapsed time: {:5.0f} sec'.format(self.init_learning_rate * self.curr_multiplier, time.time() - start_time)
+                    print(msg)
+                self.curr_epoch += 1
+        if verbose and m.rank == 0:
+            print('Total training time: {:.2f} sec'.format(time.time() - start_time))
+        if details:
+            return dict(train_losses=train_losses, train_scores=train_scores, eval_losses=eval_losses, eval_scores=eval_scores)
+
+
+class MomentumOptimizer(Optimizer):
+    """reference optimizers.py:668-677: tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True)."""
+    name = 'SGD with Momentum'
+
+    def _optimizer(self, **kwargs):
+        return dict(kind='nesterov', momentum=float(kwargs.get('momentum', 0.9)))

@@ -1,0 +1,119 @@
+"""Thin numpy <-> C-ABI helpers for the GPU parity tests (calls go through ctypes into libmcn_hip.so exactly as
+the product does; torch is only the device-memory container)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from myconvnet_amd import _ffi
+from myconvnet_amd._ffi import lib
+from oracle import ops as O
+
+DEV = 'cuda:0'
+TDT = {'float32': torch.float32, 'bfloat16': torch.bfloat16}
+MDT = {'float32': _ffi.F32, 'bfloat16': _ffi.BF16}
+
+
+def dev(a, dtype='float32'):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV).to(TDT[dtype]).contiguous()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.float().cpu().numpy()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def bf16_round(a):
+    """Round an fp32/fp64 array to bf16 precision (what the device stores), returned as float64."""
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
+def geom(x_shape, w_shape, stride, padding, dilation=1, x_cs=0):
+    n, h, w, c = x_shape
+    kh, kw, cin, cout = w_shape
+    sh, sw = O._pair(stride)
+    dh, dw = O._pair(dilation)
+    pads = O.resolve_pads(h, w, kh, kw, sh, sw, padding, dh, dw)
+    return _ffi.conv_geom(n, h, w, cin, cout, kh, kw, sh, sw, dh, dw, pads, x_cs)
+
+
+def workspace(nbytes):
+    return torch.zeros(max(int(nbytes), 256) // 4 + 64, dtype=torch.float32, device=DEV)
+
+
+def conv_fwd(x, w, stride, padding, dilation=1, dtype='float32', bias=None, x_cs=0):
+    g = geom(x.shape[:3] + (w.shape[2],), w.shape, stride, padding, dilation, x_cs)
+    oh = O.out_size(x.shape[1], w.shape[0], O._pair(stride)[0], padding, O._pair(dilation)[0])
+    ow = O.out_size(x.shape[2], w.shape[1], O._pair(stride)[1], padding, O._pair(dilation)[1])
+    xd, wd = dev(x, dtype), dev(w)
+    bd = dev(bias) if bias is not None else None
+    y = torch.full((x.shape[0], oh, ow, w.shape[3]), float('nan'), dtype=TDT[dtype], device=DEV)
+    ws = workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), MDT[dtype]))
+    _ffi.check(lib.mcn_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if bd is not None else 0, y.data_ptr(), ctypes.byref(g),
+                                  MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, stream()))
+    return host(y)
+
+
+def conv_dgrad(dy, w, x_shape, stride, padding, dilation=1, dtype='float32', accumulate_into=None):
+    g = geom(x_shape, w.shape, stride, padding, dilation)
+    dyd, wd = dev(dy, dtype), dev(w)
+    if accumulate_into is not None:
+        dx = dev(accumulate_into, dtype)
+    else:
+        dx = torch.full(tuple(x_shape), float('nan'), dtype=TDT[dtype], device=DEV)
+    ws = workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), MDT[dtype]))
+    _ffi.check(lib.mcn_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), ctypes.byref(g), 1 if accumulate_into is not None else 0,
+                                    MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, stream()))
+    return host(dx)
+
+
+def conv_wgrad(x, dy, w_shape, stride, padding, dilation=1, dtype='float32', with_bias=False, scale=1.0, x_cs=0):
+    g = geom(x.shape[:3] + (w_shape[2],), w_shape, stride, padding, dilation, x_cs)
+    xd, dyd = dev(x, dtype), dev(dy, dtype)
+    dw = torch.full(tuple(w_shape), float('nan'), dtype=torch.float32, device=DEV)
+    db = torch.full((w_shape[3],), float('nan'), dtype=torch.float32, device=DEV) if with_bias else None
+    ws = workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_WGRAD, ctypes.byref(g), MDT[dtype]))
+    _ffi.check(lib.mcn_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else 0, ctypes.byref(g),
+                                    float(scale), MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, stream()))
+    return (host(dw), host(db)) if with_bias else host(dw)
+
+
+def bn_fwd_train(x, gamma, beta, eps=1e-3, dtype='float32', skip=None, act=0, running=None, momentum=0.99):
+    c = x.shape[-1]
+    m = x.size // c
+    xd = dev(x, dtype)
+    gd, bd = dev(gamma), dev(beta)
+    sd = dev(skip, dtype) if skip is not None else None
+    y = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    sm, si, bm, bv = [torch.zeros(c, dtype=torch.float32, device=DEV) for _ in range(4)]
+    rm = dev(running[0]) if running is not None else None
+    rv = dev(running[1]) if running is not None else None
+    ws = workspace(lib.mcn_bn_workspace_bytes(m, c))
+    _ffi.check(lib.mcn_bn_fwd_train(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sd.data_ptr() if sd is not None else 0, y.data_ptr(),
+                                    sm.data_ptr(), si.data_ptr(), bm.data_ptr(), bv.data_ptr(), rm.data_ptr() if rm is not None else 0,
+                                    rv.data_ptr() if rv is not None else 0, momentum, m, c, eps, act, MDT[dtype], ws.data_ptr(),
+                                    ws.numel() * 4, stream()))
+    out = dict(y=host(y), save_mean=host(sm), save_invstd=host(si), batch_mean=host(bm), batch_var=host(bv))
+    if running is not None:
+        out['running_mean'], out['running_var'] = host(rm), host(rv)
+    return out
+
+
+def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want_dskip=False, scale=1.0):
+    c = x.shape[-1]
+    m = x.size // c
+    dyd, xd = dev(dy, dtype), dev(x, dtype)
+    yd = dev(y, dtype) if y is not None else None
+    gd, smd, sid = dev(gamma), dev(save_mean), dev(save_invstd)
+    dx = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    dsk = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV) if want_dskip else None
+    dg, db = torch.zeros(c, dtype=torch.float32, device=DEV), torch.zeros(c, dtype=torch.float32, device=DEV)
+    ws = workspace(lib.mcn_bn_workspace_bytes(m, c))
+    _ffi.check(lib.mcn_bn_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr() if yd is not None else 0, gd.data_ptr(), smd.data_ptr(), sid.data_ptr(),
+                              dx.data_ptr(), dsk.data_ptr() if dsk is not None else 0, dg.data_ptr(), db.data_ptr(), float(scale), m, c, act,
+                              MDT[dtype], ws.data_ptr(), ws.numel() * 4, stream()))
+    return host(dx), host(dg), host(db), (host(dsk) if dsk is not None else None)

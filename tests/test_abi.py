@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/mcn.h declares
+(no compute without a GPU), and argument validation returns status codes + messages instead of crashing."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'mcn.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mcn_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from myconvnet_amd import _ffi
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), 'libmcn_hip.so does not export {}'.format(s)
+    assert set(syms) == set(_ffi.SIGNATURES), set(syms) ^ set(_ffi.SIGNATURES)
+    assert _ffi.lib.mcn_version() == 100
+
+
+def test_header_compiles_as_c():
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, 't.c')
+        open(c, 'w').write('#include "mcn.h"\nint main(void){ mcn_conv_geom g; (void)g; return MCN_OK; }\n')
+        subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-c', c, '-o', os.path.join(d, 't.o')])
+
+
+def test_argument_validation_without_gpu():
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    g = _ffi.conv_geom(1, 8, 8, 0, 16, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))       # Cin = 0
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
+    assert 'bad geometry' in _ffi.last_error()
+    g = _ffi.conv_geom(1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))
+    assert lib.mcn_conv2d_fwd(0, 0, 0, 0, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NCHW, 0, 0, 0) == _ffi.E_UNSUPPORTED
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F16, _ffi.NHWC, 0, 0, 0) == _ffi.E_UNSUPPORTED
+    assert 'fp16' in _ffi.last_error()
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_WORKSPACE
+    assert lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) >= 16 * 9 * 16 * 4
+    assert lib.mcn_bn_fwd_train(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.9, 10, 4, 1e-3, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
+    assert lib.mcn_bn_workspace_bytes(1000, 64) > 0
+    assert lib.mcn_relu_fwd(0, 0, 10, _ffi.F32, 0) == _ffi.E_BADARG
+    assert lib.mcn_sgd_nesterov_fused(0, 0, 0, 0, 10, 0.1, 0.9, 0.0, 0.0, 0.99, 1.0, 0) == _ffi.E_BADARG
+    with pytest.raises(_ffi.McnError):
+        _ffi.check(lib.mcn_softmax_xent_fwd_bwd(0, 0, 0, 0, 0, 0, 0, 0, 4, 10, 0.0, 1.0, 0))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from myconvnet_amd import _ffi
+    with pytest.raises(ImportError, match='no CPU fallback'):
+        _ffi.load(str(tmp_path / 'libmcn_hip.so'))

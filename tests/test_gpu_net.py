@@ -1,0 +1,155 @@
+"""GPU parity tests, whole network: the product's ResNet / VGG graphs (HIP kernels through the C-ABI) against the
+oracle's stand-alone NumPy restatement of the same reference model files, same injected weights, same batch.
+
+fp32 tolerance: north_star's 1e-3 relative (asserted tighter where the network is well conditioned); arg-max of the
+predictions bit-exact.  bf16 is checked against the float64 oracle with bf16-sized tolerances.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import net as ON  # noqa: E402
+from oracle import ops as O   # noqa: E402
+
+RNG = np.random.default_rng(5)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def make_resnet(kind, dtype, fuse, batch=4, size=64, classes=10):
+    import myconvnet_amd as M
+    cls = M.ResNet50 if kind == 50 else M.ResNet18
+    spec = ON.ResNetSpec.resnet50(classes, 8) if kind == 50 else ON.ResNetSpec.resnet18(classes, 8)
+    model = cls([size, size, 3], classes, batch_size=batch, width_div=8, fuse=fuse, half_precision=(dtype == 'bfloat16'), num_gpus=1)
+    params, stats = ON.init_variables(spec.variables(), seed=3, dtype=np.float32)
+    rng = np.random.default_rng(9)
+    for k in params:                                   # non-trivial BN parameters (zero-init gammas would hide branches)
+        if k.endswith('gamma'):
+            params[k] = (0.5 + rng.random(params[k].shape)).astype(np.float32)
+        if k.endswith('beta'):
+            params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    model.set_variables(dict(params, **stats))
+    return model, spec, params, stats
+
+
+@pytest.mark.parametrize('kind,fuse', [(50, True), (50, False), (18, True)])
+def test_resnet_two_steps_fp32(kind, fuse):
+    import myconvnet_amd as M
+    model, spec, params, stats = make_resnet(kind, 'float32', fuse)
+    assert set(model.variables) == set(params) | set(stats)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    for step in range(2):
+        x = RNG.random((4, 64, 64, 3)).astype(np.float32)
+        y = np.array([1, 7, 3, 9], dtype=np.float32)
+        model.feed(x, y)
+        loss, y_true, y_pred = opt._step(None)
+        rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=4)
+        assert abs(loss - rloss) <= 1e-4 * abs(rloss), (loss, rloss)
+        assert rel_l2(y_pred, rpred) <= 1e-4
+        np.testing.assert_array_equal(y_pred.argmax(-1), rpred.argmax(-1))
+        np.testing.assert_array_equal(y_true, O.one_hot_labels(y, 10))
+        grads = model.get_variables('grad')
+        worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
+        assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+        got = model.get_variables('data')
+        worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
+        assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
+        ema = model.get_variables('ema')
+        worst = max((rel_l2(ema[k], v), k) for k, v in list(state.ema.items()) + list(state.ema_stats.items()))
+        assert worst[0] <= 1e-4, 'step {}: worst EMA {}'.format(step, worst)
+
+
+def test_resnet_step_bf16():
+    import myconvnet_amd as M
+    model, spec, params, stats = make_resnet(50, 'bfloat16', True)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    x = RNG.random((4, 64, 64, 3)).astype(np.float32)
+    y = np.array([1, 7, 3, 9], dtype=np.float32)
+    model.feed(x, y)
+    loss, _, y_pred = opt._step(None)
+    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=4)
+    assert abs(loss - rloss) <= 3e-2 * abs(rloss), (loss, rloss)
+    assert rel_l2(y_pred, rpred) <= 6e-2
+    grads = model.get_variables('grad')
+    big = [k for k in rgrads if k.endswith('weights')]
+    worst = max((rel_l2(grads[k], rgrads[k]), k) for k in big)
+    assert worst[0] <= 0.15, worst
+
+
+def test_resnet_eval_uses_ema_and_running_stats():
+    import myconvnet_amd as M
+    model, spec, params, stats = make_resnet(50, 'float32', True)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    x = RNG.random((4, 64, 64, 3)).astype(np.float32)
+    y = np.array([2, 0, 5, 9], dtype=np.float32)
+    model.feed(x, y)
+    opt._step(None)
+    ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=4)
+    ds = M.DataSet(x, y, batch_size=4)
+    _, y_true, y_pred, loss = model.predict(ds, return_images=False)
+    t, out, pred, rloss, _ = ON.forward_loss(spec, state, x.astype(np.float64), y.astype(np.float64), train=False, use_ema=True)
+    # the L2 term of the reported loss always reads the master variables (convnet.py:535)
+    rloss = rloss - O.l2_reg_loss([v for k, v in state.ema.items() if k.endswith('/weights')]) + \
+        O.l2_reg_loss([v for k, v in state.params.items() if k.endswith('/weights')])
+    assert rel_l2(y_pred, pred) <= 1e-4
+    assert abs(loss - rloss) <= 1e-4 * abs(rloss)
+    np.testing.assert_array_equal(y_pred.argmax(-1), pred.argmax(-1))
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_vgg16_trunk_config1(dtype):
+    """BASELINE config #1: VGG-16 on 8x8x3 random images, batch 4 (trunk only: the head needs 224x224)."""
+    import myconvnet_amd as M
+    spec = ON.VGGSpec(16, 10, backbone_only=True, width_div=4)
+    model = M.VGG16([8, 8, 3], 10, batch_size=4, backbone_only=True, width_div=4, half_precision=(dtype == 'bfloat16'), num_gpus=1)
+    params, _ = ON.init_variables(spec.variables(), seed=1, dtype=np.float32)
+    rng = np.random.default_rng(2)
+    for k in params:
+        if k.endswith('biases'):
+            params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+        else:
+            params[k] = (params[k] * 0.3).astype(np.float32)      # keep activations O(1) after the *255 input scaling
+    model.set_variables(params)
+    x = RNG.random((4, 8, 8, 3)).astype(np.float32)
+    model.feed(x, np.zeros(4, np.float32))
+    model.forward(train=True)
+    out = model.d['block_4']
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {})
+    tape, rout, _, _, _ = ON.forward_loss(spec, state, x.astype(np.float64), None)
+    got = model.fetch(out)
+    tol = 1e-4 if dtype == 'float32' else 5e-2
+    assert got.shape == rout.a.shape == (4, 1, 1, 128)
+    assert rel_l2(got, rout.a) <= tol
+    # backward from an injected output gradient
+    dy = RNG.standard_normal(rout.a.shape).astype(np.float32)
+    out.grad.copy_(torch.as_tensor(dy).to(out.grad.dtype).to(out.grad.device))
+    model.backward()
+    rout.g = torch.as_tensor(dy).to(out.grad.dtype).float().numpy().astype(np.float64)
+    rgrads = tape.backward()
+    grads = model.get_variables('grad')
+    worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
+    assert worst[0] <= (1e-3 if dtype == 'float32' else 0.2), worst
+
+
+def test_channel_first_input_matches_nhwc():
+    """channel_first=True: the batch is fed NCHW (reference convnet.py:467-468) and must give the same logits."""
+    import myconvnet_amd as M
+    a, spec, params, stats = make_resnet(50, 'float32', True)
+    b = M.ResNet50([64, 64, 3], 10, batch_size=4, width_div=8, channel_first=True, num_gpus=1)
+    b.set_variables(dict(params, **stats))
+    x = RNG.random((4, 64, 64, 3)).astype(np.float32)
+    y = np.array([1, 2, 3, 4], np.float32)
+    a.feed(x, y)
+    a.forward(train=True)
+    b.feed(np.ascontiguousarray(x.transpose(0, 3, 1, 2)), y)
+    b.forward(train=True)
+    np.testing.assert_array_equal(a.fetch(a.logits), b.fetch(b.logits))
+    assert b.d['block_1'].get_shape() == [4, 32, 16, 16]

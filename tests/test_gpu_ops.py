@@ -1,0 +1,404 @@
+"""GPU parity tests, op by op: HIP kernels (through the C-ABI) vs the NumPy oracle on the same seeded inputs.
+
+Tolerances: fp32 path — north_star's 1e-3 relative (we assert much tighter: rel-L2 <= 2e-5 and max-abs <= 1e-3 of the
+reference's max magnitude); bf16 path — oracle evaluated in float64 on the bf16-rounded inputs, rel-L2 <= 8e-3
+(bf16 has 8 significant bits; outputs are rounded once).  Integer outputs (arg-max) are bit-exact.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O  # noqa: E402
+
+
+def _u():
+    import abi_util
+    return abi_util
+
+
+RNG = np.random.default_rng(11)
+DTYPES = ['float32', 'bfloat16']
+
+
+def check(got, ref, dtype, what='', rel=None, mx=None):
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    assert got.shape == ref.shape, '{}: shape {} vs {}'.format(what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), '{}: non-finite output'.format(what)
+    scale = max(np.abs(ref).max(), 1e-30)
+    rl2 = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+    mabs = np.abs(got - ref).max() / scale
+    rel = rel if rel is not None else (2e-5 if dtype == 'float32' else 8e-3)
+    mx = mx if mx is not None else (1e-3 if dtype == 'float32' else 3e-2)
+    assert rl2 <= rel and mabs <= mx, '{} [{}]: rel-L2 {:.3e} (<= {:.1e}), max-abs/scale {:.3e} (<= {:.1e})'.format(what, dtype, rl2, rel, mabs, mx)
+
+
+def q(a, dtype):
+    return _u().bf16_round(a) if dtype == 'bfloat16' else np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+# n, h, w, cin, cout, k, stride, padding, dilation
+CONV_CASES = [
+    (2, 8, 8, 16, 32, 1, 1, 'SAME', 1),          # 1x1 plain GEMM path
+    (2, 8, 8, 16, 32, 1, 2, 'SAME', 1),          # 1x1 / 2 (projection shortcut)
+    (2, 7, 7, 32, 16, 3, 1, 'SAME', 1),          # 3x3 / 1
+    (2, 16, 16, 16, 16, 3, 2, 'SAME', 1),        # 3x3 / 2 even H: pads (0,1)
+    (2, 15, 15, 16, 16, 3, 2, 'SAME', 1),        # 3x3 / 2 odd H: pads (1,1)
+    (3, 14, 14, 64, 64, 3, 1, 'SAME', 1),        # one full 64-wide K step per tap
+    (2, 14, 14, 128, 256, 1, 1, 'SAME', 1),      # multi K-step, BN=128 tiles
+    (5, 9, 11, 72, 136, 3, 1, 'SAME', 1),        # ragged M / N / K tails
+    (2, 9, 9, 8, 16, 7, 1, 'VALID', 1),          # VGG-head style VALID
+    (1, 14, 14, 16, 16, 3, 1, 'SAME', 2),        # dilated (DeepLab row)
+    (2, 8, 6, 5, 7, 3, 1, 'SAME', 1),            # odd channels: naive fallback kernels
+    (1, 1, 1, 32, 16, 3, 1, 'SAME', 1),          # 1x1 map (VGG trunk at 8x8 ends here)
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    u = _u()
+    n, h, w_, cin, cout, k, s, pad, dil = case
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    w = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    xq, wq = q(x, dtype), q(w, dtype)
+    y_ref = O.conv2d_fwd(xq, wq, s, pad, dil)
+    check(u.conv_fwd(x, w, s, pad, dil, dtype), y_ref, dtype, 'conv_fwd')
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dyq = q(dy, dtype)
+    check(u.conv_dgrad(dy, w, x.shape, s, pad, dil, dtype), O.conv2d_dgrad(dyq, wq, x.shape, s, pad, dil), dtype, 'conv_dgrad')
+    dw_ref = O.conv2d_wgrad(xq, dyq, w.shape, s, pad, dil)
+    dw, db = u.conv_wgrad(x, dy, w.shape, s, pad, dil, dtype, with_bias=True)
+    check(dw, dw_ref, dtype, 'conv_wgrad', rel=2e-5 if dtype == 'float32' else 2e-3)   # fp32 accumulation of exact products
+    check(db, O.bias_add_bwd(dyq), dtype, 'bias_grad', rel=2e-5 if dtype == 'float32' else 2e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_stem_padded_channels(dtype):
+    """Stem: 7x7/2 on 3 channels stored with a channel stride of one 16-byte chunk (pads (2,3))."""
+    u = _u()
+    cs = 4 if dtype == 'float32' else 8
+    x = RNG.random((2, 32, 32, 3)).astype(np.float32)
+    xp = np.zeros((2, 32, 32, cs), np.float32)
+    xp[..., :3] = x
+    w = (RNG.standard_normal((7, 7, 3, 16)) / 12).astype(np.float32)
+    y_ref = O.conv2d_fwd(q(x, dtype), q(w, dtype), 2, 'SAME')
+    check(u.conv_fwd(xp, w, 2, 'SAME', 1, dtype, x_cs=cs), y_ref, dtype, 'stem fwd')
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    check(u.conv_wgrad(xp, dy, w.shape, 2, 'SAME', 1, dtype, x_cs=cs), O.conv2d_wgrad(q(x, dtype), q(dy, dtype), w.shape, 2, 'SAME'), dtype,
+          'stem wgrad', rel=2e-5 if dtype == 'float32' else 2e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_bias_and_dgrad_accumulate(dtype):
+    u = _u()
+    x = RNG.standard_normal((2, 8, 8, 16)).astype(np.float32)
+    w = (RNG.standard_normal((3, 3, 16, 32)) / 12).astype(np.float32)
+    b = RNG.standard_normal(32).astype(np.float32)
+    check(u.conv_fwd(x, w, 1, 'SAME', 1, dtype, bias=b), O.conv2d_fwd(q(x, dtype), q(w, dtype), 1, 'SAME') + b, dtype, 'conv+bias')
+    dy = RNG.standard_normal((2, 8, 8, 32)).astype(np.float32)
+    base = RNG.standard_normal(x.shape).astype(np.float32)
+    ref = q(base, dtype) + O.conv2d_dgrad(q(dy, dtype), q(w, dtype), x.shape, 1, 'SAME')
+    check(u.conv_dgrad(dy, w, x.shape, 1, 'SAME', 1, dtype, accumulate_into=base), ref, dtype, 'dgrad accumulate')
+    # strided 1x1 accumulate (projection shortcut joining conv_0's dgrad)
+    w1 = (RNG.standard_normal((1, 1, 16, 32)) / 4).astype(np.float32)
+    dy1 = RNG.standard_normal((2, 4, 4, 32)).astype(np.float32)
+    ref = q(base, dtype) + O.conv2d_dgrad(q(dy1, dtype), q(w1, dtype), x.shape, 2, 'SAME')
+    check(u.conv_dgrad(dy1, w1, x.shape, 2, 'SAME', 1, dtype, accumulate_into=base), ref, dtype, 'strided dgrad accumulate')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(4, 6, 6, 16), (2, 5, 7, 24), (3, 4, 4, 7), (8, 14, 14, 256), (2, 3, 3, 2048)])
+def test_bn_fwd_bwd(shape, dtype):
+    u = _u()
+    c = shape[-1]
+    x = (RNG.standard_normal(shape) * 2.0 + 3.0).astype(np.float32)        # non-zero mean: exercises the shifted sums
+    g = (0.5 + RNG.random(c)).astype(np.float32)
+    b = RNG.standard_normal(c).astype(np.float32)
+    xq = q(x, dtype)
+    y, bm, bv, sm, si = O.bn_fwd_train(xq, g.astype(np.float64), b.astype(np.float64), 1e-3)
+    run0 = (RNG.standard_normal(c).astype(np.float32), (0.5 + RNG.random(c)).astype(np.float32))
+    out = u.bn_fwd_train(x, g, b, 1e-3, dtype, running=run0, momentum=0.9)
+    check(out['y'], y, dtype, 'bn y')
+    check(out['batch_mean'], bm, 'float32', 'bn batch_mean', rel=1e-5)
+    check(out['batch_var'], bv, 'float32', 'bn batch_var (unbiased)', rel=1e-5)
+    check(out['save_invstd'], si, 'float32', 'bn invstd', rel=1e-5)
+    rm, rv = O.bn_running_update(run0[0].astype(np.float64), run0[1].astype(np.float64), bm, bv, 0.9)
+    check(out['running_mean'], rm, 'float32', 'running mean', rel=1e-5)
+    check(out['running_var'], rv, 'float32', 'running var', rel=1e-5)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    dx, dg, db = O.bn_bwd(q(dy, dtype), xq, g.astype(np.float64), sm, si)
+    gdx, gdg, gdb, _ = u.bn_bwd(dy, x, None, g, sm, si, dtype)
+    check(gdx, dx, dtype, 'bn dx')
+    check(gdg, dg, 'float32', 'bn dgamma', rel=1e-4)
+    check(gdb, db, 'float32', 'bn dbeta', rel=1e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_fused_add_relu(dtype):
+    """y = relu(bn(x) + skip); backward masks with [y > 0] and fans the masked gradient out to the skip branch."""
+    u = _u()
+    shape = (4, 7, 7, 32)
+    x = RNG.standard_normal(shape).astype(np.float32)
+    skip = RNG.standard_normal(shape).astype(np.float32)
+    g = (0.5 + RNG.random(32)).astype(np.float32)
+    b = RNG.standard_normal(32).astype(np.float32)
+    xq, sq = q(x, dtype), q(skip, dtype)
+    ybn, _, _, sm, si = O.bn_fwd_train(xq, g.astype(np.float64), b.astype(np.float64), 1e-3)
+    y_ref = np.maximum(ybn + sq, 0)
+    out = u.bn_fwd_train(x, g, b, 1e-3, dtype, skip=skip, act=1)
+    check(out['y'], y_ref, dtype, 'bn+add+relu')
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    ydev = out['y']                                    # the mask must come from the values the device stored
+    dmask = q(dy, dtype) * (ydev > 0)
+    dx, dg, db = O.bn_bwd(dmask, xq, g.astype(np.float64), sm, si)
+    gdx, gdg, gdb, gds = u.bn_bwd(dy, x, ydev, g, sm, si, dtype, act=1, want_dskip=True)
+    check(gdx, dx, dtype, 'fused dx')
+    check(gds, dmask, dtype, 'fused dskip', rel=1e-6 if dtype == 'float32' else 1e-6)
+    check(gdg, dg, 'float32', 'fused dgamma', rel=1e-4)
+    check(gdb, db, 'float32', 'fused dbeta', rel=1e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_infer_and_affine(dtype):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    shape = (2, 5, 5, 16)
+    x = RNG.standard_normal(shape).astype(np.float32)
+    g, b = (0.5 + RNG.random(16)).astype(np.float32), RNG.standard_normal(16).astype(np.float32)
+    mu, var = RNG.standard_normal(16).astype(np.float32), (0.5 + RNG.random(16)).astype(np.float32)
+    xd, y = u.dev(x, dtype), torch.zeros(shape, dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_infer(xd.data_ptr(), u.dev(g).data_ptr(), u.dev(b).data_ptr(), u.dev(mu).data_ptr(), u.dev(var).data_ptr(), 0,
+                                    y.data_ptr(), 50, 16, 1e-3, 0, u.MDT[dtype], u.stream()))
+    check(u.host(y), O.bn_fwd_infer(q(x, dtype), g.astype(np.float64), b.astype(np.float64), mu.astype(np.float64), var.astype(np.float64)), dtype, 'bn infer')
+    _ffi.check(lib.mcn_channel_affine(xd.data_ptr(), u.dev(g).data_ptr(), u.dev(b).data_ptr(), y.data_ptr(), 50, 16, u.MDT[dtype], u.stream()))
+    check(u.host(y), q(x, dtype) * g + b, dtype, 'channel affine')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(16, 3, 2, 'SAME', 16), (15, 3, 2, 'SAME', 8), (8, 2, 2, 'SAME', 32), (7, 2, 2, 'SAME', 5), (1, 2, 2, 'SAME', 8),
+                                 (8, 2, 2, 'VALID', 16)])
+def test_maxpool(cfg, dtype):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    h, k, s, pad, c = cfg
+    x = RNG.standard_normal((2, h, h, c)).astype(np.float32)
+    x[0, :, :, 0] = 0.0                              # ties (post-ReLU zeros are the common case)
+    xq = q(x, dtype)
+    y_ref, arg_ref = O.maxpool_fwd(xq, k, s, pad)
+    pt, _, pl, _ = O.resolve_pads(h, h, k, k, s, s, pad)
+    oh = y_ref.shape[1]
+    xd = u.dev(x, dtype)
+    y = torch.zeros(y_ref.shape, dtype=u.TDT[dtype], device=u.DEV)
+    arg = torch.zeros(y_ref.shape, dtype=torch.int8, device=u.DEV)
+    _ffi.check(lib.mcn_maxpool_fwd(xd.data_ptr(), y.data_ptr(), arg.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
+    np.testing.assert_array_equal(u.host(y).astype(np.float64), y_ref)              # max is exact
+    np.testing.assert_array_equal(arg.cpu().numpy(), arg_ref)                       # integer arg-max bit-exact
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dx = torch.zeros(x.shape, dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_maxpool_bwd(u.dev(dy, dtype).data_ptr(), arg.data_ptr(), dx.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype],
+                                   u.stream()))
+    check(u.host(dx), O.maxpool_bwd(q(dy, dtype), arg_ref, x.shape, k, s, pad), dtype, 'maxpool bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(8, 3, 2, 'SAME', 16), (7, 3, 1, 'SAME', 8), (8, 2, 2, 'VALID', 5)])
+def test_avgpool(cfg, dtype):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    h, k, s, pad, c = cfg
+    x = RNG.standard_normal((2, h, h, c)).astype(np.float32)
+    y_ref = O.avgpool_fwd(q(x, dtype), k, s, pad)
+    pt, _, pl, _ = O.resolve_pads(h, h, k, k, s, s, pad)
+    oh = y_ref.shape[1]
+    y = torch.zeros(y_ref.shape, dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_avgpool_fwd(u.dev(x, dtype).data_ptr(), y.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
+    check(u.host(y), y_ref, dtype, 'avgpool fwd')
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dx = torch.zeros(x.shape, dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_avgpool_bwd(u.dev(dy, dtype).data_ptr(), dx.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
+    check(u.host(dx), O.avgpool_bwd(q(dy, dtype), x.shape, k, s, pad), dtype, 'avgpool bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_global_avgpool_and_eltwise(dtype):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    md = u.MDT[dtype]
+    x = RNG.standard_normal((3, 7, 7, 40)).astype(np.float32)
+    y = torch.zeros((3, 40), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_global_avgpool_fwd(u.dev(x, dtype).data_ptr(), y.data_ptr(), 3, 49, 40, md, u.stream()))
+    check(u.host(y), O.global_avgpool_fwd(q(x, dtype)), dtype, 'gap fwd')
+    dy = RNG.standard_normal((3, 40)).astype(np.float32)
+    dx = torch.zeros(x.shape, dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_global_avgpool_bwd(u.dev(dy, dtype).data_ptr(), dx.data_ptr(), 3, 49, 40, md, u.stream()))
+    check(u.host(dx), O.global_avgpool_bwd(q(dy, dtype), x.shape), dtype, 'gap bwd')
+    # relu / relu_bwd / add_relu / accumulate on a ragged length (vector body + scalar tail)
+    n = 1003
+    a, b = RNG.standard_normal(n).astype(np.float32), RNG.standard_normal(n).astype(np.float32)
+    ad, bd = u.dev(a, dtype), u.dev(b, dtype)
+    o = torch.zeros(n, dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_relu_fwd(ad.data_ptr(), o.data_ptr(), n, md, u.stream()))
+    np.testing.assert_array_equal(u.host(o), np.maximum(q(a, dtype), 0))
+    _ffi.check(lib.mcn_relu_bwd(ad.data_ptr(), bd.data_ptr(), o.data_ptr(), n, md, u.stream()))
+    np.testing.assert_array_equal(u.host(o), q(a, dtype) * (q(b, dtype) > 0))
+    _ffi.check(lib.mcn_add_relu_fwd(ad.data_ptr(), bd.data_ptr(), o.data_ptr(), n, 1, md, u.stream()))
+    check(u.host(o), np.maximum(q(a, dtype) + q(b, dtype), 0), dtype, 'add_relu')
+    _ffi.check(lib.mcn_accumulate(ad.data_ptr(), bd.data_ptr(), n, md, u.stream()))
+    check(u.host(ad), q(a, dtype) + q(b, dtype), dtype, 'accumulate')
+    f = torch.zeros(n, dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_cast(bd.data_ptr(), md, f.data_ptr(), _ffi.F32, n, u.stream()))
+    np.testing.assert_array_equal(u.host(f), q(b, dtype))
+
+
+@pytest.mark.parametrize('layout', ['NHWC', 'NCHW'])
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_input_prep_and_one_hot(dtype, layout):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    x = RNG.random((2, 6, 5, 3)).astype(np.float32)
+    src = x if layout == 'NHWC' else np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+    cs = 8
+    y = torch.full((2, 6, 5, cs), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_input_prep(u.dev(src).data_ptr(), y.data_ptr(), 2, 6, 5, 3, cs, 0.5, 2.0, _ffi.NCHW if layout == 'NCHW' else _ffi.NHWC,
+                                  u.MDT[dtype], u.stream()))
+    got = u.host(y)
+    check(got[..., :3], O.input_prep(x.astype(np.float64)), dtype, 'input_prep')
+    assert (got[..., 3:] == 0).all()
+    labels = np.array([1, 3, np.nan, 9, 0, 12, -1], dtype=np.float32)
+    oh = torch.zeros((7, 10), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_one_hot(u.dev(labels).data_ptr(), oh.data_ptr(), 7, 10, u.stream()))
+    np.testing.assert_array_equal(u.host(oh), O.one_hot_labels(labels, 10))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('dims', [(8, 64, 40), (5, 2048 // 8, 1000), (3, 10, 7)])
+def test_fc_fwd_bwd(dims, dtype):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    B, In, Out = dims
+    x = RNG.standard_normal((B, In)).astype(np.float32)
+    w = (RNG.standard_normal((In, Out)) / np.sqrt(In)).astype(np.float32)
+    b = RNG.standard_normal(Out).astype(np.float32)
+    md = u.MDT[dtype]
+    ws = u.workspace(lib.mcn_fc_workspace_bytes(B, In, Out, md))
+    xd, wd, bd = u.dev(x, dtype), u.dev(w), u.dev(b)
+    y = torch.zeros((B, Out), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_fc_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, In, Out, md, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    xq, wq = q(x, dtype), q(w, dtype)
+    check(u.host(y), O.fc_fwd(xq, wq, b.astype(np.float64)), dtype, 'fc fwd')
+    dy = RNG.standard_normal((B, Out)).astype(np.float32)
+    dx = torch.zeros((B, In), dtype=u.TDT[dtype], device=u.DEV)
+    dw = torch.zeros((In, Out), dtype=torch.float32, device=u.DEV)
+    db = torch.zeros(Out, dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_fc_bwd(u.dev(dy, dtype).data_ptr(), xd.data_ptr(), wd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0, B, In, Out,
+                              md, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    rdx, rdw, rdb = O.fc_bwd(q(dy, dtype), xq, wq)
+    check(u.host(dx), rdx, dtype, 'fc dx')
+    check(u.host(dw), rdw, dtype, 'fc dw', rel=2e-5 if dtype == 'float32' else 2e-3)
+    check(u.host(db), rdb, dtype, 'fc db', rel=2e-5 if dtype == 'float32' else 2e-3)
+
+
+@pytest.mark.parametrize('ls', [0.0, 0.1])
+def test_softmax_xent(ls):
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    B, C = 7, 1000
+    logits = (RNG.standard_normal((B, C)) * 3).astype(np.float32)
+    labels = np.array([1, 3, np.nan, 999, 0, 1200, 5], dtype=np.float32)
+    oh = O.one_hot_labels(labels, C)
+    cw = (0.5 + RNG.random(C)).astype(np.float32)
+    pred_r, loss_r, ce_r, dl_r = O.softmax_xent_fwd_bwd(logits.astype(np.float64), oh.astype(np.float64), cw.astype(np.float64), ls, 4.0)
+    pred, dl = [torch.zeros((B, C), dtype=torch.float32, device=u.DEV) for _ in range(2)]
+    ce, coef, loss = [torch.zeros(8, dtype=torch.float32, device=u.DEV) for _ in range(3)]
+    _ffi.check(lib.mcn_softmax_xent_fwd_bwd(u.dev(logits).data_ptr(), u.dev(oh).data_ptr(), u.dev(cw).data_ptr(), pred.data_ptr(), ce.data_ptr(),
+                                            coef.data_ptr(), dl.data_ptr(), loss.data_ptr(), B, C, ls, 4.0, u.stream()))
+    check(u.host(pred), pred_r, 'float32', 'pred', rel=1e-5)
+    check(u.host(ce)[:B], ce_r, 'float32', 'ce', rel=1e-5)
+    check(u.host(dl), dl_r, 'float32', 'dlogits', rel=1e-5)
+    assert abs(u.host(loss)[0] - loss_r) <= 1e-5 * abs(loss_r)
+    np.testing.assert_array_equal(u.host(pred).argmax(-1), pred_r.argmax(-1))          # integer arg-max bit-exact
+
+
+def test_sgd_nesterov_ema_l2_trajectory():
+    """3-step trajectory of the fused update vs the oracle (EMA of the pre-update value, L2 folded into the gradient)."""
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    n = 1027
+    w0 = RNG.standard_normal(n).astype(np.float32)
+    w, a, e = w0.astype(np.float64), np.zeros(n), w0.astype(np.float64)
+    pad = (n + 3) // 4 * 4
+    wd_, ad_, ed_ = [torch.zeros(pad, dtype=torch.float32, device=u.DEV) for _ in range(3)]
+    wd_[:n] = u.dev(w0)
+    ed_[:n] = u.dev(w0)
+    for step in range(3):
+        g = RNG.standard_normal(n).astype(np.float32)
+        gd = torch.zeros(pad, dtype=torch.float32, device=u.DEV)
+        gd[:n] = u.dev(g)
+        d = O.ema_decay(0.99, step)
+        lr = 0.05 * (step + 1)
+        w, a, e = O.sgd_nesterov_step(w, g.astype(np.float64), a, lr, 0.9, l2=1e-4, ema=e, ema_d=d, wd=1e-3, grad_scale=0.5)
+        _ffi.check(lib.mcn_sgd_nesterov_fused(wd_.data_ptr(), gd.data_ptr(), ad_.data_ptr(), ed_.data_ptr(), n, lr, 0.9, 1e-4, 1e-3, d, 0.5, u.stream()))
+        check(u.host(wd_)[:n], w, 'float32', 'w step {}'.format(step), rel=1e-6)
+        check(u.host(ad_)[:n], a, 'float32', 'accum step {}'.format(step), rel=1e-6)
+        check(u.host(ed_)[:n], e, 'float32', 'ema step {}'.format(step), rel=1e-6)
+
+
+def test_l2_loss_ema_and_bn_chain():
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    n = 40000
+    w = RNG.standard_normal(n).astype(np.float32)
+    out = torch.full((4,), 2.5, dtype=torch.float32, device=u.DEV)
+    ws = u.workspace(8192)
+    _ffi.check(lib.mcn_l2_loss(u.dev(w).data_ptr(), n, 1e-4, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, u.stream()))
+    assert abs(u.host(out)[0] - (2.5 + O.l2_reg_loss([w], 1e-4))) < 1e-5
+    run = RNG.standard_normal(300).astype(np.float32)
+    batch = RNG.standard_normal((4, 300)).astype(np.float32)
+    rd = u.dev(run)
+    _ffi.check(lib.mcn_bn_running_chain(rd.data_ptr(), u.dev(batch).data_ptr(), 4, 300, 0.99, u.stream()))
+    ref = run.astype(np.float64)
+    for k in range(4):
+        ref = 0.99 * ref + 0.01 * batch[k]
+    check(u.host(rd), ref, 'float32', 'bn chain', rel=1e-6)
+    sh = u.dev(run)
+    _ffi.check(lib.mcn_ema_update(sh.data_ptr(), u.dev(batch[0]).data_ptr(), 300, 0.9, u.stream()))
+    check(u.host(sh), 0.9 * run + 0.1 * batch[0], 'float32', 'ema', rel=1e-6)
+
+
+def test_full_size_properties():
+    """Size-independent properties at BASELINE's full layer sizes (B=256 is too slow for the oracle):
+    linearity of conv in x, <dy, conv(x)> == <dgrad(dy), x> == <wgrad(x,dy), w> (adjointness), and BN output moments."""
+    u = _u()
+    # block_2/res_0/conv_1 at reduced batch: 3x3/2, 128->128, 56x56
+    n, h, c = 8, 56, 128
+    x = RNG.standard_normal((n, h, h, c)).astype(np.float32)
+    x2 = RNG.standard_normal((n, h, h, c)).astype(np.float32)
+    w = (RNG.standard_normal((3, 3, c, c)) / np.sqrt(9 * c)).astype(np.float32)
+    y1, y2 = u.conv_fwd(x, w, 2, 'SAME'), u.conv_fwd(x2, w, 2, 'SAME')
+    y12 = u.conv_fwd(x + 2 * x2, w, 2, 'SAME')
+    check(y12, y1.astype(np.float64) + 2 * y2, 'float32', 'linearity', rel=1e-5)
+    dy = RNG.standard_normal(y1.shape).astype(np.float32)
+    lhs = float((dy.astype(np.float64) * y1).sum())
+    dx = u.conv_dgrad(dy, w, x.shape, 2, 'SAME')
+    dw = u.conv_wgrad(x, dy, w.shape, 2, 'SAME')
+    assert abs(lhs - float((dx.astype(np.float64) * x).sum())) <= 1e-4 * abs(lhs) + 1e-2
+    assert abs(lhs - float((dw.astype(np.float64) * w).sum())) <= 1e-4 * abs(lhs) + 1e-2
+    out = u.bn_fwd_train(y1, np.ones(c, np.float32), np.zeros(c, np.float32), 1e-3)
+    yb = out['y'].reshape(-1, c).astype(np.float64)
+    assert np.abs(yb.mean(0)).max() < 1e-4
+    v = y1.reshape(-1, c).astype(np.float64).var(0)
+    np.testing.assert_allclose(yb.var(0), v / (v + 1e-3), rtol=1e-3)

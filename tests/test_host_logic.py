@@ -1,0 +1,137 @@
+"""CPU tests of the host side: graph construction through the reference's block-method surface, fusion, the
+reference's printed known answers, parameter naming, LR schedule, EMA rule, data sharding, bucket planner."""
+import numpy as np
+import pytest
+
+import myconvnet_amd as M
+from myconvnet_amd import dist as D
+from oracle import net as ON
+from oracle import ops as O
+
+
+def test_resnet50_known_answers_and_names():
+    net = M.ResNet50([224, 224, 3], 1000, batch_size=256, auto_compile=False)
+    assert net.params == 25557032                       # reference prints this (convnet.py:212)
+    assert net.conv_macs == 4087136256
+    fc = [li for li in net.layer_info if li['name'] == 'block_None/logits'][0]
+    assert fc['flops'] == 2048 * 1000 + 1000
+    spec = ON.ResNetSpec.resnet50(1000)
+    assert [(v.name, v.shape, v.kind if v.kind != 'gamma' else v.kind) for v in net._var_order] == \
+        [(n, tuple(s), k.replace('gamma0', 'gamma')) for n, s, k in spec.variables()]
+    # 16 zero-initialised gammas (models/resnet_v1_5.py:179-181)
+    assert sum(1 for n, s, k in spec.variables() if k == 'gamma0') == 16
+    assert net.block_list == [None, 0, 1, 2, 3, 4]      # None first: _init_model sets _curr_block = None (convnet.py:433)
+    assert len(net.get_collection('weight_variables')) == 54
+    assert len(net.get_collection('norm_statistics')) == 106
+    d = net.d
+    assert d['block_0'].shape == (256, 56, 56, 64) and d['block_4'].shape == (256, 7, 7, 2048)
+    assert d['block_2/res_0/conv_1'].shape == (256, 28, 28, 128)      # v1.5: the 3x3 carries the stride
+    assert d['logits'].shape == (256, 1000)
+
+
+def test_same_padding_geometry_of_the_53_convs():
+    net = M.ResNet50([224, 224, 3], 1000, batch_size=2, auto_compile=False)
+    geoms = {n.scope: n.attrs['geom'] for n in net.graph.nodes if n.op == 'conv'}
+    g = geoms['block_0/conv_0']
+    assert (g.padT, g.padB, g.padL, g.padR, g.x_cs) == (2, 3, 2, 3, 4)
+    g = geoms['block_2/res_0/conv_1']
+    assert (g.KH, g.SH, g.padT, g.padB) == (3, 2, 0, 1)
+    g = geoms['block_2/res_0/conv_skip']
+    assert (g.KH, g.SH, g.padT, g.padB) == (1, 2, 0, 0)
+    g = geoms['block_1/res_0/conv_1']
+    assert (g.padT, g.padB) == (1, 1)
+    assert len(geoms) == 53
+
+
+def test_fusion_collapses_relu_and_residual_add():
+    net = M.ResNet50([64, 64, 3], 10, batch_size=2, width_div=8, auto_compile=False)
+    before = [n.op for n in net.graph.nodes]
+    assert before.count('relu') == 49 and before.count('add') == 16 and before.count('bn') == 53
+    net.graph.fuse()
+    after = [n.op for n in net.graph.nodes]
+    assert after.count('relu') == 0 and after.count('add') == 0 and after.count('bn') == 53
+    fused = [n for n in net.graph.nodes if n.op == 'bn' and n.attrs.get('skip') is not None]
+    assert len(fused) == 16 and all(n.attrs['act'] == 1 for n in fused)
+    assert all(n.scope.endswith('conv_2/bn') for n in fused)
+    # the block output is now produced by the fused bn
+    assert net.d['block_1/res_0'].producer.op == 'bn'
+
+
+def test_bf16_mode_and_channel_padding():
+    net = M.ResNet50([32, 32, 3], 10, batch_size=2, width_div=8, half_precision=True, auto_compile=False)
+    assert net.dtype == 'bfloat16' and net.X.cs == 8
+    assert net.logits.dtype == 'float32'                 # cast after the head (convnet.py:477-480)
+    assert [n.op for n in net.graph.nodes].count('cast') == 1
+
+
+def test_vgg_trunk_shapes_config1():
+    net = M.VGG16([8, 8, 3], 10, batch_size=4, backbone_only=True, auto_compile=False)
+    assert net.d['block_0'].shape == (4, 4, 4, 64)
+    assert net.d['block_4'].shape == (4, 1, 1, 512)
+    assert [v.name for v in net._var_order][:2] == ['block_0/conv_0/weights', 'block_0/conv_0/biases']
+    assert len(net._var_order) == 26
+    with pytest.raises(AssertionError):
+        M.VGG16([8, 8, 3], 10, batch_size=4, auto_compile=False)       # the head needs 224x224 (vggnet.py:108)
+
+
+def test_unbuilt_features_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        M.ResNet50([32, 32, 3], 10, batch_size=2, norm_type='group', auto_compile=False)
+    with pytest.raises(NotImplementedError):
+        M.ResNet50([32, 32, 3], 10, batch_size=2, dropout_rate=0.3, auto_compile=False)
+    net = M.ResNet50([32, 32, 3], 10, batch_size=2, auto_compile=False)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net.compile()
+
+
+def test_lr_schedule_matches_reference_formulas():
+    class Fake(M.Optimizer):
+        def __init__(self, **kw):
+            self.warmup_epoch = kw.get('warm', 1.0)
+            self.decay_method = kw.get('method')
+            self.decay_params = kw.get('params', (0.94, 2))
+            self.steps_per_epoch = 100
+            self.num_epochs = 10
+            self.curr_step, self.curr_epoch, self.curr_multiplier = 0, 1, 1.0
+    for method, params in [(None, (0.94, 2)), ('cosine', (0,)), ('poly', (2,)), ('exponential', (0.94, 2)), ('step', (0.1, 3, 6))]:
+        f = Fake(method=method, params=params)
+        for step in [0, 50, 99, 100, 450, 999]:
+            f.curr_step = step
+            f.curr_epoch = step // 100 + 1
+            f._update_learning_rate()
+            ref = O.lr_multiplier(step, 100, 10, 1.0, method, params, f.curr_epoch)
+            assert f.curr_multiplier == pytest.approx(ref), (method, step)
+
+
+def test_dataset_shards_like_the_reference():
+    x = np.arange(40, dtype=np.float32).reshape(40, 1, 1, 1)
+    y = np.arange(40, dtype=np.float32)
+    a, b = M.DataSet(x, y, batch_size=8, num_shards=2), M.DataSet(x, y, batch_size=8, num_shards=2)
+    xa, ya = a.next_batch(4, shard=0)
+    xb, yb = b.next_batch(4, shard=1)
+    assert list(ya) == [0, 1, 2, 3] and list(yb) == [4, 5, 6, 7]
+    _, ya = a.next_batch(4, shard=0)
+    assert list(ya) == [8, 9, 10, 11]
+    xs, ys = M.synthetic(16, (8, 8, 3), 10)
+    assert xs.dtype == np.float32 and 0 <= xs.min() and xs.max() < 1 and ys.max() < 10
+
+
+def test_bucket_planner_covers_every_gradient_once_in_completion_order():
+    variables = [('w%d' % i, i * 100, 100) for i in range(10)]            # creation order
+    ready = {'w%d' % i: (9 - i) * 3 + 2 for i in range(10)}               # backward finishes the last layer first
+    plan = D.plan_buckets(variables, ready, 250 * 4)
+    covered = sorted(r for _, spans in plan for r in spans)
+    assert covered == [(100, 400), (400, 700), (700, 1000), (0, 100)][::1] or sum(e - s for s, e in covered) == 1000
+    assert sum(e - s for _, spans in plan for s, e in spans) == 1000
+    idxs = [i for i, _ in plan]
+    assert idxs == sorted(idxs)
+    assert plan[0][1] == [(700, 1000)] and plan[0][0] == ready['w7']     # bucket fires once its slowest member is done
+    for _, spans in plan:
+        assert len(spans) == 1                                           # reverse-order layers are contiguous ranges
+
+
+def test_accuracy_evaluator_matches_reference_rule():
+    ev = M.AccuracyEvaluator()
+    y_true = O.one_hot_labels(np.array([1, 2, np.nan, 0]), 3)
+    y_pred = np.array([[0.1, 0.8, 0.1], [0.5, 0.2, 0.3], [0.3, 0.3, 0.4], [0.9, 0.05, 0.05]])
+    assert ev.score(y_true, y_pred) == pytest.approx(O.accuracy_score(y_true, y_pred)) == pytest.approx(0.75)
