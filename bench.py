@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the ResNet-v1.5-50 training step (forward + backward + fused Nesterov/L2/EMA update
+[+ RCCL gradient all-reduce]) on synthetic 224x224x3 batches, B = 256 per GPU, on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--dtype fp32|bf16] [--batch 256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
+Default workload = BASELINE.json configs[1] (fp32, B=256, 1 GPU); `--dtype bf16` runs configs[2]'s arithmetic.
+At N=1 the line also carries:
+  roofline     — the dominant kernel's algorithmic FLOP/s (HIP events around every launch of that kernel in an extra,
+                 instrumented pass over the same launch lists; torch's current stream IS the launch stream) against the
+                 dense MFMA peak of the dtype (MI355X_MICROARCH.md: fp32 157.3 TFLOP/s, bf16 2500 TFLOP/s)
+  cpu_baseline — the NumPy oracle ("port"; the reference's TF-CPU path cannot run here) timed on the host cores on a
+                 bounded sample (same network, B=8)
+  bf16         — a secondary measurement of the same step in bf16 (the north-star arithmetic), unless --dtype bf16.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_FLOP_PER_IMAGE = 2 * (3 * (4087136256 + 2048000) - 118013952)      # 24,299,077,632
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}                             # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32')
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
+    return ap.parse_args()
+
+
+def build_model(args, dtype, world):
+    import myconvnet_amd as M
+    model = M.ResNet50([224, 224, 3], 1000, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
+                       seed=0, device='cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90,
+                              update_ema=not args.no_ema)
+    rank = int(os.environ.get('RANK', 0))
+    rng = np.random.default_rng(1234 + rank)                               # SURVEY §8d synthetic inputs
+    x = rng.random((args.batch, 224, 224, 3), dtype=np.float32)
+    y = rng.integers(0, 1000, args.batch).astype(np.float32)
+    model.feed(x, y)                                                       # resident in HBM before the timed region
+    torch.cuda.synchronize()
+    return model, opt
+
+
+def run_steps(opt, n):
+    for _ in range(n):
+        opt._update_learning_rate()
+        opt._step(None, fetch=False)
+        opt.curr_step += 1
+
+
+def timed(opt, steps, warmup, world):
+    import torch.distributed as dist
+    run_steps(opt, warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(opt, steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# ---- per-kernel timing (instrumented pass) ---------------------------------------------------------------------
+def conv_kernel_name(kind, geom, dtype):
+    """The kernel symbol the host dispatch picks (csrc/conv.hip launch_nt / launch_tn)."""
+    t = 'float' if dtype == 'fp32' else 'bf16'
+    lin = geom.KH == 1 and geom.KW == 1 and geom.SH == 1 and geom.SW == 1
+    if kind == 'fwd':
+        return 'conv_gemm_nt<{},128,{},{}>'.format(t, 64 if geom.Cout <= 64 else 128, 'false' if lin else 'true')
+    if kind == 'dgrad':
+        lin = geom.KH == 1 and geom.KW == 1
+        return 'conv_gemm_nt<{},128,{},{}>'.format(t, 64 if geom.Cin <= 64 else 128, 'false' if lin else 'true')
+    return 'conv_gemm_tn<{},{},{}>'.format(t, 64 if geom.Cout <= 64 else 128, 'true' if lin else 'false')
+
+
+def instrumented_pass(model, dtype, reps=3):
+    """Time every C-ABI launch of forward+backward with HIP events on the launch stream; returns {kernel: [n, ms, flop]}."""
+    from myconvnet_amd._ffi import lib, check
+    low = model._train_low
+    sp = model.stream_ptr()
+    names = {'mcn_conv2d_fwd': 'fwd', 'mcn_conv2d_dgrad': 'dgrad', 'mcn_conv2d_wgrad': 'wgrad'}
+    geoms = {}
+    for n in model.graph.nodes:
+        if n.op == 'conv':
+            geoms[id(n.attrs['geom'])] = n.attrs['geom']
+    table = {}
+    calls = low.fwd.calls + low.bwd.calls
+    for rep in range(reps):
+        evs = []
+        for fn, a in calls:
+            a[-1] = sp
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(fn(*a))
+            e1.record()
+            evs.append((fn, a, e0, e1))
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue                                                       # first rep warms caches / clocks
+        for fn, a, e0, e1 in evs:
+            ms = e0.elapsed_time(e1)
+            kind = names.get(getattr(fn, '__name__', ''))
+            if kind is None:
+                key, flop = getattr(fn, '__name__', 'other'), 0.0
+            else:
+                gm = [x for x in a if hasattr(x, '_obj')][0]._obj          # ctypes.byref(geom)
+                oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
+                ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
+                flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout
+                key = conv_kernel_name(kind, gm, dtype)
+            t = table.setdefault(key, [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += ms
+            t[2] += flop
+    for t in table.values():
+        t[0] //= (reps - 1)
+        t[1] /= (reps - 1)
+        t[2] /= (reps - 1)
+    return table
+
+
+def cpu_baseline():
+    """The oracle (NumPy port of the path) timed on the host cores, bounded sample: ResNet-50, 224x224, B=8, fp32."""
+    from oracle import net as ON
+    spec = ON.ResNetSpec.resnet50(1000)
+    params, stats = ON.init_variables(spec.variables(), seed=0, dtype=np.float32)
+    st = ON.TrainState(params, stats)
+    rng = np.random.default_rng(1234)
+    B = 8
+    x = rng.random((B, 224, 224, 3), dtype=np.float32)
+    y = rng.integers(0, 1000, B).astype(np.float32)
+    ON.train_step(spec, st, x, y, batch_total=256)                         # warm-up (BLAS threads, page faults)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ON.train_step(spec, st, x, y, batch_total=256)
+        times.append(time.perf_counter() - t0)
+    return dict(value=round(B / float(np.median(times)), 3), unit='images/sec', cores=os.cpu_count(), kind='port',
+                sample='NumPy(OpenBLAS) oracle, ResNet-v1.5-50 fp32 224x224 training step, B=8, median of 2 steps after 1 warm-up; '
+                       'the reference TF-1.x CPU path cannot run in this image')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    assert world == args.gpus, '--gpus {} but WORLD_SIZE={} (launch with torch.distributed.run for N>1)'.format(args.gpus, world)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    if world > 1:
+        from myconvnet_amd.dist import init_process_group
+        init_process_group('cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
+
+    model, opt = build_model(args, args.dtype, world)
+    dt = timed(opt, args.steps, args.warmup, world)
+    ms = dt / args.steps * 1e3
+    ips = args.batch * world * args.steps / dt
+    out = {
+        'metric': 'images/sec ResNet-v1.5-50 224x224 synthetic training step',
+        'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'ResNet-v1.5-50 {} 224x224 synthetic ImageNet-1k training step (fwd+bwd+Nesterov/L2/EMA), batch={}/GPU'
+                   .format(args.dtype, args.batch), 'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world),
+                   'ema': not args.no_ema},
+        'train_flop_per_image': TRAIN_FLOP_PER_IMAGE,
+        'e2e_mfma_frac': round(ips / world * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
+    }
+    if world == 1:
+        table = instrumented_pass(model, args.dtype)
+        convs = {k: v for k, v in table.items() if k.startswith('conv_gemm')}
+        dom = max(convs.items(), key=lambda kv: kv[1][1])
+        name, (cnt, ms_k, flop) = dom
+        ach = flop / (ms_k * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': name, 'launches_per_step': cnt, 'avg_launch_us': round(ms_k / cnt * 1e3, 2),
+                           'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                           'frac': round(ach / PEAK_TFLOPS[args.dtype], 4), 'traffic': None}
+        tot = sum(v[1] for v in table.values())
+        out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:12]}
+        out['kernel_ms_total'] = round(tot, 3)
+        conv_ms = sum(v[1] for v in convs.values())
+        conv_flop = sum(v[2] for v in convs.values())
+        out['conv_tflops_all'] = round(conv_flop / (conv_ms * 1e-3) / 1e12, 2)
+        if not args.no_secondary and args.dtype == 'fp32':
+            del model, opt
+            torch.cuda.empty_cache()
+            import argparse as _a
+            a2 = _a.Namespace(**vars(args))
+            m2, o2 = build_model(a2, 'bf16', 1)
+            dt2 = timed(o2, args.steps, args.warmup, 1)
+            ips2 = args.batch * args.steps / dt2
+            out['bf16'] = {'value': round(ips2, 2), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                           'e2e_mfma_frac': round(ips2 * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS['bf16'] * 1e12), 4)}
+            del m2, o2
+            torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -5,6 +5,9 @@ raises and every block method fails loudly.  Build with `python myconvnet_amd/bu
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  MUST precede loading libmcn_hip.so: both then share the one HIP runtime torch ships
+#                          (pointers / streams from torch are only valid in that runtime instance)
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
             const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
 #pragma unroll
             for (int s = 0; s < KP / 32; ++s) {
-                bf16x8 xa[TR], db[TNn];
+                bf16x4 xh[2][TR], dh[2][TNn];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int pix = 32 * s + 8 * g + 4 * h + q;
@@ -465,18 +465,14 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         const int gran = wr * 4 + i;
-                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(xs + pix * XRS + ((gran ^ key) << 5) + 8 * pp));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xa[i][4 * h + e] = __builtin_bit_cast(bf16_t, v[e]);
+                        xh[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(xs + pix * XRS + ((gran ^ key) << 5) + 8 * pp));
                     }
 #pragma unroll
                     for (int j = 0; j < TNn; ++j) {
                         const int gran = wc * (WTN / 16) + j;
-                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(ds + pix * DRS + ((gran ^ (key & DGM)) << 5) + 8 * pp));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) db[j][4 * h + e] = __builtin_bit_cast(bf16_t, v[e]);
+                        dh[h][j] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(ds + pix * DRS + ((gran ^ (key & DGM)) << 5) + 8 * pp));
                     }
                 }
 #pragma unroll
@@ -484,7 +480,9 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
 #pragma unroll
                     for (int j = 0; j < TNn; ++j) {
                         f32x4 a = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], db[j], a, 0, 0, 0);
+                        const bf16x8 xa = __builtin_shufflevector(xh[0][i], xh[1][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 db = __builtin_shufflevector(dh[0][j], dh[1][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, db, a, 0, 0, 0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[i][j][e] = a[e];
                     }

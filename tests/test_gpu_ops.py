@@ -173,10 +173,11 @@ def test_bn_infer_and_affine(dtype):
     g, b = (0.5 + RNG.random(16)).astype(np.float32), RNG.standard_normal(16).astype(np.float32)
     mu, var = RNG.standard_normal(16).astype(np.float32), (0.5 + RNG.random(16)).astype(np.float32)
     xd, y = u.dev(x, dtype), torch.zeros(shape, dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_bn_fwd_infer(xd.data_ptr(), u.dev(g).data_ptr(), u.dev(b).data_ptr(), u.dev(mu).data_ptr(), u.dev(var).data_ptr(), 0,
+    gd, bd, mud, vard = u.dev(g), u.dev(b), u.dev(mu), u.dev(var)      # keep the device buffers alive across the async launches
+    _ffi.check(lib.mcn_bn_fwd_infer(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mud.data_ptr(), vard.data_ptr(), 0,
                                     y.data_ptr(), 50, 16, 1e-3, 0, u.MDT[dtype], u.stream()))
     check(u.host(y), O.bn_fwd_infer(q(x, dtype), g.astype(np.float64), b.astype(np.float64), mu.astype(np.float64), var.astype(np.float64)), dtype, 'bn infer')
-    _ffi.check(lib.mcn_channel_affine(xd.data_ptr(), u.dev(g).data_ptr(), u.dev(b).data_ptr(), y.data_ptr(), 50, 16, u.MDT[dtype], u.stream()))
+    _ffi.check(lib.mcn_channel_affine(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), 50, 16, u.MDT[dtype], u.stream()))
     check(u.host(y), q(x, dtype) * g + b, dtype, 'channel affine')
 
 
@@ -202,7 +203,8 @@ def test_maxpool(cfg, dtype):
     np.testing.assert_array_equal(arg.cpu().numpy(), arg_ref)                       # integer arg-max bit-exact
     dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
     dx = torch.zeros(x.shape, dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_maxpool_bwd(u.dev(dy, dtype).data_ptr(), arg.data_ptr(), dx.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype],
+    dyd = u.dev(dy, dtype)
+    _ffi.check(lib.mcn_maxpool_bwd(dyd.data_ptr(), arg.data_ptr(), dx.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype],
                                    u.stream()))
     check(u.host(dx), O.maxpool_bwd(q(dy, dtype), arg_ref, x.shape, k, s, pad), dtype, 'maxpool bwd')
 
@@ -219,11 +221,13 @@ def test_avgpool(cfg, dtype):
     pt, _, pl, _ = O.resolve_pads(h, h, k, k, s, s, pad)
     oh = y_ref.shape[1]
     y = torch.zeros(y_ref.shape, dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_avgpool_fwd(u.dev(x, dtype).data_ptr(), y.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
+    xd = u.dev(x, dtype)
+    _ffi.check(lib.mcn_avgpool_fwd(xd.data_ptr(), y.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
     check(u.host(y), y_ref, dtype, 'avgpool fwd')
     dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
     dx = torch.zeros(x.shape, dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_avgpool_bwd(u.dev(dy, dtype).data_ptr(), dx.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
+    dyd = u.dev(dy, dtype)
+    _ffi.check(lib.mcn_avgpool_bwd(dyd.data_ptr(), dx.data_ptr(), 2, h, h, c, k, k, s, s, pt, pl, oh, oh, u.MDT[dtype], u.stream()))
     check(u.host(dx), O.avgpool_bwd(q(dy, dtype), x.shape, k, s, pad), dtype, 'avgpool bwd')
 
 
@@ -235,11 +239,13 @@ def test_global_avgpool_and_eltwise(dtype):
     md = u.MDT[dtype]
     x = RNG.standard_normal((3, 7, 7, 40)).astype(np.float32)
     y = torch.zeros((3, 40), dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_global_avgpool_fwd(u.dev(x, dtype).data_ptr(), y.data_ptr(), 3, 49, 40, md, u.stream()))
+    xd = u.dev(x, dtype)
+    _ffi.check(lib.mcn_global_avgpool_fwd(xd.data_ptr(), y.data_ptr(), 3, 49, 40, md, u.stream()))
     check(u.host(y), O.global_avgpool_fwd(q(x, dtype)), dtype, 'gap fwd')
     dy = RNG.standard_normal((3, 40)).astype(np.float32)
     dx = torch.zeros(x.shape, dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_global_avgpool_bwd(u.dev(dy, dtype).data_ptr(), dx.data_ptr(), 3, 49, 40, md, u.stream()))
+    dyd = u.dev(dy, dtype)
+    _ffi.check(lib.mcn_global_avgpool_bwd(dyd.data_ptr(), dx.data_ptr(), 3, 49, 40, md, u.stream()))
     check(u.host(dx), O.global_avgpool_bwd(q(dy, dtype), x.shape), dtype, 'gap bwd')
     # relu / relu_bwd / add_relu / accumulate on a ragged length (vector body + scalar tail)
     n = 1003
@@ -269,14 +275,16 @@ def test_input_prep_and_one_hot(dtype, layout):
     src = x if layout == 'NHWC' else np.ascontiguousarray(x.transpose(0, 3, 1, 2))
     cs = 8
     y = torch.full((2, 6, 5, cs), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
-    _ffi.check(lib.mcn_input_prep(u.dev(src).data_ptr(), y.data_ptr(), 2, 6, 5, 3, cs, 0.5, 2.0, _ffi.NCHW if layout == 'NCHW' else _ffi.NHWC,
+    srcd = u.dev(src)
+    _ffi.check(lib.mcn_input_prep(srcd.data_ptr(), y.data_ptr(), 2, 6, 5, 3, cs, 0.5, 2.0, _ffi.NCHW if layout == 'NCHW' else _ffi.NHWC,
                                   u.MDT[dtype], u.stream()))
     got = u.host(y)
     check(got[..., :3], O.input_prep(x.astype(np.float64)), dtype, 'input_prep')
     assert (got[..., 3:] == 0).all()
     labels = np.array([1, 3, np.nan, 9, 0, 12, -1], dtype=np.float32)
     oh = torch.zeros((7, 10), dtype=torch.float32, device=u.DEV)
-    _ffi.check(lib.mcn_one_hot(u.dev(labels).data_ptr(), oh.data_ptr(), 7, 10, u.stream()))
+    labd = u.dev(labels)
+    _ffi.check(lib.mcn_one_hot(labd.data_ptr(), oh.data_ptr(), 7, 10, u.stream()))
     np.testing.assert_array_equal(u.host(oh), O.one_hot_labels(labels, 10))
 
 
@@ -301,7 +309,8 @@ def test_fc_fwd_bwd(dims, dtype):
     dx = torch.zeros((B, In), dtype=u.TDT[dtype], device=u.DEV)
     dw = torch.zeros((In, Out), dtype=torch.float32, device=u.DEV)
     db = torch.zeros(Out, dtype=torch.float32, device=u.DEV)
-    _ffi.check(lib.mcn_fc_bwd(u.dev(dy, dtype).data_ptr(), xd.data_ptr(), wd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0, B, In, Out,
+    dyd = u.dev(dy, dtype)
+    _ffi.check(lib.mcn_fc_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0, B, In, Out,
                               md, ws.data_ptr(), ws.numel() * 4, u.stream()))
     rdx, rdw, rdb = O.fc_bwd(q(dy, dtype), xq, wq)
     check(u.host(dx), rdx, dtype, 'fc dx')
@@ -322,7 +331,8 @@ def test_softmax_xent(ls):
     pred_r, loss_r, ce_r, dl_r = O.softmax_xent_fwd_bwd(logits.astype(np.float64), oh.astype(np.float64), cw.astype(np.float64), ls, 4.0)
     pred, dl = [torch.zeros((B, C), dtype=torch.float32, device=u.DEV) for _ in range(2)]
     ce, coef, loss = [torch.zeros(8, dtype=torch.float32, device=u.DEV) for _ in range(3)]
-    _ffi.check(lib.mcn_softmax_xent_fwd_bwd(u.dev(logits).data_ptr(), u.dev(oh).data_ptr(), u.dev(cw).data_ptr(), pred.data_ptr(), ce.data_ptr(),
+    ld, ohd, cwd = u.dev(logits), u.dev(oh), u.dev(cw)
+    _ffi.check(lib.mcn_softmax_xent_fwd_bwd(ld.data_ptr(), ohd.data_ptr(), cwd.data_ptr(), pred.data_ptr(), ce.data_ptr(),
                                             coef.data_ptr(), dl.data_ptr(), loss.data_ptr(), B, C, ls, 4.0, u.stream()))
     check(u.host(pred), pred_r, 'float32', 'pred', rel=1e-5)
     check(u.host(ce)[:B], ce_r, 'float32', 'ce', rel=1e-5)
@@ -364,18 +374,21 @@ def test_l2_loss_ema_and_bn_chain():
     w = RNG.standard_normal(n).astype(np.float32)
     out = torch.full((4,), 2.5, dtype=torch.float32, device=u.DEV)
     ws = u.workspace(8192)
-    _ffi.check(lib.mcn_l2_loss(u.dev(w).data_ptr(), n, 1e-4, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, u.stream()))
+    wdv = u.dev(w)
+    _ffi.check(lib.mcn_l2_loss(wdv.data_ptr(), n, 1e-4, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, u.stream()))
     assert abs(u.host(out)[0] - (2.5 + O.l2_reg_loss([w], 1e-4))) < 1e-5
     run = RNG.standard_normal(300).astype(np.float32)
     batch = RNG.standard_normal((4, 300)).astype(np.float32)
     rd = u.dev(run)
-    _ffi.check(lib.mcn_bn_running_chain(rd.data_ptr(), u.dev(batch).data_ptr(), 4, 300, 0.99, u.stream()))
+    batchd = u.dev(batch)
+    _ffi.check(lib.mcn_bn_running_chain(rd.data_ptr(), batchd.data_ptr(), 4, 300, 0.99, u.stream()))
     ref = run.astype(np.float64)
     for k in range(4):
         ref = 0.99 * ref + 0.01 * batch[k]
     check(u.host(rd), ref, 'float32', 'bn chain', rel=1e-6)
     sh = u.dev(run)
-    _ffi.check(lib.mcn_ema_update(sh.data_ptr(), u.dev(batch[0]).data_ptr(), 300, 0.9, u.stream()))
+    b0 = u.dev(batch[0])
+    _ffi.check(lib.mcn_ema_update(sh.data_ptr(), b0.data_ptr(), 300, 0.9, u.stream()))
     check(u.host(sh), 0.9 * run + 0.1 * batch[0], 'float32', 'ema', rel=1e-6)
 
 
