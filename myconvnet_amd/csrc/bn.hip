@@ -111,20 +111,61 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     }
 }
 
+// Second reduction stage shared by the forward / backward finalize kernels: a block owns FIN_CH channels and
+// FIN_LANES threads per channel stride over the row-block partials (coalesced FIN_CH-float segments, several
+// independent loads in flight per thread), then fold through LDS in double precision.  (A one-thread-per-channel
+// loop over ~2000 partials is a serial chain of dependent L2 round trips: it cost 0.45 ms per layer.)
+#define FIN_CH 8
+#define FIN_LANES 32
+__device__ __forceinline__ void fin_reduce(const float* __restrict__ part, int nparts, int C, int c, int lane, double* sh, double& a, double& b) {
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C) {
+        int k = lane;
+        for (; k + 3 * FIN_LANES < nparts; k += 4 * FIN_LANES) {
+            float v0[4], v1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v0[u] = part[((long)(k + u * FIN_LANES) * 2 + 0) * C + c];
+                v1[u] = part[((long)(k + u * FIN_LANES) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0 += (double)v0[u];
+                s1 += (double)v1[u];
+            }
+        }
+        for (; k < nparts; k += FIN_LANES) {
+            s0 += (double)part[((long)k * 2 + 0) * C + c];
+            s1 += (double)part[((long)k * 2 + 1) * C + c];
+        }
+    }
+    const int cl = threadIdx.x % FIN_CH;
+    sh[(lane * FIN_CH + cl) * 2 + 0] = s0;
+    sh[(lane * FIN_CH + cl) * 2 + 1] = s1;
+    __syncthreads();
+    a = 0.0;
+    b = 0.0;
+    if (lane == 0) {
+        for (int l = 0; l < FIN_LANES; ++l) {
+            a += sh[(l * FIN_CH + cl) * 2 + 0];
+            b += sh[(l * FIN_CH + cl) * 2 + 1];
+        }
+    }
+}
+
 // scale/shift for the apply pass + saved statistics + running-statistics update
 template <typename T>
-__global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ part, int nparts, long M, int C,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ batch_mean,
-                                       float* __restrict__ batch_var, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                       float momentum, float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nparts; ++k) {
-        a += (double)part[((long)k * 2 + 0) * C + c];
-        b += (double)part[((long)k * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_kernel(
+    const T* __restrict__ x, const float* __restrict__ part, int nparts, long M, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ batch_mean, float* __restrict__ batch_var, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float momentum, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double sh[FIN_CH * FIN_LANES * 2];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const int lane = threadIdx.x / FIN_CH;
+    double a, b;
+    fin_reduce(part, nparts, C, c, lane, sh, a, b);
+    if (lane != 0 || c >= C) return;
     const double piv = (double)to_f32(x[c]);
     const double inv_m = 1.0 / (double)M;
     const double dm = a * inv_m;
@@ -239,16 +280,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = dbeta/M, coef[2][c] = dgamma/M
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, long M, int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float grad_scale, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nparts; ++k) {
-        a += (double)part[((long)k * 2 + 0) * C + c];
-        b += (double)part[((long)k * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, long M, int C,
+                                                                             const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                             float grad_scale, float* __restrict__ coef) {
+    __shared__ double sh[FIN_CH * FIN_LANES * 2];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const int lane = threadIdx.x / FIN_CH;
+    double a, b;
+    fin_reduce(part, nparts, C, c, lane, sh, a, b);
+    if (lane != 0 || c >= C) return;
     if (dbeta) dbeta[c] = (float)a * grad_scale;
     if (dgamma) dgamma[c] = (float)b * grad_scale;
     coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
@@ -313,7 +354,7 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     const dim3 grid(L.gx, L.gy), block(256);
     hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)x, part, M, C, L.TX, L.TY, L.rpb);
     MCN_CHECK_LAUNCH();
-    hipLaunchKernelGGL((bn_fwd_finalize_kernel<T>), dim3((C + 255) / 256), block, 0, st, (const T*)x, (const float*)part, L.gy, M, C, gamma,
+    hipLaunchKernelGGL((bn_fwd_finalize_kernel<T>), dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const T*)x, (const float*)part, L.gy, M, C, gamma,
                        beta, eps, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
     MCN_CHECK_LAUNCH();
     const bool relu = act == MCN_ACT_RELU;
@@ -440,7 +481,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, false>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x,
                            (const T*)y, save_mean, save_invstd, part, M, C, L.TX, L.TY, L.rpb);
     MCN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), block, 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
                        dbeta, grad_scale, coef);
     MCN_CHECK_LAUNCH();
 #define BN_BWD_APPLY(RL, DS)                                                                                                    \
