@@ -19,19 +19,29 @@ from . import ops
 
 
 class V(object):
-    """A value on the oracle's tape: array + accumulated gradient."""
-    __slots__ = ('a', 'g')
+    """A value on the oracle's tape: array + accumulated gradient.  `q` (optional) rounds activations and their
+    gradients to the storage precision of the low-precision mode (see Tape.quant)."""
+    __slots__ = ('a', 'g', 'q')
 
-    def __init__(self, a):
-        self.a = a
+    def __init__(self, a, q=None):
+        self.q = q
+        self.a = a if q is None else q(a)
         self.g = None
 
     def acc(self, g):
+        if self.q is not None:
+            g = self.q(g)
         self.g = g if self.g is None else self.g + g
+        if self.q is not None:
+            self.g = self.q(self.g)
 
 
 class Tape(object):
-    def __init__(self, params, train=True, bn_stats=None, eps=1e-3):
+    def __init__(self, params, train=True, bn_stats=None, eps=1e-3, quant=None):
+        """quant: optional rounding function emulating low-precision STORAGE of activations / activation gradients and
+        the per-use cast of the weights (reference half_precision structure, convnet.py:63,1421-1422,1878-1879: fp32
+        master weights, BN statistics and all accumulation in fp32).  Used to compare the bf16 device path like with like."""
+        self.quant = quant
         self.params = params          # name -> ndarray
         self.pv = {}                  # name -> V (created on first use)
         self.train = train
@@ -49,16 +59,18 @@ class Tape(object):
     # ---- ops ---------------------------------------------------------------------------
     def conv(self, x, scope, stride, padding='SAME', dilation=1, biased=False):
         w = self.p(scope + '/weights')
-        y = V(ops.conv2d_fwd(x.a, w.a, stride, padding, dilation))
+        q = self.quant
+        wq = w.a if q is None else q(w.a)
+        y = V(ops.conv2d_fwd(x.a, wq, stride, padding, dilation), q)
 
         def bw():
             w.acc(ops.conv2d_wgrad(x.a, y.g, w.a.shape, stride, padding, dilation))
             if x.g is not False:
-                x.acc(ops.conv2d_dgrad(y.g, w.a, x.a.shape, stride, padding, dilation))
+                x.acc(ops.conv2d_dgrad(y.g, wq, x.a.shape, stride, padding, dilation))
         self.bw.append(bw)
         if biased:
             b = self.p(scope + '/biases')
-            y2 = V(ops.bias_add_fwd(y.a, b.a))
+            y2 = V(ops.bias_add_fwd(y.a, b.a), q)
 
             def bwb():
                 b.acc(ops.bias_add_bwd(y2.g))
@@ -74,7 +86,7 @@ class Tape(object):
         if self.train:
             ya, bm, bv, sm, si = ops.bn_fwd_train(x.a, gamma.a, beta.a, self.eps)
             self.batch_stats[scope] = (bm, bv)
-            y = V(ya)
+            y = V(ya, self.quant)
 
             def bw():
                 dx, dg, db = ops.bn_bwd(y.g, x.a, gamma.a, sm, si)
@@ -85,15 +97,15 @@ class Tape(object):
             return y
         mu = self.bn_stats[scope + '/mu']
         sigma = self.bn_stats[scope + '/sigma']
-        return V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps))
+        return V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant)
 
     def relu(self, x):
-        y = V(ops.relu_fwd(x.a))
+        y = V(ops.relu_fwd(x.a), self.quant)
         self.bw.append(lambda: x.acc(ops.relu_bwd(y.g, y.a)))
         return y
 
     def add(self, x, skip):
-        y = V(ops.add_fwd(x.a, skip.a))
+        y = V(ops.add_fwd(x.a, skip.a), self.quant)
 
         def bw():
             x.acc(y.g)
@@ -103,27 +115,29 @@ class Tape(object):
 
     def max_pool(self, x, k, s, padding='SAME'):
         ya, arg = ops.maxpool_fwd(x.a, k, s, padding)
-        y = V(ya)
+        y = V(ya, self.quant)
         self.bw.append(lambda: x.acc(ops.maxpool_bwd(y.g, arg, x.a.shape, k, s, padding)))
         return y
 
     def avg_pool(self, x, k, s, padding='SAME'):
-        y = V(ops.avgpool_fwd(x.a, k, s, padding))
+        y = V(ops.avgpool_fwd(x.a, k, s, padding), self.quant)
         self.bw.append(lambda: x.acc(ops.avgpool_bwd(y.g, x.a.shape, k, s, padding)))
         return y
 
     def global_avgpool(self, x):
-        y = V(ops.global_avgpool_fwd(x.a))
+        y = V(ops.global_avgpool_fwd(x.a), self.quant)
         self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g, x.a.shape)))
         return y
 
     def fc(self, x, scope):
         w = self.p(scope + '/weights')
         b = self.p(scope + '/biases')
-        y = V(ops.fc_fwd(x.a, w.a, b.a))
+        q = self.quant
+        wq = w.a if q is None else q(w.a)
+        y = V(ops.fc_fwd(x.a, wq, b.a), q)
 
         def bw():
-            dx, dw, db = ops.fc_bwd(y.g, x.a, w.a)
+            dx, dw, db = ops.fc_bwd(y.g, x.a, wq)
             x.acc(dx)
             w.acc(dw)
             b.acc(db)
@@ -281,7 +295,7 @@ class VGGSpec(object):
     def forward(self, t, x, image_mean=0.5, scale_factor=2.0):
         """vggnet.py:23-25 re-scales the prepared input: (X/scale + mean)*255 - VGG_MEAN."""
         d = t.d
-        xin = V(((x.a / scale_factor + image_mean) * 255.0 - VGG_MEAN.astype(x.a.dtype)).astype(x.a.dtype))
+        xin = V(((x.a / scale_factor + image_mean) * 255.0 - VGG_MEAN.astype(x.a.dtype)).astype(x.a.dtype), t.quant)
         xin.g = False
         h = xin
         for b, blk in enumerate(self.plan):
@@ -341,13 +355,13 @@ class TrainState(object):
         self.step = 0
 
 
-def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False):
+def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False, quant=None):
     hp = dict(DEFAULT_HP, **(hp or {}))
     params = state.ema if use_ema else state.params
     stats = state.ema_stats if use_ema else state.stats
-    t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'])
+    t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'], quant=quant)
     dt = next(iter(params.values())).dtype
-    x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']))
+    x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']), quant)
     x.g = False
     if isinstance(spec, VGGSpec):
         out = spec.forward(t, x, hp['image_mean'], hp['scale_factor'])
@@ -359,12 +373,12 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
     pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
     weights = [v for k, v in params.items() if k.endswith('/weights')]
     loss = float(sm_loss) + ops.l2_reg_loss(weights, hp['l2_reg'])
-    out.g = dlogits
+    out.g = dlogits if quant is None else quant(dlogits)
     return t, out, pred, loss, onehot
 
 
 def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=None,
-               tower_batches=None):
+               tower_batches=None, quant=None):
     """One optimisation step.  `tower_batches` (list of (x,y)) restates the multi-tower path:
     gradients averaged over towers (optimizers.py:125-142), BN running stats chained
     (convnet.py:1899-1909), loss = mean of tower losses (convnet.py:510)."""
@@ -374,7 +388,7 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
     lr = hp['base_learning_rate'] * btot / 256.0 * lr_mult          # optimizers.py:46,57
     grads_sum, losses, preds, bstats = None, [], [], []
     for (xr, yf) in towers:
-        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True)
+        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant)
         g = t.backward()
         grads_sum = g if grads_sum is None else {k: grads_sum[k] + g[k] for k in g}
         losses.append(loss)

@@ -78,9 +78,16 @@ def cosine(a, b):
     return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
 
 
+def bf16q(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
 def test_resnet_step_bf16():
-    """bf16 storage (8 significant bits) through 53 conv+BN layers: checked in aggregate against the float64 oracle —
-    loss, predictions, and direction / magnitude of the full gradient; the 1e-3 bar applies to the fp32 path."""
+    """bf16 storage (8 significant bits) through 53 conv+BN layers.  Compared like with like: the float64 oracle with
+    every activation / activation-gradient / per-use weight rounded to bf16 (oracle.net.Tape(quant=...)), i.e. the
+    reference's half-precision structure (fp32 masters, fp32 BN statistics, fp32 accumulation).  Rounding points differ
+    slightly where the device fuses BN+add+ReLU (one rounding instead of three), hence aggregate criteria; the 1e-3 bar
+    applies to the fp32 path."""
     import myconvnet_amd as M
     model, spec, params, stats = make_resnet(50, 'bfloat16', True)
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
@@ -89,18 +96,25 @@ def test_resnet_step_bf16():
     y = LABELS
     model.feed(x, y)
     loss, _, y_pred = opt._step(None)
-    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH)
-    assert abs(loss - rloss) <= 3e-2 * abs(rloss), (loss, rloss)
-    assert rel_l2(y_pred, rpred) <= 0.1
+    state64 = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH, quant=bf16q)
+    xloss, xpred, xgrads = ON.train_step(spec, state64, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH)
+    assert abs(loss - rloss) <= 2e-2 * abs(rloss), (loss, rloss)
+    assert rel_l2(y_pred, rpred) <= 5e-2
     grads = model.get_variables('grad')
     keys = sorted(k for k in rgrads if k.endswith('weights'))
     g = np.concatenate([grads[k].ravel() for k in keys])
     r = np.concatenate([rgrads[k].ravel() for k in keys])
-    assert cosine(g, r) >= 0.98, cosine(g, r)
-    assert abs(np.linalg.norm(g) / np.linalg.norm(r) - 1.0) <= 0.1
+    e = np.concatenate([xgrads[k].ravel() for k in keys])
+    # the device must be as accurate (vs exact arithmetic) as a plain bf16-storage evaluation of the same network
+    err_dev, err_emu = rel_l2(g, e), rel_l2(r, e)
+    print('bf16 gradient error vs float64: device {:.3f}, bf16-emulating oracle {:.3f}; cos(device, emu) {:.3f}'.format(err_dev, err_emu, cosine(g, r)))
+    assert err_dev <= 1.5 * err_emu + 0.02, (err_dev, err_emu)
+    assert cosine(g, e) >= 0.9
+    assert abs(np.linalg.norm(g) / np.linalg.norm(e) - 1.0) <= 0.1
     # running statistics come from fp32 sums of the bf16 activations
     got = model.get_variables('data')
-    assert rel_l2(got['block_0/conv_0/bn/mu'], state.stats['block_0/conv_0/bn/mu']) <= 2e-2
+    assert rel_l2(got['block_0/conv_0/bn/mu'], state.stats['block_0/conv_0/bn/mu']) <= 1e-2
 
 
 def test_resnet_eval_uses_ema_and_running_stats():
@@ -143,7 +157,7 @@ def test_vgg16_trunk_config1(dtype):
     model.forward(train=True)
     out = model.d['block_4']
     state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {})
-    tape, rout, _, _, _ = ON.forward_loss(spec, state, x.astype(np.float64), None)
+    tape, rout, _, _, _ = ON.forward_loss(spec, state, x.astype(np.float64), None, quant=(bf16q if dtype == 'bfloat16' else None))
     got = model.fetch(out)
     tol = 1e-4 if dtype == 'float32' else 5e-2
     assert got.shape == rout.a.shape == (4, 1, 1, 128)
