@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
+    ap.add_argument('--layers', action='store_true', help='print a per-launch table (stderr) from the instrumented pass')
     return ap.parse_args()
 
 
@@ -89,18 +90,13 @@ def timed(opt, steps, warmup, world):
 
 # ---- per-kernel timing (instrumented pass) ---------------------------------------------------------------------
 def conv_kernel_name(kind, geom, dtype):
-    """The kernel symbol the host dispatch picks (csrc/conv.hip launch_nt / launch_tn)."""
+    """The kernel FAMILY a conv call runs in (csrc/conv.hip): fwd and dgrad share conv_gemm_nt (the tile shape is picked
+    per layer by pick_nt_tile), wgrad runs conv_gemm_tn."""
     t = 'float' if dtype == 'fp32' else 'bf16'
-    lin = geom.KH == 1 and geom.KW == 1 and geom.SH == 1 and geom.SW == 1
-    if kind == 'fwd':
-        return 'conv_gemm_nt<{},128,{},{}>'.format(t, 64 if geom.Cout <= 64 else 128, 'false' if lin else 'true')
-    if kind == 'dgrad':
-        lin = geom.KH == 1 and geom.KW == 1
-        return 'conv_gemm_nt<{},128,{},{}>'.format(t, 64 if geom.Cin <= 64 else 128, 'false' if lin else 'true')
-    return 'conv_gemm_tn<{},{},{}>'.format(t, 64 if geom.Cout <= 64 else 128, 'true' if lin else 'false')
+    return ('conv_gemm_nt<{}> (fwd+dgrad)' if kind in ('fwd', 'dgrad') else 'conv_gemm_tn<{}> (wgrad)').format(t)
 
 
-def instrumented_pass(model, dtype, reps=3):
+def instrumented_pass(model, dtype, reps=3, layers=False):
     """Time every C-ABI launch of forward+backward with HIP events on the launch stream; returns {kernel: [n, ms, flop]}."""
     from myconvnet_amd._ffi import lib, check
     low = model._train_low
@@ -139,6 +135,26 @@ def instrumented_pass(model, dtype, reps=3):
             t[0] += 1
             t[1] += ms
             t[2] += flop
+    if layers:
+        es = 4 if dtype == 'fp32' else 2
+        rows = {}
+        for fn, a, e0, e1 in evs:
+            kind = names.get(getattr(fn, '__name__', ''))
+            if kind is None:
+                continue
+            gm = [x for x in a if hasattr(x, '_obj')][0]._obj
+            oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
+            flop = 2.0 * gm.N * oh * oh * gm.KH * gm.KW * gm.Cin * gm.Cout
+            byt = es * gm.N * (gm.H * gm.W * gm.Cin + oh * oh * gm.Cout)
+            key = (kind, gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH)
+            r = rows.setdefault(key, [0, 0.0, flop, byt])
+            r[0] += 1
+            r[1] += e0.elapsed_time(e1)
+        print('kind   H   Cin  Cout k s  n    us/launch  TFLOP/s   GB/s(min traffic)', file=sys.stderr)
+        for key, (n, ms, flop, byt) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            us = ms / n * 1e3
+            print('{:5s} {:3d} {:5d} {:5d} {} {} {:2d} {:10.1f} {:8.1f} {:8.0f}'.format(key[0], key[1], key[2], key[3], key[4], key[5], n, us,
+                  flop / us / 1e6, byt / us / 1e3), file=sys.stderr)
     for t in table.values():
         t[0] //= (reps - 1)
         t[1] /= (reps - 1)
@@ -195,7 +211,7 @@ def main():
         'e2e_mfma_frac': round(ips / world * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
     }
     if world == 1:
-        table = instrumented_pass(model, args.dtype)
+        table = instrumented_pass(model, args.dtype, layers=args.layers)
         convs = {k: v for k, v in table.items() if k.startswith('conv_gemm')}
         dom = max(convs.items(), key=lambda kv: kv[1][1])
         name, (cnt, ms_k, flop) = dom

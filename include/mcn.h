@@ -100,13 +100,16 @@ int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const
                      void* stream);
 
 /* replaces FusedBatchNormGrad [+ ReluGrad + the add's gradient fan-out].
- * dy: gradient w.r.t. the (activated) output y.  If act == RELU the mask [y > 0] is applied
- * first (y must then be the forward output).  dskip (may be NULL): receives the masked dy, i.e.
- * the gradient of the residual branch.  dgamma/dbeta fp32 [C], multiplied by grad_scale. */
-int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-               const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale,
-               int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes,
-               void* stream);
+ * dy: gradient w.r.t. the (activated) output y.  If act == RELU the mask [y > 0] is applied first:
+ *   y != NULL : mask from the stored forward output (required when the forward fused a residual `skip`);
+ *   y == NULL : mask recomputed from x as [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0], the expression the
+ *               forward apply pass evaluated (saves one read of y per pass; forward without `skip` only).
+ * dskip (may be NULL): receives the masked dy, i.e. the gradient of the residual branch.
+ * dgamma/dbeta fp32 [C], multiplied by grad_scale. */
+int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
+               const float* save_mean, const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta,
+               float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* per-channel affine y[m][c] = x[m][c]*scale[c] + shift[c] over [M][C] (the VGG input re-scaling,
  * reference models/vggnet.py:25; also the apply pass of batch norm). scale/shift fp32 [C]. */

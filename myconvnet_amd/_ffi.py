@@ -42,7 +42,7 @@ SIGNATURES = {
     'mcn_bn_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'mcn_bn_fwd_train': (c_int, [c_void_p] * 11 + [c_float, c_int64, c_int32, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_bn_fwd_infer': (c_int, [c_void_p] * 7 + [c_int64, c_int32, c_float, c_int, c_int, c_void_p]),
-    'mcn_bn_bwd': (c_int, [c_void_p] * 10 + [c_float, c_int64, c_int32, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_bn_bwd': (c_int, [c_void_p] * 11 + [c_float, c_int64, c_int32, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_channel_affine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     'mcn_relu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'mcn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -221,9 +221,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 
 // ---- backward --------------------------------------------------------------------------------------
 // part[(rb*2+0)*C + c] = sum dy', part[(rb*2+1)*C + c] = sum dy' * xhat   (dy' = dy*[y>0] if RELU)
-template <typename T, int VEC, bool RELU>
+// RELU: 0 = no activation, 1 = mask from the stored forward output y, 2 = mask RECOMPUTED from x as
+// [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0] — the same fp32 expression the forward apply pass evaluated, so
+// the mask is the forward's; saves one full read of y in each backward pass (only valid without a fused residual).
+template <typename T, int VEC, int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ part, long M, int C, int TX, int TY, long rpb) {
     extern __shared__ float red[];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -233,11 +237,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
     if (active) {
-        float mu[VEC], is[VEC];
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             mu[i] = mean[col * VEC + i];
             is[i] = invstd[col * VEC + i];
+            if (RELU == 2) {
+                sc[i] = (gamma ? gamma[col * VEC + i] : 1.f) * is[i];
+                sh[i] = (beta ? beta[col * VEC + i] : 0.f) - mu[i] * sc[i];
+            }
         }
         const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
         for (long r = r0 + ty; r < r1; r += TY) {
@@ -245,11 +253,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             float g[VEC], v[VEC], o[VEC];
             ldv<T, VEC>(dy + off, g);
             ldv<T, VEC>(x + off, v);
-            if (RELU) ldv<T, VEC>(y + off, o);
+            if (RELU == 1) ldv<T, VEC>(y + off, o);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float gg = g[i];
-                if (RELU) gg = o[i] > 0.f ? gg : 0.f;
+                if (RELU == 1) gg = o[i] > 0.f ? gg : 0.f;
+                if (RELU == 2) gg = fmaf(v[i], sc[i], sh[i]) > 0.f ? gg : 0.f;
                 s1[i] += gg;
                 s2[i] = fmaf(gg, (v[i] - mu[i]) * is[i], s2[i]);
             }
@@ -297,15 +306,16 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_bwd_finalize_kernel(con
     coef[2 * C + c] = (float)(b / (double)M);
 }
 
-template <typename T, int VEC, bool RELU, bool DSKIP>
+template <typename T, int VEC, int RELU, bool DSKIP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dskip,
                                                            long M, int C, int TX, int TY, long rpb) {
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int col = blockIdx.x * TX + tx;
     if (ty >= TY || col * VEC >= C) return;
-    float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC];
+    float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         mu[i] = mean[col * VEC + i];
@@ -313,6 +323,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         ca[i] = coef[col * VEC + i];
         cb[i] = coef[C + col * VEC + i];
         cc[i] = coef[2 * C + col * VEC + i];
+        if (RELU == 2) {
+            sc[i] = (gamma ? gamma[col * VEC + i] : 1.f) * is[i];
+            sh[i] = (beta ? beta[col * VEC + i] : 0.f) - mu[i] * sc[i];
+        }
     }
     const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
     for (long r = r0 + ty; r < r1; r += TY) {
@@ -320,10 +334,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float g[VEC], v[VEC], o[VEC];
         ldv<T, VEC>(dy + off, g);
         ldv<T, VEC>(x + off, v);
-        if (RELU) ldv<T, VEC>(y + off, o);
+        if (RELU == 1) ldv<T, VEC>(y + off, o);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            if (RELU) g[i] = o[i] > 0.f ? g[i] : 0.f;
+            if (RELU == 1) g[i] = o[i] > 0.f ? g[i] : 0.f;
+            if (RELU == 2) g[i] = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
             const float xh = (v[i] - mu[i]) * is[i];
             v[i] = ca[i] * (g[i] - cb[i] - xh * cc[i]);
         }
@@ -466,43 +481,42 @@ extern "C" int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* 
 }
 
 template <typename T, int VEC>
-static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_invstd,
-                    void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, long M, int C, mcn_act act, void* ws,
-                    hipStream_t st) {
+static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, long M, int C, mcn_act act,
+                    void* ws, hipStream_t st) {
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
     const dim3 grid(L.gx, L.gy), block(256);
-    const bool relu = act == MCN_ACT_RELU;
-    if (relu)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, true>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x,
-                           (const T*)y, save_mean, save_invstd, part, M, C, L.TX, L.TY, L.rpb);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, false>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x,
-                           (const T*)y, save_mean, save_invstd, part, M, C, L.TX, L.TY, L.rpb);
+    const int relu = act != MCN_ACT_RELU ? 0 : (y ? 1 : 2);
+#define BN_BWD_REDUCE(RL)                                                                                                          \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, RL>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x, \
+                       (const T*)y, save_mean, save_invstd, gamma, beta, part, M, C, L.TX, L.TY, L.rpb)
+    if (relu == 0) BN_BWD_REDUCE(0); else if (relu == 1) BN_BWD_REDUCE(1); else BN_BWD_REDUCE(2);
+#undef BN_BWD_REDUCE
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
                        dbeta, grad_scale, coef);
     MCN_CHECK_LAUNCH();
 #define BN_BWD_APPLY(RL, DS)                                                                                                    \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, RL, DS>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, \
-                       save_invstd, (const float*)coef, (T*)dx, (T*)dskip, M, C, L.TX, L.TY, L.rpb)
-    if (relu) { if (dskip) BN_BWD_APPLY(true, true); else BN_BWD_APPLY(true, false); }
-    else { if (dskip) BN_BWD_APPLY(false, true); else BN_BWD_APPLY(false, false); }
+                       save_invstd, gamma, beta, (const float*)coef, (T*)dx, (T*)dskip, M, C, L.TX, L.TY, L.rpb)
+    if (relu == 1) { if (dskip) BN_BWD_APPLY(1, true); else BN_BWD_APPLY(1, false); }
+    else if (relu == 2) { if (dskip) BN_BWD_APPLY(2, true); else BN_BWD_APPLY(2, false); }
+    else { if (dskip) BN_BWD_APPLY(0, true); else BN_BWD_APPLY(0, false); }
 #undef BN_BWD_APPLY
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
-extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
                           const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, int64_t M,
                           int32_t C, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !dx || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd: bad argument");
-    if (act == MCN_ACT_RELU && !y) MCN_FAIL(MCN_E_BADARG, "bn_bwd: act=RELU needs the forward output y");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
-                                            : bn_bwd_t<float, 1>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
-    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
-                                             : bn_bwd_t<bf16_t, 1>(dy, x, y, gamma, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                            : bn_bwd_t<float, 1>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                             : bn_bwd_t<bf16_t, 1>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
 }

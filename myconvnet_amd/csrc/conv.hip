@@ -128,28 +128,74 @@ static void allow_lds(K kernel, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// Tile shape for conv_gemm_nt.  In the MFMA-bound regime a CU's time is (tiles it receives) x (work per tile), so a layer
+// with W equal tiles costs ceil(W/256) tile-times: at B=256 the late ResNet stages have only 392..1568 tiles of 128x128
+// (1.53 / 3.06 / 6.125 per CU) and lose 13-23 % to the last, nearly empty round, while the K-loop itself runs at 91 % of
+// the MFMA rate (in-kernel stamps).  Smaller tiles quantise better and fit 4 workgroups per CU instead of 2 (their
+// prologue / epilogue / barrier bubbles overlap better), but re-read more LDS per MFMA.  Per-area cost factors from
+// whole-network A/B runs on MI355X: fp32 (64-cycle MFMAs, LDS far from limiting) prefers 64x64 everywhere
+// (conv fwd+dgrad 38.4 ms vs 41.5 ms per step with 128x128); bf16 is LDS-bandwidth sensitive and keeps the big tiles.
+// (A body/tail split — big tiles for whole rounds, small tiles for the remainder in a second launch — was measured
+// and lost 4 %: the kernel boundary costs more than the shorter tail saves.)
+#define MCN_NUM_CU 256
+struct NtTile { int bm, bn; };
+static inline double nt_tile_work(int c, size_t es) {
+    static const double w[3] = {128.0 * 128, 128.0 * 64, 64.0 * 64};
+    static const double f32[3] = {1.08, 1.03, 1.00}, bf16[3] = {1.00, 1.08, 1.35};
+    return w[c] * (es == 4 ? f32[c] : bf16[c]);
+}
 template <typename T>
-static int launch_nt(const GemmNTParams& p, bool taps, hipStream_t st) {
-    const int BN = p.Nn <= 64 ? 64 : 128;
-    const int BM = 128;
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Nn + BN - 1) / BN;
-    if (ntm <= 0 || ntn <= 0) return MCN_OK;
-    const int lds = 2 * (BM + BN) * 128;
-    const dim3 grid(ntm * ntn), block(256);
-#define MCN_LAUNCH_NT(BNV, TAPSV)                                                    \
-    do {                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, 128, BNV, TAPSV>, 2 * (128 + BNV) * 128), true); \
-        (void)once;                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, 128, BNV, TAPSV>), grid, block, lds, st, p); \
-    } while (0)
-    if (BN == 128) {
-        if (taps) MCN_LAUNCH_NT(128, true); else MCN_LAUNCH_NT(128, false);
-    } else {
-        if (taps) MCN_LAUNCH_NT(64, true); else MCN_LAUNCH_NT(64, false);
+static int pick_nt_tile(int M, int Nn) {
+    static const int forced = [] { const char* e = getenv("MCN_NT_TILE"); return e ? atoi(e) : -1; }();
+    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    int best = Nn <= 64 ? 1 : 0;
+    double best_cost = -1;
+    for (int c = 0; c < 3; ++c) {
+        if (Nn <= 64 && cand[c].bn > 64) continue;
+        if (forced >= 0 && forced < 3 && c != forced && !(Nn <= 64 && forced == 0)) continue;
+        const long w = (long)((M + cand[c].bm - 1) / cand[c].bm) * ((Nn + cand[c].bn - 1) / cand[c].bn);
+        const double cost = (double)((w + MCN_NUM_CU - 1) / MCN_NUM_CU) * nt_tile_work(c, sizeof(T));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
     }
+    return best;
+}
+
+template <typename T>
+static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, bool taps, hipStream_t st) {
+    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const NtTile t = cand[tile];
+    p.m_begin = m_begin;
+    p.m_end = m_end;
+    const int ntm = (m_end - m_begin + t.bm - 1) / t.bm, ntn = (p.Nn + t.bn - 1) / t.bn;
+    if (ntm <= 0 || ntn <= 0) return MCN_OK;
+    const int lds = 2 * (t.bm + t.bn) * 128;
+    const dim3 grid(ntm * ntn), block(256);
+    const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
+#define MCN_LAUNCH_NT(BMV, BNV, MODEV)                                               \
+    do {                                                                             \
+        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV>, 2 * (BMV + BNV) * 128), true); \
+        (void)once;                                                                  \
+        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV>), grid, block, lds, st, p); \
+    } while (0)
+#define MCN_LAUNCH_NT_MODE(BMV, BNV)                                    \
+    do {                                                                \
+        if (mode == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NT_LINEAR);      \
+        else if (mode == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NT_UNIFORM); \
+        else MCN_LAUNCH_NT(BMV, BNV, NT_GENERIC);                       \
+    } while (0)
+    if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_NT_MODE(128, 128);
+    else if (t.bm == 128) MCN_LAUNCH_NT_MODE(128, 64);
+    else MCN_LAUNCH_NT_MODE(64, 64);
+#undef MCN_LAUNCH_NT_MODE
 #undef MCN_LAUNCH_NT
     MCN_CHECK_LAUNCH();
     return MCN_OK;
+}
+
+template <typename T>
+static int launch_nt(const GemmNTParams& p, bool taps, hipStream_t st) {
+    if (p.M <= 0 || p.Nn <= 0) return MCN_OK;
+    return launch_nt_range<T>(p, pick_nt_tile<T>(p.M, p.Nn), 0, p.M, taps, st);
 }
 
 template <typename T>
@@ -395,8 +441,11 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
             if (rc) return rc;
         }
         const long total = (long)ntaps * g.Cin * g.Cout;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks(total, 2048)), dim3(256), 0, st, (const float*)wsp, dw, M > 0 ? splits : 0, ntaps,
-                           Cp, g.Cin, g.Cout, scale);
+        const int nsp = M > 0 ? splits : 0;
+        if (Cp == g.Cin && total % 4 == 0 && (((uintptr_t)dw) & 15) == 0)
+            hipLaunchKernelGGL(wgrad_reduce_linear_kernel, dim3(nblocks(total / 4, 2048)), dim3(256), 0, st, (const float*)wsp, dw, nsp, total / 4, scale);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks(total, 2048)), dim3(256), 0, st, (const float*)wsp, dw, nsp, ntaps, Cp, g.Cin, g.Cout, scale);
         MCN_CHECK_LAUNCH();
         wsp += align_up((size_t)splits * p.rows * g.Cout * 4, 256);
     }

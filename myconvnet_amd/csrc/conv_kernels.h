@@ -29,7 +29,11 @@ struct GemmNTParams {
     const void* wt;
     void* out;
     const float* bias;
+#ifdef MCN_ABL_STAMP
+    const float* bias_stamp;
+#endif
     int M, OH, OW;          // GEMM rows = N*OH*OW of the (sub-)grid
+    int m_begin, m_end;     // row range this launch covers (a conv may be split into a big-tile body and a small-tile tail)
     int IH, IW, Cs;         // gathered tensor: spatial dims, channel stride (elements)
     int cpt;                // 16-byte chunks per tap
     int ntaps;
@@ -107,10 +111,19 @@ __device__ __forceinline__ int nt_lds_off(int r, int c) { return r * 128 + ((c ^
 // ------------------------------------------------------------------------------------------------
 // conv_gemm_nt
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, bool TAPS>
+// MODE 0 (NT_LINEAR) : A is a plain [M][Cs] matrix (1x1 / stride 1 / no padding).
+// MODE 1 (NT_UNIFORM): every K-step lies inside ONE filter tap (chunks per tap % 8 == 0, true for every conv of the
+//                      path except the stem): the tap and its (dy,dx) are wave-uniform scalars, the per-row work is
+//                      two adds, two unsigned compares and a select — branch-free, so the compiler can schedule it
+//                      between the MFMAs of the previous K-step instead of in front of them.
+// MODE 2 (NT_GENERIC): a K-step may straddle taps (stem: 1-2 chunks per tap); per-thread tap decode from an LDS table.
+enum { NT_LINEAR = 0, NT_UNIFORM = 1, NT_GENERIC = 2 };
+
+template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
+    constexpr bool TAPS = MODE != NT_LINEAR;
     constexpr int AR = BM / 32, BR = BN / 32;          // staged chunks per thread
     constexpr int WTM = BM / 2, WTN = BN / 2;          // wave tile (2x2 waves)
     constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
@@ -119,13 +132,16 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     __shared__ signed char s_tdy[MCN_MAX_TAPS], s_tdx[MCN_MAX_TAPS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MCN_ABL_STAMP
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_t1 = 0, st_t2 = 0;
+#endif
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.Nn + BN - 1) / BN;
-    const int ntm = (p.M + BM - 1) / BM;
+    const int ntm = (p.m_end - p.m_begin + BM - 1) / BM;
     const int L = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (L / ntn) * BM, n0 = (L % ntn) * BN;
+    const int m0 = p.m_begin + (L / ntn) * BM, n0 = (L % ntn) * BN;
 
-    if (TAPS) {
+    if (MODE == NT_GENERIC) {
         if (tid < MCN_MAX_TAPS) {
             s_tdy[tid] = p.tdy[tid];
             s_tdx[tid] = p.tdx[tid];
@@ -137,68 +153,70 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
 
     const int crow = tid >> 3, cid = tid & 7;
-    // per-thread A rows
-    int a_base[AR], a_y[AR], a_x[AR];
+    // per-thread A rows: byte offset of the row's pixel at tap offset (0,0) + its grid coordinates for the bounds test
+    unsigned a_off[AR];
+    int a_y[AR], a_x[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + crow + 32 * i;
-        if (m < p.M) {
-            if (TAPS) {
-                const int hw = p.OH * p.OW;
-                const int img = m / hw, rem = m - img * hw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                a_base[i] = img * p.IH * p.IW;
-                a_y[i] = oy * p.sy;
-                a_x[i] = ox * p.sx;
-            } else {
-                a_base[i] = m;   // plain [M][Cs] matrix (1x1, stride folded by the host)
-                a_y[i] = 0;
-                a_x[i] = 0;
-            }
+        const bool mv = m < p.m_end;
+        if (TAPS) {
+            const int mm = mv ? m : 0;
+            const int hw = p.OH * p.OW;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_y[i] = mv ? oy * p.sy : -0x40000000;       // invalid rows fail the unsigned bounds test for every tap
+            a_x[i] = ox * p.sx;
+            a_off[i] = (unsigned)((img * p.IH + oy * p.sy) * p.IW + ox * p.sx) * (unsigned)p.Cs * (unsigned)sizeof(T) + (unsigned)cid * 16u;
         } else {
-            a_base[i] = -1;
             a_y[i] = 0;
             a_x[i] = 0;
+            a_off[i] = mv ? (unsigned)m * (unsigned)p.Cs * (unsigned)sizeof(T) + (unsigned)cid * 16u : MCN_OOB;
         }
     }
     unsigned b_off[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + crow + 32 * i;
-        b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u : MCN_OOB;
+        b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u + (unsigned)cid * 16u : MCN_OOB;
     }
     const int wr_off = crow * 128 + ((cid ^ ((crow >> 1) & 7)) << 4);
+    const int pix_bytes = p.Cs * (int)sizeof(T);
+    const int kpt = p.cpt >> 3;                          // K-steps per tap (NT_UNIFORM)
 
     i32x4 ra[AR], rb[BR];
     auto issue = [&](int ks) {
-        const int j = ks * 8 + cid;
-        const bool kv = j < p.nchunks;
-        int tap = 0, cc = j;
-        int dy = 0, dx = 0;
-        if (TAPS) {
-            tap = j / p.cpt;
-            cc = j - tap * p.cpt;
-            const int tt = kv ? tap : 0;
-            dy = s_tdy[tt];
-            dx = s_tdx[tt];
-        }
+        if (MODE == NT_UNIFORM) {
+            const int tap = ks / kpt;                    // wave-uniform (scalar ALU)
+            const int cb = ks - tap * kpt;
+            const int dy = p.tdy[tap], dx = p.tdx[tap];
+            const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + cb * 128);
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            unsigned off = MCN_OOB;
-            if (TAPS) {
-                const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-                const bool ok = kv && a_base[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-                if (ok) off = ((unsigned)(a_base[i] + iy * p.IW + ix) * (unsigned)p.Cs + (unsigned)cc * CE) * (unsigned)sizeof(T);
-            } else {
-                if (kv && a_base[i] >= 0) off = ((unsigned)a_base[i] * (unsigned)p.Cs + (unsigned)cc * CE) * (unsigned)sizeof(T);
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
+                ra[i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
             }
-            ra[i] = buf_load16(rsA, off);
-        }
+        } else if (MODE == NT_LINEAR) {
+            const int j = ks * 8 + cid;
+            const bool kv = j < p.nchunks;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const unsigned off = (kv && b_off[i] != MCN_OOB) ? b_off[i] + (unsigned)j * 16u : MCN_OOB;
-            rb[i] = buf_load16(rsB, off);
+            for (int i = 0; i < AR; ++i) ra[i] = buf_load16(rsA, kv ? a_off[i] + (unsigned)ks * 128u : MCN_OOB);
+        } else {
+            const int j = ks * 8 + cid;
+            const bool kv = j < p.nchunks;
+            const int tap = kv ? j / p.cpt : 0;
+            const int cc = j - tap * p.cpt;
+            const int dy = s_tdy[tap], dx = s_tdx[tap];
+            const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + (cc - cid) * 16);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = kv && (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
+                ra[i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
+            }
         }
+        const bool kvb = MODE == NT_UNIFORM || (ks * 8 + cid) < p.nchunks;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) rb[i] = buf_load16(rsB, kvb ? b_off[i] + (unsigned)ks * 128u : MCN_OOB);   // OOB + small stays OOB
     };
     auto commit = [&](int buf) {
         char* a = smem + buf * TILE_BYTES;
@@ -222,37 +240,71 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     const int a_rd = (wm * WTM + fr) * 128;
     const int b_rd = BM * 128 + (wn * WTN + fr) * 128;
 
+    // Fragment registers are double-buffered and the K-loop is skewed by one slab: the ds_reads of slab s+1 are in
+    // flight under the MFMAs of slab s, and the first slab of the NEXT K-step is read right after the barrier, under
+    // the MFMAs of the current K-step's last slab.  (With one register set the reads can only issue after the last
+    // MFMA that sources them, exposing the LDS latency once per slab: -27 % on the fp32 loop, worse on bf16.)
+    static_assert(MM::SLABS % 2 == 0, "slab skew needs an even slab count");
+    typename MM::Frag xa[2][TM], wb[2][TN];
+    auto load_frags = [&](int set, int sl, const char* base) {
+        const int coff = (((sl * MM::CPS + fc) ^ fsw) << 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[set][i] = *reinterpret_cast<const typename MM::Frag*>(base + a_rd + i * MM::MT * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[set][j] = *reinterpret_cast<const typename MM::Frag*>(base + b_rd + j * MM::MT * 128 + coff);
+    };
+    auto mma_set = [&](int set) {
+#ifndef MCN_ABL_NOMFMA
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[set][j], xa[set][i]);
+#else
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i][0] += wb[set][j][0] * xa[set][i][0];
+#endif
+    };
+
     const int nk = (p.nchunks + 7) >> 3;
     issue(0);
     commit(0);
     __syncthreads();
+#ifdef MCN_ABL_STAMP
+    st_t1 = __builtin_amdgcn_s_memtime();
+#endif
+    load_frags(0, 0, smem);
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) issue(ks + 1);
         const char* base = smem + buf * TILE_BYTES;
+#ifndef MCN_ABL_NOLOAD
+        if (ks + 1 < nk) issue(ks + 1);
+#endif
 #pragma unroll
-        for (int s = 0; s < MM::SLABS; ++s) {
-            const int coff = (((s * MM::CPS + fc) ^ fsw) << 4);
-            typename MM::Frag xa[TM], wb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const typename MM::Frag*>(base + a_rd + i * MM::MT * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const typename MM::Frag*>(base + b_rd + j * MM::MT * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[j], xa[i]);
+        for (int s = 0; s + 1 < MM::SLABS; ++s) {
+            load_frags((s + 1) & 1, s + 1, base);
+            mma_set(s & 1);
         }
+#ifndef MCN_ABL_NOLOAD
         if (ks + 1 < nk) commit(buf ^ 1);
+#endif
+#ifndef MCN_ABL_NOBARRIER
         __syncthreads();
+#endif
+        if (ks + 1 < nk) load_frags(0, 0, smem + (buf ^ 1) * TILE_BYTES);
+        mma_set(1);
     }
 
+#ifdef MCN_ABL_STAMP
+    st_t2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: lane holds 4 consecutive output channels of one pixel per register group ----
     T* out = reinterpret_cast<T*>(p.out);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * MM::MT + fr;
-        if (m >= p.M) continue;
+        if (m >= p.m_end) continue;
         long pix;
         if (TAPS || p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf) {
             const int hw = p.OH * p.OW;
@@ -301,6 +353,15 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
             }
         }
     }
+#ifdef MCN_ABL_STAMP
+    if (tid == 0) {
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias_stamp));
+        sb[blockIdx.x * 4 + 0] = st_t0;
+        sb[blockIdx.x * 4 + 1] = st_t1;
+        sb[blockIdx.x * 4 + 2] = st_t2;
+        sb[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,6 +611,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slab[(long)k * rowsNn + src];
         dw[idx] = s * scale;
+    }
+}
+// Cp == Cin (every conv but the stem): the slab rows are the HWIO rows, so the reduction is a plain strided sum of
+// `splits` arrays — 16-byte lanes, 4 independent slab loads in flight per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_linear_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
+                                                                  long total4, float scale) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dw);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        int k = 0;
+        for (; k + 3 < splits; k += 4) {
+            const f32x4 v0 = s4[(long)k * total4 + i], v1 = s4[(long)(k + 1) * total4 + i];
+            const f32x4 v2 = s4[(long)(k + 2) * total4 + i], v3 = s4[(long)(k + 3) * total4 + i];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; k < splits; ++k) a0 += s4[(long)k * total4 + i];
+        d4[i] = ((a0 + a1) + (a2 + a3)) * scale;
     }
 }
 

@@ -167,8 +167,11 @@ class Lowering(object):
                 post = (skip.grad.data_ptr(), s.data_ptr(), skip.grad.numel(), MCN_DT[skip.dtype])
         g, b = a['gamma'], a['beta']
 
+        # ReLU without a fused residual: the mask is recomputed from x inside the kernel (y pointer = 0)
+        yptr = y.buf.data_ptr() if (skip is not None or not a.get('act', 0)) else 0
+
         def emit(dst):
-            self.bwd.add(lib.mcn_bn_bwd, y.grad.data_ptr(), x.buf.data_ptr(), y.buf.data_ptr(), self.vptr(g), st['mean'].data_ptr(),
+            self.bwd.add(lib.mcn_bn_bwd, y.grad.data_ptr(), x.buf.data_ptr(), yptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
                          st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
                          b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, a.get('act', 0), MCN_DT[x.dtype],
                          self.ws_ptr, self.ws_bytes)

@@ -103,17 +103,18 @@ def bn_fwd_train(x, gamma, beta, eps=1e-3, dtype='float32', skip=None, act=0, ru
     return out
 
 
-def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want_dskip=False, scale=1.0):
+def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want_dskip=False, scale=1.0, beta=None):
     c = x.shape[-1]
     m = x.size // c
     dyd, xd = dev(dy, dtype), dev(x, dtype)
     yd = dev(y, dtype) if y is not None else None
     gd, smd, sid = dev(gamma), dev(save_mean), dev(save_invstd)
+    bd = dev(beta) if beta is not None else None
     dx = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
     dsk = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV) if want_dskip else None
     dg, db = torch.zeros(c, dtype=torch.float32, device=DEV), torch.zeros(c, dtype=torch.float32, device=DEV)
     ws = workspace(lib.mcn_bn_workspace_bytes(m, c))
-    _ffi.check(lib.mcn_bn_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr() if yd is not None else 0, gd.data_ptr(), smd.data_ptr(), sid.data_ptr(),
+    _ffi.check(lib.mcn_bn_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr() if yd is not None else 0, gd.data_ptr(), bd.data_ptr() if bd is not None else 0, smd.data_ptr(), sid.data_ptr(),
                               dx.data_ptr(), dsk.data_ptr() if dsk is not None else 0, dg.data_ptr(), db.data_ptr(), float(scale), m, c, act,
                               MDT[dtype], ws.data_ptr(), ws.numel() * 4, stream()))
     return host(dx), host(dg), host(db), (host(dsk) if dsk is not None else None)

@@ -164,6 +164,29 @@ def test_bn_fused_add_relu(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_relu_mask_recomputed_from_x(dtype):
+    """y = relu(bn(x)) without a residual: the backward may drop the read of y and recompute the mask from x with the
+    forward's own fp32 expression; it must agree with the stored-y mask element for element."""
+    u = _u()
+    shape = (8, 9, 9, 64)
+    x = RNG.standard_normal(shape).astype(np.float32)
+    g = (0.5 + RNG.random(64)).astype(np.float32)
+    b = (0.3 * RNG.standard_normal(64)).astype(np.float32)
+    out = u.bn_fwd_train(x, g, b, 1e-3, dtype, act=1)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    sm, si = out['save_mean'], out['save_invstd']
+    ref = u.bn_bwd(dy, x, out['y'], g, sm, si, dtype, act=1)                 # mask from the stored forward output
+    got = u.bn_bwd(dy, x, None, g, sm, si, dtype, act=1, beta=b)             # mask recomputed from x
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    xq = q(x, dtype)
+    dx, dg, db = O.bn_bwd(q(dy, dtype) * (out['y'] > 0), xq, g.astype(np.float64), sm.astype(np.float64), si.astype(np.float64))
+    check(got[0], dx, dtype, 'dx (recomputed mask)')
+    check(got[1], dg, 'float32', 'dgamma', rel=1e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_bn_infer_and_affine(dtype):
     u = _u()
     from myconvnet_amd import _ffi
