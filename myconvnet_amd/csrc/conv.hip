@@ -74,13 +74,26 @@ static size_t fwd_pack_bytes(const Geo& g, mcn_dtype dt) {
 static size_t dgrad_pack_bytes(const Geo& g, mcn_dtype dt) {
     return align_up((size_t)g.Cin * g.KH * g.KW * round_up(g.Cout, ce_of(dt)) * mcn_dtype_size(dt), 256) + 256 * (size_t)g.SH * g.SW;
 }
+// wgrad tile: fp32 runs 64x64 tiles (32 KB of LDS -> 4 workgroups per CU, same finding as conv_gemm_nt); bf16 keeps
+// 128-row tiles unless the operand has no more than 64 rows / columns (1x1 convs on 64 channels)
+// (per-layer A/B on MI355X: fp32 1x1/stride-1 wgrads gain 5-55 % from 64x64 tiles, the gathered (3x3 / strided) ones lose
+// 8-25 % because the per-K-step pixel bookkeeping is amortised over fewer MFMAs)
+static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int* br, int* bn) {
+    if (dt == MCN_F32 && linear) { *br = 64; *bn = 64; return; }
+    *br = rows <= 64 ? 64 : 128;
+    *bn = Cout <= 64 ? 64 : 128;
+}
+static inline bool conv_is_linear(const Geo& g) {
+    return g.KH * g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
+}
 static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_out) {
     const int KP = dt == MCN_F32 ? 32 : 64;
     const long M = (long)g.N * g.OH * g.OW;
     const int nsteps = (int)((M + KP - 1) / KP);
     const int rows = g.KH * g.KW * round_up(g.Cin, ce_of(dt));
-    const int BN = g.Cout <= 64 ? 64 : 128;
-    const int tiles = ((rows + 127) / 128) * ((g.Cout + BN - 1) / BN);
+    int BR, BN;
+    tn_tile(rows, g.Cout, dt, conv_is_linear(g), &BR, &BN);
+    const int tiles = ((rows + BR - 1) / BR) * ((g.Cout + BN - 1) / BN);
     int splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU in total
     if (splits > nsteps) splits = nsteps;
     if (splits > 512) splits = 512;
@@ -200,22 +213,27 @@ static int launch_nt(const GemmNTParams& p, bool taps, hipStream_t st) {
 
 template <typename T>
 static int launch_tn(const GemmTNParams& p, bool linear, int splits, hipStream_t st) {
-    const int BN = p.Nn <= 64 ? 64 : 128;
-    const int tiles = ((p.rows + 127) / 128) * ((p.Nn + BN - 1) / BN);
+    int BR, BN;
+    tn_tile(p.rows, p.Nn, sizeof(T) == 4 ? MCN_F32 : MCN_BF16, linear, &BR, &BN);
+    const int tiles = ((p.rows + BR - 1) / BR) * ((p.Nn + BN - 1) / BN);
     const dim3 grid(tiles, splits), block(256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
-#define MCN_LAUNCH_TN(BNV, LINV)                                                     \
+#define MCN_LAUNCH_TN(BRV, BNV, LINV)                                                \
     do {                                                                             \
-        const int lds = 2 * (KP * 128 * (int)sizeof(T) + KP * BNV * (int)sizeof(T)); \
-        static bool once = (allow_lds(conv_gemm_tn<T, BNV, LINV>, 2 * (64 * 128 * 4 + 64 * BNV * 4)), true); \
+        const int lds = 2 * KP * (BRV + BNV) * (int)sizeof(T);                       \
+        static bool once = (allow_lds(conv_gemm_tn<T, BRV, BNV, LINV>, 2 * 64 * (BRV + BNV) * 4), true); \
         (void)once;                                                                  \
-        hipLaunchKernelGGL((conv_gemm_tn<T, BNV, LINV>), grid, block, lds, st, p);   \
+        hipLaunchKernelGGL((conv_gemm_tn<T, BRV, BNV, LINV>), grid, block, lds, st, p); \
     } while (0)
-    if (BN == 128) {
-        if (linear) MCN_LAUNCH_TN(128, true); else MCN_LAUNCH_TN(128, false);
-    } else {
-        if (linear) MCN_LAUNCH_TN(64, true); else MCN_LAUNCH_TN(64, false);
-    }
+#define MCN_LAUNCH_TN_LIN(BRV, BNV)                                  \
+    do {                                                             \
+        if (linear) MCN_LAUNCH_TN(BRV, BNV, true); else MCN_LAUNCH_TN(BRV, BNV, false); \
+    } while (0)
+    if (BR == 128 && BN == 128) MCN_LAUNCH_TN_LIN(128, 128);
+    else if (BR == 128) MCN_LAUNCH_TN_LIN(128, 64);
+    else if (BN == 128) MCN_LAUNCH_TN_LIN(64, 128);
+    else MCN_LAUNCH_TN_LIN(64, 64);
+#undef MCN_LAUNCH_TN_LIN
 #undef MCN_LAUNCH_TN
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -435,7 +453,7 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         p.sy = g.SH; p.sx = g.SW; p.Nn = g.Cout; p.ldy = g.Cout; p.nsteps = nsteps; p.steps_per_split = sps;
         p.x_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(T));
         p.dy_bytes = (unsigned)((size_t)M * g.Cout * sizeof(T));
-        const bool linear = ntaps == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
+        const bool linear = conv_is_linear(g);
         if (M > 0) {
             int rc = launch_tn<T>(p, linear, splits, st);
             if (rc) return rc;

@@ -19,6 +19,7 @@
 // (weights, activations) so that each lane ends with 4 consecutive output channels of one pixel
 // => 8/16-byte epilogue stores.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 #define MCN_MAX_TAPS 64
@@ -184,8 +185,11 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     const int pix_bytes = p.Cs * (int)sizeof(T);
     const int kpt = p.cpt >> 3;                          // K-steps per tap (NT_UNIFORM)
 
-    i32x4 ra[AR], rb[BR];
-    auto issue = [&](int ks) {
+    // two staging register sets: the global loads of K-step ks+2 are issued while step ks is computed and step ks+1
+    // is still in flight (prefetch distance 2: twice the bytes in flight per CU against L2 / HBM latency)
+    i32x4 ra[2][AR], rb[2][BR];
+    auto issue = [&](int ks, auto setc) {
+        constexpr int S = decltype(setc)::value;
         if (MODE == NT_UNIFORM) {
             const int tap = ks / kpt;                    // wave-uniform (scalar ALU)
             const int cb = ks - tap * kpt;
@@ -194,13 +198,13 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ra[i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
+                ra[S][i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
             }
         } else if (MODE == NT_LINEAR) {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) ra[i] = buf_load16(rsA, kv ? a_off[i] + (unsigned)ks * 128u : MCN_OOB);
+            for (int i = 0; i < AR; ++i) ra[S][i] = buf_load16(rsA, kv ? a_off[i] + (unsigned)ks * 128u : MCN_OOB);
         } else {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
@@ -211,20 +215,21 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = kv && (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ra[i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
+                ra[S][i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
             }
         }
         const bool kvb = MODE == NT_UNIFORM || (ks * 8 + cid) < p.nchunks;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = buf_load16(rsB, kvb ? b_off[i] + (unsigned)ks * 128u : MCN_OOB);   // OOB + small stays OOB
+        for (int i = 0; i < BR; ++i) rb[S][i] = buf_load16(rsB, kvb ? b_off[i] + (unsigned)ks * 128u : MCN_OOB);   // OOB + small stays OOB
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, auto setc) {
+        constexpr int S = decltype(setc)::value;
         char* a = smem + buf * TILE_BYTES;
         char* b = a + BM * 128;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<i32x4*>(a + wr_off + i * 32 * 128) = ra[i];
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<i32x4*>(a + wr_off + i * 32 * 128) = ra[S][i];
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<i32x4*>(b + wr_off + i * 32 * 128) = rb[i];
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<i32x4*>(b + wr_off + i * 32 * 128) = rb[S][i];
     };
 
     typename MM::Acc acc[TN][TM];
@@ -268,18 +273,21 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     };
 
     const int nk = (p.nchunks + 7) >> 3;
-    issue(0);
-    commit(0);
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    issue(0, S0{});
+    if (nk > 1) issue(1, S1{});
+    commit(0, S0{});
     __syncthreads();
 #ifdef MCN_ABL_STAMP
     st_t1 = __builtin_amdgcn_s_memtime();
 #endif
     load_frags(0, 0, smem);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
+    // one K-step: LDS buffer `buf` holds step ks, register set CS holds step ks+1 (in flight), set IS is free
+    auto kstep = [&](int ks, int buf, auto cs, auto is) {
         const char* base = smem + buf * TILE_BYTES;
 #ifndef MCN_ABL_NOLOAD
-        if (ks + 1 < nk) issue(ks + 1);
+        if (ks + 2 < nk) issue(ks + 2, is);
 #endif
 #pragma unroll
         for (int s = 0; s + 1 < MM::SLABS; ++s) {
@@ -287,13 +295,17 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
             mma_set(s & 1);
         }
 #ifndef MCN_ABL_NOLOAD
-        if (ks + 1 < nk) commit(buf ^ 1);
+        if (ks + 1 < nk) commit(buf ^ 1, cs);
 #endif
 #ifndef MCN_ABL_NOBARRIER
         __syncthreads();
 #endif
         if (ks + 1 < nk) load_frags(0, 0, smem + (buf ^ 1) * TILE_BYTES);
         mma_set(1);
+    };
+    for (int ks = 0; ks < nk; ks += 2) {
+        kstep(ks, 0, S1{}, S0{});
+        if (ks + 1 < nk) kstep(ks + 1, 1, S0{}, S1{});
     }
 
 #ifdef MCN_ABL_STAMP
@@ -383,11 +395,10 @@ struct TNCfg<float> {
 // bf16 pixel-major tile: row stride RS bytes, 32-byte granule g of pixel row p stored at granule g ^ key(p)
 __device__ __forceinline__ int tn_key(int p) { return (p & 3) | (((p >> 3) & 1) << 2); }
 
-template <typename T, int BN, bool LINEAR>
+template <typename T, int BR, int BN, bool LINEAR>
 __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
     typedef TNCfg<T> CF;
     constexpr int CE = VecTraits<T>::CE;
-    constexpr int BR = 128;
     constexpr int KP = CF::KP;
     constexpr int XRS = BR * (int)sizeof(T);           // X tile row stride (bytes): 256 / 512
     constexpr int DRS = BN * (int)sizeof(T);
@@ -396,9 +407,10 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
     constexpr int XN = KP / XPR, DN = KP / DPR;        // chunks per thread
     constexpr int XBYTES = KP * XRS, DBYTES = KP * DRS;
     constexpr int TILE_BYTES = XBYTES + DBYTES;
-    constexpr int WTR = 64, WTN = BN / 2;
+    constexpr int WTR = BR / 2, WTN = BN / 2;
     constexpr int TR = WTR / CF::MT, TNn = WTN / CF::MT;
-    constexpr int DGM = (DRS / 32) - 1;                // granule mask of the D tile
+    constexpr int DGM = (DRS / 32) - 1;                // granule masks of the D / X tiles
+    constexpr int XGM = (XRS / 32) - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
         for (int i = 0; i < XN; ++i) {
             const int pr = xpr + XPR * i;
             int off;
-            if (sizeof(T) == 2) off = pr * XRS + ((((xcc >> 1) ^ tn_key(pr))) << 5) + ((xcc & 1) << 4);
+            if (sizeof(T) == 2) off = pr * XRS + ((((xcc >> 1) ^ (tn_key(pr) & XGM))) << 5) + ((xcc & 1) << 4);
             else off = pr * XRS + xcc * 16;
             *reinterpret_cast<i32x4*>(xs + off) = rx[i];
         }
@@ -525,9 +537,9 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
                     const int key = tn_key(pix);
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
-                        const int gran = wr * 4 + i;
+                        const int gran = wr * (WTR / 16) + i;
                         xh[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(xs + pix * XRS + ((gran ^ key) << 5) + 8 * pp));
+                            (__attribute__((address_space(3))) bf16x4*)(xs + pix * XRS + ((gran ^ (key & XGM)) << 5) + 8 * pp));
                     }
 #pragma unroll
                     for (int j = 0; j < TNn; ++j) {
