@@ -21,6 +21,7 @@ def init_process_group(device=None):
     if dist.is_initialized():
         return
     backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
+    backend = os.environ.get('MCN_DIST_BACKEND', backend)        # 'gloo' lets several ranks share one GPU in tests
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     kw = {}
@@ -118,7 +119,10 @@ class DataParallel(object):
         self.reducer.finish()
 
     def gather_bn_stats(self):
-        dist.all_gather_into_tensor(self.gathered_stats.view(-1), self.model.batch_stats)
+        if dist.get_backend() == 'nccl':
+            dist.all_gather_into_tensor(self.gathered_stats.view(-1), self.model.batch_stats)
+        else:                                                    # gloo has no all_gather_into_tensor for device tensors
+            dist.all_gather([self.gathered_stats[r] for r in range(self.world)], self.model.batch_stats)
 
     def mean_scalar(self, t):
         self._loss_tmp.copy_(t.reshape(1))

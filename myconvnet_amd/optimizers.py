@@ -97,11 +97,12 @@ class Optimizer(object):
         # cross-rank running-statistics chain (convnet.py:1899-1909)
         self._post_fwd = Program()
         self.dp = None
-        if m.world_size > 1:
+        if m.world_size > 1 or kwargs.get('force_data_parallel', False):      # (forced with one rank: exercises the RCCL calls in tests)
             from .dist import DataParallel
             self.dp = DataParallel(m, bucket_mb=float(kwargs.get('allreduce_bucket_mb', 25.0)))
-            self._post_fwd.add(lib.mcn_bn_running_chain, m.stats.data.data_ptr(), self.dp.gathered_stats.data_ptr(), m.world_size,
-                               m.stats.size, float(m.batch_norm_decay))
+            if m.world_size > 1:                         # with one rank the BN kernel itself updates the running statistics
+                self._post_fwd.add(lib.mcn_bn_running_chain, m.stats.data.data_ptr(), self.dp.gathered_stats.data_ptr(), m.world_size,
+                                   m.stats.size, float(m.batch_norm_decay))
         return P
 
     def _set_hyper(self):

@@ -1,0 +1,131 @@
+"""Data-parallel training step on the GPU box: two ranks (gloo rendezvous on 127.0.0.1, both on the one MI355X the box has;
+the production backend is RCCL) against the oracle's multi-tower restatement — tower-mean gradients
+(optimizers.py:125-142), chained BN running statistics (convnet.py:1899-1909), mean of tower losses (convnet.py:510)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      MCN_DIST_BACKEND='gloo')
+    import make_golden as MG
+    import myconvnet_amd as M
+    from oracle import net as ON
+    spec = ON.ResNetSpec.resnet50(10, 8)
+    params, stats = MG.net_params(spec)
+    B = 8                                              # per rank; total batch 16 (B=4 towers make the tiny net ill-conditioned in fp32)
+    model = M.ResNet50([64, 64, 3], 10, batch_size=B * world, width_div=8, num_gpus=world, device='cuda:0', seed=rank)  # different init per rank:
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, allreduce_bucket_mb=0.2)
+    if rank == 0:                                      # rank 0's variables are broadcast at DataParallel construction...
+        pass
+    model.set_variables(dict(params, **stats))         # ...then every rank gets the same injected weights
+    rng = np.random.default_rng(123)
+    out = []
+    for step in range(2):
+        x = rng.random((B * world, 64, 64, 3)).astype(np.float32)
+        y = rng.integers(0, 10, B * world).astype(np.float32)
+        model.feed(x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B])       # rank r owns images [r*B, (r+1)*B) (dataset.py:113-129)
+        loss, _, pred = opt._step(None)
+        out.append((loss, pred))
+    q.put((rank, out, model.get_variables('data'), model.get_variables('ema'), len(opt.dp.reducer.plan)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_matches_multi_tower_oracle():
+    import make_golden as MG
+    from oracle import net as ON
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    spec = ON.ResNetSpec.resnet50(10, 8)
+    params, stats = MG.net_params(spec)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    rng = np.random.default_rng(123)
+    B = 8
+    for step in range(2):
+        x = rng.random((B * world, 64, 64, 3)).astype(np.float32)
+        y = rng.integers(0, 10, B * world).astype(np.float32)
+        towers = [(x[r * B:(r + 1) * B].astype(np.float64), y[r * B:(r + 1) * B].astype(np.float64)) for r in range(world)]
+        rloss, rpred, _ = ON.train_step(spec, state, None, None, batch_total=B * world, tower_batches=towers)
+        for r in range(world):
+            loss, pred = res[r][1][step]
+            assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, r, loss, rloss)        # mean of tower losses on every rank
+            np.testing.assert_allclose(pred, rpred[r * B:(r + 1) * B], rtol=0, atol=2e-4)
+
+    def rel(a, b):
+        return np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+    for r in range(world):
+        data, ema = res[r][2], res[r][3]
+        assert max(rel(data[k], v) for k, v in state.params.items()) <= 1e-4
+        assert max(rel(data[k], v) for k, v in state.stats.items()) <= 1e-4           # chained running statistics
+        assert max(rel(ema[k], v) for k, v in state.ema.items()) <= 1e-4
+        assert res[r][4] >= 2                                                         # several buckets => overlap points
+    for k in res[0][2]:                                                               # replicas stay bit-identical
+        np.testing.assert_array_equal(res[0][2][k], res[1][2][k])
+
+
+def _nccl_worker(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.pop('MCN_DIST_BACKEND', None)
+    import make_golden as MG
+    import myconvnet_amd as M
+    from oracle import net as ON
+    import torch.distributed as dist
+    spec = ON.ResNetSpec.resnet50(10, 8)
+    params, stats = MG.net_params(spec)
+    res = {}
+    rng = np.random.default_rng(5)
+    x = rng.random((8, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 10, 8).astype(np.float32)
+    for name, force in (('plain', False), ('rccl', True)):
+        model = M.ResNet50([64, 64, 3], 10, batch_size=8, width_div=8, num_gpus=1, device='cuda:0')
+        opt = M.MomentumOptimizer(model, None, None, steps_per_epoch=1, learning_warmup_epochs=0.0, force_data_parallel=force, allreduce_bucket_mb=0.2)
+        model.set_variables(dict(params, **stats))
+        model.feed(x, y)
+        loss, _, _ = opt._step(None)
+        res[name] = (loss, model.get_variables('data'))
+        if force:
+            assert dist.get_backend() == 'nccl' and len(opt.dp.reducer.plan) >= 2
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_rccl_calls_with_one_rank_change_nothing():
+    """The production collectives (RCCL: async all_reduce on flat-buffer slices, all_gather_into_tensor, broadcast) with a
+    single rank must reproduce the plain step bit for bit (sum over one rank, 1/N = 1)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res['plain'][0] == res['rccl'][0]
+    for k, v in res['plain'][1].items():
+        np.testing.assert_array_equal(v, res['rccl'][1][k])
