@@ -89,25 +89,32 @@ def timed(opt, steps, warmup, world):
 
 
 # ---- per-kernel timing (instrumented pass) ---------------------------------------------------------------------
-def conv_kernel_name(kind, geom, dtype):
-    """The kernel FAMILY a conv call runs in (csrc/conv.hip): fwd and dgrad share conv_gemm_nt (the tile shape is picked
-    per layer by pick_nt_tile), wgrad runs conv_gemm_tn."""
-    t = 'float' if dtype == 'fp32' else 'bf16'
-    return ('conv_gemm_nt<{}> (fwd+dgrad)' if kind in ('fwd', 'dgrad') else 'conv_gemm_tn<{}> (wgrad)').format(t)
-
-
 def instrumented_pass(model, dtype, reps=3, layers=False):
-    """Time every C-ABI launch of forward+backward with HIP events on the launch stream; returns {kernel: [n, ms, flop]}."""
+    """Time every C-ABI launch of forward+backward with HIP events on the launch stream (torch's current stream IS the
+    launch stream).  Conv calls are keyed by the exact kernel symbol rocprofv3 reports (mcn_conv2d_kernel_name); a call
+    that launches the kernel several times (stride-2 dgrad: one launch per parity class) is counted as that many
+    launches.  Returns {key: [launches, ms, flop]} per step."""
+    import ctypes
+    from myconvnet_amd import _ffi
     from myconvnet_amd._ffi import lib, check
     low = model._train_low
     sp = model.stream_ptr()
-    names = {'mcn_conv2d_fwd': 'fwd', 'mcn_conv2d_dgrad': 'dgrad', 'mcn_conv2d_wgrad': 'wgrad'}
-    geoms = {}
-    for n in model.graph.nodes:
-        if n.op == 'conv':
-            geoms[id(n.attrs['geom'])] = n.attrs['geom']
-    table = {}
+    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+    mdt = _ffi.F32 if dtype == 'fp32' else _ffi.BF16
+    buf = ctypes.create_string_buffer(128)
+    table, rows = {}, {}
     calls = low.fwd.calls + low.bwd.calls
+    low.prepack.run(sp)
+    # cost of an empty event bracket on this stream (two records back to back), subtracted from every bracket below
+    empt = []
+    for _ in range(64):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        empt.append((e0, e1))
+    torch.cuda.synchronize()
+    bracket_ms = float(np.median([a.elapsed_time(b) for a, b in empt]))
+    table['_bracket_us'] = [0, bracket_ms, 0.0]
     for rep in range(reps):
         evs = []
         for fn, a in calls:
@@ -121,41 +128,36 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
         if rep == 0:
             continue                                                       # first rep warms caches / clocks
         for fn, a, e0, e1 in evs:
-            ms = e0.elapsed_time(e1)
-            kind = names.get(getattr(fn, '__name__', ''))
-            if kind is None:
-                key, flop = getattr(fn, '__name__', 'other'), 0.0
+            ms = max(e0.elapsed_time(e1) - bracket_ms, 0.0)
+            name = getattr(fn, '__name__', 'other')
+            if name not in ops:
+                key, flop, nl = name, 0.0, 1
             else:
                 gm = [x for x in a if hasattr(x, '_obj')][0]._obj          # ctypes.byref(geom)
                 oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
                 ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
                 flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout
-                key = conv_kernel_name(kind, gm, dtype)
+                nl = lib.mcn_conv2d_kernel_name(ops[name], ctypes.byref(gm), mdt, buf, 128)
+                key = buf.value.decode()
+                if layers:
+                    es = 4 if dtype == 'fp32' else 2
+                    byt = es * gm.N * (gm.H * gm.W * gm.Cin + oh * ow * gm.Cout)
+                    r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
+                    r[0] += 1
+                    r[1] += ms
             t = table.setdefault(key, [0, 0.0, 0.0])
-            t[0] += 1
+            t[0] += nl
             t[1] += ms
             t[2] += flop
     if layers:
-        es = 4 if dtype == 'fp32' else 2
-        rows = {}
-        for fn, a, e0, e1 in evs:
-            kind = names.get(getattr(fn, '__name__', ''))
-            if kind is None:
-                continue
-            gm = [x for x in a if hasattr(x, '_obj')][0]._obj
-            oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
-            flop = 2.0 * gm.N * oh * oh * gm.KH * gm.KW * gm.Cin * gm.Cout
-            byt = es * gm.N * (gm.H * gm.W * gm.Cin + oh * oh * gm.Cout)
-            key = (kind, gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH)
-            r = rows.setdefault(key, [0, 0.0, flop, byt])
-            r[0] += 1
-            r[1] += e0.elapsed_time(e1)
-        print('kind   H   Cin  Cout k s  n    us/launch  TFLOP/s   GB/s(min traffic)', file=sys.stderr)
+        print('kind   H   Cin  Cout k s  n    us/call   TFLOP/s   GB/s(min traffic)  kernel', file=sys.stderr)
         for key, (n, ms, flop, byt) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
             us = ms / n * 1e3
-            print('{:5s} {:3d} {:5d} {:5d} {} {} {:2d} {:10.1f} {:8.1f} {:8.0f}'.format(key[0], key[1], key[2], key[3], key[4], key[5], n, us,
-                  flop / us / 1e6, byt / us / 1e3), file=sys.stderr)
-    for t in table.values():
+            print('{:5s} {:3d} {:5d} {:5d} {} {} {:2d} {:10.1f} {:8.1f} {:8.0f}  {}'.format(key[0], key[1], key[2], key[3], key[4], key[5],
+                  n // (reps - 1), us, flop / us / 1e6, byt / us / 1e3, key[6]), file=sys.stderr)
+    for k, t in table.items():
+        if k == '_bracket_us':
+            continue
         t[0] //= (reps - 1)
         t[1] /= (reps - 1)
         t[2] /= (reps - 1)
@@ -212,13 +214,15 @@ def main():
     }
     if world == 1:
         table = instrumented_pass(model, args.dtype, layers=args.layers)
+        bracket_us = table.pop('_bracket_us')[1] * 1e3
         convs = {k: v for k, v in table.items() if k.startswith('conv_gemm')}
-        dom = max(convs.items(), key=lambda kv: kv[1][1])
+        dom = max(convs.items(), key=lambda kv: kv[1][1])                 # the kernel symbol with the most time per step
         name, (cnt, ms_k, flop) = dom
         ach = flop / (ms_k * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': name, 'launches_per_step': cnt, 'avg_launch_us': round(ms_k / cnt * 1e3, 2),
                            'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
-                           'frac': round(ach / PEAK_TFLOPS[args.dtype], 4), 'traffic': None}
+                           'frac': round(ach / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
+                           'event_bracket_overhead_us': round(bracket_us, 2)}
         tot = sum(v[1] for v in table.values())
         out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:12]}
         out['kernel_ms_total'] = round(tot, 3)

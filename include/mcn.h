@@ -62,14 +62,41 @@ typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_co
 size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
 
 /* replaces tf.nn.conv2d (reference convnet.py:1659) [+ tf.nn.bias_add, convnet.py:1694, when
- * bias != NULL]. */
-int mcn_conv2d_fwd(const void* x, const float* w_hwio, const float* bias, void* y, const mcn_conv_geom* g,
-                   mcn_dtype dtype, mcn_layout layout, void* workspace, size_t workspace_bytes, void* stream);
+ * bias != NULL].  w_packed (may be NULL): the operand produced by mcn_conv2d_pack_* from the same
+ * w_hwio for MCN_CONV_FWD; when NULL the call re-packs w_hwio into `workspace` itself. */
+int mcn_conv2d_fwd(const void* x, const float* w_hwio, const void* w_packed, const float* bias, void* y,
+                   const mcn_conv_geom* g, mcn_dtype dtype, mcn_layout layout, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* replaces Conv2DBackpropInput (autograd of convnet.py:1659 via optimizers.py:106).
- * dx:[N][H][W][Cin] (dense, channel stride Cin).  accumulate != 0 => dx += result. */
-int mcn_conv2d_dgrad(const void* dy, const float* w_hwio, void* dx, const mcn_conv_geom* g, int accumulate,
-                     mcn_dtype dtype, mcn_layout layout, void* workspace, size_t workspace_bytes, void* stream);
+ * dx:[N][H][W][Cin] (dense, channel stride Cin).  accumulate != 0 => dx += result.
+ * w_packed (may be NULL): operand packed for MCN_CONV_DGRAD. */
+int mcn_conv2d_dgrad(const void* dy, const float* w_hwio, const void* w_packed, void* dx, const mcn_conv_geom* g,
+                     int accumulate, mcn_dtype dtype, mcn_layout layout, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* The per-use cast of the fp32 master weights (reference weight_variable(), convnet.py:1421-1422) done ONCE per
+ * step for every convolution of a model in a single launch: the caller keeps one packed operand per (conv, op),
+ * builds a descriptor table on the host, uploads it once, and runs it whenever the masters changed.
+ *   bytes  = mcn_conv2d_packed_bytes(op, geom, dtype)           (0: this op takes no packed operand)
+ *   mcn_conv2d_pack_table_build(jobs, n, dtype, host_table, mcn_conv2d_pack_table_bytes(jobs, n), &ndesc)
+ *   copy host_table to the device;  mcn_conv2d_pack_run(dev_table, ndesc, dtype, stream)            */
+typedef struct {
+    const float* w_hwio; /* device pointer: fp32 master [KH][KW][Cin][Cout] */
+    void* packed;        /* device pointer: mcn_conv2d_packed_bytes() bytes */
+    mcn_conv_geom geom;
+    int32_t op;          /* MCN_CONV_FWD or MCN_CONV_DGRAD */
+    int32_t reserved;
+} mcn_pack_job;
+size_t mcn_conv2d_packed_bytes(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
+size_t mcn_conv2d_pack_table_bytes(const mcn_pack_job* jobs, int32_t njobs);
+int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njobs, mcn_dtype dtype, void* host_table,
+                                size_t host_table_bytes, int32_t* ndesc);
+int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, void* stream);
+
+/* profiling aid: writes the name of the GEMM kernel a conv call launches (as rocprofv3 prints it) into buf
+ * (>= 64 bytes) and returns how many launches of it the call makes (stride-2 dgrad: one per parity class). */
+int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype, char* buf, size_t buflen);
 
 /* replaces Conv2DBackpropFilter.  dw:[KH][KW][Cin][Cout] fp32 (overwritten; deterministic
  * split-K through workspace slabs).  dbias (optional, fp32 [Cout]) = column sums of dy

@@ -31,13 +31,22 @@ class ConvGeom(ctypes.Structure):
                                        'padT', 'padB', 'padL', 'padR', 'x_cs')]
 
 
+class PackJob(ctypes.Structure):
+    _fields_ = [('w_hwio', c_void_p), ('packed', c_void_p), ('geom', ConvGeom), ('op', c_int32), ('reserved', c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/mcn.h declares
 SIGNATURES = {
     'mcn_version': (c_int, []),
     'mcn_last_error': (c_char_p, []),
     'mcn_conv2d_workspace_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
-    'mcn_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    'mcn_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_packed_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
+    'mcn_conv2d_pack_table_bytes': (c_size_t, [ctypes.POINTER(PackJob), c_int32]),
+    'mcn_conv2d_pack_table_build': (c_int, [ctypes.POINTER(PackJob), c_int32, c_int, c_void_p, c_size_t, ctypes.POINTER(c_int32)]),
+    'mcn_conv2d_pack_run': (c_int, [c_void_p, c_int32, c_int, c_void_p]),
+    'mcn_conv2d_kernel_name': (c_int, [c_int, ctypes.POINTER(ConvGeom), c_int, ctypes.c_char_p, c_size_t]),
     'mcn_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_bn_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'mcn_bn_fwd_train': (c_int, [c_void_p] * 11 + [c_float, c_int64, c_int32, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -363,7 +363,9 @@ class ConvNet(object):
 
     def forward(self, train=True):
         low = self._train_low if train else self._eval_low
-        low.fwd.run(self.stream_ptr())
+        sp = self.stream_ptr()
+        low.prepack.run(sp)            # weights changed since the last pass (optimizer step / EMA): refresh the packed operands
+        low.fwd.run(sp)
 
     def backward(self, hooks=None):
         self._train_low.bwd.run(self.stream_ptr(), hooks)

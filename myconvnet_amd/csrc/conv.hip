@@ -267,8 +267,8 @@ static inline unsigned nblocks(long total, int cap = 8192) {
 
 // ---- forward -------------------------------------------------------------------------------------------
 template <typename T>
-static int conv_fwd_t(const void* x, const float* w, const float* bias, void* y, const Geo& g, mcn_dtype dt, void* ws,
-                      size_t ws_bytes, hipStream_t st) {
+static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const Geo& g, mcn_dtype dt,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
     const long M = (long)g.N * g.OH * g.OW;
     if (M == 0) return MCN_OK;
     if (!mfma_path_ok(g, dt)) {
@@ -279,7 +279,7 @@ static int conv_fwd_t(const void* x, const float* w, const float* bias, void* y,
         return MCN_OK;
     }
     const size_t need = fwd_pack_bytes(g, dt);
-    if (!ws || ws_bytes < need) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+    if (!w_packed && (!ws || ws_bytes < need)) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
     const int ce = ce_of(dt), Cp = round_up(g.Cin, ce), ntaps = g.KH * g.KW;
     PackParams pk;
     memset(&pk, 0, sizeof(pk));
@@ -293,9 +293,11 @@ static int conv_fwd_t(const void* x, const float* w, const float* bias, void* y,
             p.tdy[t] = (signed char)(r * g.DH - g.pT);
             p.tdx[t] = (signed char)(s * g.DW - g.pL);
         }
-    int rc = launch_pack<T>(pk, st);
-    if (rc) return rc;
-    p.in = x; p.wt = ws; p.out = y; p.bias = bias;
+    if (!w_packed) {                                     // per-use cast / re-pack of the fp32 master (convnet.py:1421-1422)
+        int rc = launch_pack<T>(pk, st);
+        if (rc) return rc;
+    }
+    p.in = x; p.wt = w_packed ? w_packed : ws; p.out = y; p.bias = bias;
     p.M = (int)M; p.OH = g.OH; p.OW = g.OW; p.IH = g.H; p.IW = g.W; p.Cs = g.xcs;
     p.cpt = Cp / ce; p.ntaps = ntaps; p.nchunks = ntaps * p.cpt; p.sy = g.SH; p.sx = g.SW; p.Nn = g.Cout;
     p.OHf = g.OH; p.OWf = g.OW; p.ldo = g.Cout; p.osy = 1; p.osx = 1; p.oy0 = 0; p.ox0 = 0; p.accumulate = 0;
@@ -305,8 +307,8 @@ static int conv_fwd_t(const void* x, const float* w, const float* bias, void* y,
     return launch_nt<T>(p, !linear, st);
 }
 
-extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const float* bias, void* y, const mcn_conv_geom* gg, mcn_dtype dtype,
-                              mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const mcn_conv_geom* gg,
+                              mcn_dtype dtype, mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
     Geo g;
     int rc = geo_from(gg, &g);
     if (rc) return rc;
@@ -316,8 +318,8 @@ extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const float* bias, 
         if (mfma_path_ok(g, dtype)) MCN_FAIL(MCN_E_BADARG, "conv2d_fwd: internal: bias with Cout%%4");
     }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, bias, y, g, dtype, ws, ws_bytes, st);
-    if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, bias, y, g, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd: dtype %d unsupported (fp16 reserved; use bf16)", (int)dtype);
 }
 
@@ -325,8 +327,8 @@ extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const float* bias, 
 static inline int pos_mod(int a, int m) { return ((a % m) + m) % m; }
 
 template <typename T>
-static int conv_dgrad_t(const void* dy, const float* w, void* dx, const Geo& g, int accumulate, mcn_dtype dt, void* ws,
-                        size_t ws_bytes, hipStream_t st) {
+static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, void* dx, const Geo& g, int accumulate, mcn_dtype dt,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
     const long Min = (long)g.N * g.H * g.W;
     if (Min == 0) return MCN_OK;
     if (!mfma_dgrad_ok(g, dt)) {
@@ -337,7 +339,7 @@ static int conv_dgrad_t(const void* dy, const float* w, void* dx, const Geo& g, 
         return MCN_OK;
     }
     const size_t need = dgrad_pack_bytes(g, dt);
-    if (!ws || ws_bytes < need) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, need);
+    if (!w_packed && (!ws || ws_bytes < need)) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, need);
     const int ce = ce_of(dt), Cp = round_up(g.Cout, ce);
 
     // one exact sub-convolution per stride-parity class of dx
@@ -366,7 +368,7 @@ static int conv_dgrad_t(const void* dy, const float* w, void* dx, const Geo& g, 
     if (any_empty && !accumulate) {
         if (hipMemsetAsync(dx, 0, (size_t)Min * g.Cin * sizeof(T), st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "conv2d_dgrad: memset failed");
     }
-    char* wsp = (char*)ws;
+    char* wsp = w_packed ? (char*)const_cast<void*>(w_packed) : (char*)ws;
     for (int k = 0; k < ncls; ++k) {
         const Cls& c = cls[k];
         const int OHs = (g.H - c.py + g.SH - 1) / g.SH, OWs = (g.W - c.px + g.SW - 1) / g.SW;
@@ -381,8 +383,11 @@ static int conv_dgrad_t(const void* dy, const float* w, void* dx, const Geo& g, 
             p.tdy[t] = c.dy[t]; p.tdx[t] = c.dx[t];
             if (c.dy[t] || c.dx[t]) zero_off = false;
         }
-        int rc = launch_pack<T>(pk, st);
-        if (rc) return rc;
+        int rc = MCN_OK;
+        if (!w_packed) {
+            rc = launch_pack<T>(pk, st);
+            if (rc) return rc;
+        }
         p.in = dy; p.wt = wsp; p.out = dx; p.bias = nullptr;
         p.M = g.N * OHs * OWs; p.OH = OHs; p.OW = OWs; p.IH = g.OH; p.IW = g.OW; p.Cs = g.Cout;
         p.cpt = Cp / ce; p.ntaps = c.nt; p.nchunks = c.nt * p.cpt; p.sy = 1; p.sx = 1; p.Nn = g.Cin;
@@ -397,8 +402,8 @@ static int conv_dgrad_t(const void* dy, const float* w, void* dx, const Geo& g, 
     return MCN_OK;
 }
 
-extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, void* dx, const mcn_conv_geom* gg, int accumulate, mcn_dtype dtype,
-                                mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, const void* w_packed, void* dx, const mcn_conv_geom* gg, int accumulate,
+                                mcn_dtype dtype, mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
     Geo g;
     int rc = geo_from(gg, &g);
     if (rc) return rc;
@@ -406,8 +411,8 @@ extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, void* dx, const 
     if (!dy || !w || !dx) MCN_FAIL(MCN_E_BADARG, "conv2d_dgrad: null pointer");
     if (g.xcs != g.Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: dx must be dense (x_cs == Cin)");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, dx, g, accumulate, dtype, ws, ws_bytes, st);
-    if (dtype == MCN_BF16) return conv_dgrad_t<bf16_t>(dy, w, dx, g, accumulate, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
+    if (dtype == MCN_BF16) return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: dtype %d unsupported", (int)dtype);
 }
 
@@ -484,6 +489,132 @@ extern "C" int mcn_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_wgrad: dtype %d unsupported", (int)dtype);
 }
 
+// ---- packed operands kept by the caller: sizes, one-launch batch packing, kernel introspection --------------------------------
+extern "C" size_t mcn_conv2d_packed_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
+    Geo g;
+    if (geo_from(gg, &g) != MCN_OK || (dtype != MCN_F32 && dtype != MCN_BF16)) return 0;
+    if (op == MCN_CONV_FWD) return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) : 0;
+    if (op == MCN_CONV_DGRAD) return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) : 0;
+    return 0;
+}
+
+// descriptors for one job; returns how many (0 = the op does not use a packed operand)
+static int pack_descs(const Geo& g, mcn_dtype dt, mcn_conv_op op, const float* w, void* packed, PackParams* out) {
+    const int ce = ce_of(dt);
+    const size_t es = mcn_dtype_size(dt);
+    if (op == MCN_CONV_FWD) {
+        if (!mfma_path_ok(g, dt)) return 0;
+        PackParams& pk = out[0];
+        memset(&pk, 0, sizeof(pk));
+        pk.w = w; pk.out = packed; pk.KW = g.KW; pk.Cin = g.Cin; pk.Cout = g.Cout; pk.rows = g.Cout; pk.Cp = round_up(g.Cin, ce);
+        pk.ntaps = g.KH * g.KW; pk.mode = 0;
+        for (int r = 0; r < g.KH; ++r)
+            for (int s = 0; s < g.KW; ++s) { pk.tr[r * g.KW + s] = (signed char)r; pk.ts[r * g.KW + s] = (signed char)s; }
+        return 1;
+    }
+    if (op != MCN_CONV_DGRAD || !mfma_dgrad_ok(g, dt)) return 0;
+    const int Cp = round_up(g.Cout, ce);
+    char* dst = (char*)packed;
+    int n = 0;
+    for (int py = 0; py < g.SH; ++py)
+        for (int px = 0; px < g.SW; ++px) {
+            if (py >= g.H || px >= g.W) continue;
+            PackParams pk;
+            memset(&pk, 0, sizeof(pk));
+            for (int r = 0; r < g.KH; ++r) {
+                if (pos_mod(py + g.pT - r * g.DH, g.SH)) continue;
+                for (int s = 0; s < g.KW; ++s) {
+                    if (pos_mod(px + g.pL - s * g.DW, g.SW)) continue;
+                    pk.tr[pk.ntaps] = (signed char)r; pk.ts[pk.ntaps] = (signed char)s;
+                    pk.ntaps++;
+                }
+            }
+            if (pk.ntaps == 0) continue;
+            pk.w = w; pk.out = dst; pk.KW = g.KW; pk.Cin = g.Cin; pk.Cout = g.Cout; pk.rows = g.Cin; pk.Cp = Cp; pk.mode = 1;
+            out[n++] = pk;
+            dst += align_up((size_t)g.Cin * pk.ntaps * Cp * es, 256);
+        }
+    return n;
+}
+
+extern "C" size_t mcn_conv2d_pack_table_bytes(const mcn_pack_job* jobs, int32_t njobs) {
+    size_t n = 0;
+    for (int i = 0; i < njobs; ++i) n += jobs[i].op == MCN_CONV_DGRAD ? (size_t)jobs[i].geom.SH * jobs[i].geom.SW : 1;
+    return n * sizeof(PackParams);
+}
+extern "C" int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njobs, mcn_dtype dtype, void* host_table, size_t bytes,
+                                           int32_t* ndesc) {
+    if (!jobs || !host_table || !ndesc || njobs < 0) MCN_FAIL(MCN_E_BADARG, "pack_table_build: bad argument");
+    if (bytes < mcn_conv2d_pack_table_bytes(jobs, njobs)) MCN_FAIL(MCN_E_WORKSPACE, "pack_table_build: table buffer too small");
+    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "pack_table_build: dtype %d unsupported", (int)dtype);
+    PackParams* out = (PackParams*)host_table;
+    int n = 0;
+    for (int i = 0; i < njobs; ++i) {
+        Geo g;
+        int rc = geo_from(&jobs[i].geom, &g);
+        if (rc) return rc;
+        if (!jobs[i].w_hwio || !jobs[i].packed) MCN_FAIL(MCN_E_BADARG, "pack_table_build: job %d has a null pointer", i);
+        n += pack_descs(g, dtype, (mcn_conv_op)jobs[i].op, jobs[i].w_hwio, jobs[i].packed, out + n);
+    }
+    *ndesc = n;
+    return MCN_OK;
+}
+extern "C" int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, void* stream) {
+    if (ndesc <= 0) return MCN_OK;
+    if (!dev_table) MCN_FAIL(MCN_E_BADARG, "pack_run: null table");
+    const dim3 grid(64, ndesc), block(256);
+    if (dtype == MCN_F32) hipLaunchKernelGGL((pack_weights_batch_kernel<float>), grid, block, 0, (hipStream_t)stream, (const PackParams*)dev_table);
+    else if (dtype == MCN_BF16) hipLaunchKernelGGL((pack_weights_batch_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const PackParams*)dev_table);
+    else MCN_FAIL(MCN_E_UNSUPPORTED, "pack_run: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// name of the GEMM kernel a conv call launches and how many times (profiling aid: matches rocprofv3's kernel names)
+extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype, char* buf, size_t buflen) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (!buf || buflen < 64) MCN_FAIL(MCN_E_BADARG, "kernel_name: buffer too small");
+    const char* tn = dtype == MCN_F32 ? "float" : "bf16";
+    const int ce = ce_of(dtype);
+    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    if (op == MCN_CONV_FWD) {
+        if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
+        const long M = (long)g.N * g.OH * g.OW;
+        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout) : pick_nt_tile<bf16_t>((int)M, g.Cout);
+        const int cpt = round_up(g.Cin, ce) / ce;
+        const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
+        return 1;
+    }
+    if (op == MCN_CONV_DGRAD) {
+        if (!mfma_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_dgrad<%s>", tn); return 1; }
+        int ncls = 0, nt0 = 0;
+        for (int py = 0; py < g.SH && py < g.H; ++py)
+            for (int px = 0; px < g.SW && px < g.W; ++px) {
+                int nt = 0;
+                for (int r = 0; r < g.KH; ++r)
+                    for (int s = 0; s < g.KW; ++s)
+                        if (!pos_mod(py + g.pT - r * g.DH, g.SH) && !pos_mod(px + g.pL - s * g.DW, g.SW)) nt++;
+                if (nt) { if (!ncls) nt0 = nt; ncls++; }
+            }
+        const int OHs = (g.H + g.SH - 1) / g.SH, OWs = (g.W + g.SW - 1) / g.SW;
+        const long M = (long)g.N * OHs * OWs;
+        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin) : pick_nt_tile<bf16_t>((int)M, g.Cin);
+        const int cpt = round_up(g.Cout, ce) / ce;
+        const bool lin = g.KH * g.KW == 1 && nt0 == 1;
+        const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
+        return ncls;
+    }
+    if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
+    int br, bn;
+    tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), &br, &bn);
+    snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s>", tn, br, bn, conv_is_linear(g) ? "true" : "false");
+    return 1;
+}
+
 // ---- fully connected = 1x1 convolution on a [B][1][1][In] tensor ------------------------------------------
 static mcn_conv_geom fc_geom(int B, int In, int Out) {
     mcn_conv_geom g;
@@ -502,13 +633,13 @@ extern "C" size_t mcn_fc_workspace_bytes(int32_t B, int32_t In, int32_t Out, mcn
 extern "C" int mcn_fc_fwd(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t In, int32_t Out, mcn_dtype dtype,
                           void* ws, size_t ws_bytes, void* stream) {
     const mcn_conv_geom g = fc_geom(B, In, Out);
-    return mcn_conv2d_fwd(x, w, bias, y, &g, dtype, MCN_NHWC, ws, ws_bytes, stream);
+    return mcn_conv2d_fwd(x, w, nullptr, bias, y, &g, dtype, MCN_NHWC, ws, ws_bytes, stream);
 }
 extern "C" int mcn_fc_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias, float grad_scale, int32_t B,
                           int32_t In, int32_t Out, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     const mcn_conv_geom g = fc_geom(B, In, Out);
     int rc = MCN_OK;
-    if (dx) rc = mcn_conv2d_dgrad(dy, w, dx, &g, 0, dtype, MCN_NHWC, ws, ws_bytes, stream);
+    if (dx) rc = mcn_conv2d_dgrad(dy, w, nullptr, dx, &g, 0, dtype, MCN_NHWC, ws, ws_bytes, stream);
     if (rc) return rc;
     if (dw) rc = mcn_conv2d_wgrad(x, dy, dw, dbias, &g, grad_scale, dtype, MCN_NHWC, ws, ws_bytes, stream);
     return rc;

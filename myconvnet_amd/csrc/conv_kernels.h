@@ -674,6 +674,27 @@ __global__ void pack_weights_kernel(const PackParams p) {
     }
 }
 
+// all packed operands of a model in ONE launch: blockIdx.y selects the descriptor (device table), blockIdx.x strides
+template <typename T>
+__global__ void pack_weights_batch_kernel(const PackParams* __restrict__ table) {
+    const PackParams& p = table[blockIdx.y];
+    const long total = (long)p.rows * p.ntaps * p.Cp;
+    T* out = reinterpret_cast<T*>(p.out);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % p.Cp);
+        const long rt = idx / p.Cp;
+        const int t = (int)(rt % p.ntaps), row = (int)(rt / p.ntaps);
+        const int r = p.tr[t], s = p.ts[t];
+        float v = 0.f;
+        if (p.mode == 0) {
+            if (col < p.Cin) v = p.w[(((long)r * p.KW + s) * p.Cin + col) * p.Cout + row];
+        } else {
+            if (col < p.Cout) v = p.w[(((long)r * p.KW + s) * p.Cin + row) * p.Cout + col];
+        }
+        out[idx] = from_f32<T>(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // naive fallbacks (any channel count; also an in-library cross-check of the MFMA path)
 // ------------------------------------------------------------------------------------------------

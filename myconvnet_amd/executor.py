@@ -21,6 +21,7 @@ class Lowering(object):
         self.loss_scale = float(loss_scale)
         self.fwd = Program()
         self.bwd = Program()
+        self.prepack = Program()       # one launch: cast / re-pack every conv weight from its fp32 master (or EMA shadow)
         self.ws = None
         self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
         self.written = set()           # tensor ids whose .grad already holds a contribution
@@ -82,6 +83,7 @@ class Lowering(object):
         ws_bytes = self.workspace_bytes()
         self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=self.g.device)
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel() * 4
+        self.plan_packed_weights()
         for n in self.g.nodes:
             getattr(self, 'fwd_' + n.op)(n)
         if self.train:
@@ -90,6 +92,45 @@ class Lowering(object):
                 if f is not None:
                     f(n)
         return self
+
+    def plan_packed_weights(self):
+        """One packed operand per (conv, op) kept across the step, refreshed by ONE batched launch (mcn_conv2d_pack_run)
+        instead of a pack kernel in front of every conv launch: the reference's per-use cast of the fp32 master
+        (convnet.py:1421-1422) happens once per step here.  The buffers are shared by the train and eval lowerings
+        (each runs its own table — masters vs EMA shadows — before its forward pass)."""
+        jobs, offs, total = [], {}, 0
+        for n in self.g.nodes:
+            if n.op != 'conv':
+                continue
+            gm = n.attrs['geom']
+            for op in ((_ffi.CONV_FWD, _ffi.CONV_DGRAD) if (self.train and n.inputs[0].needs_grad) else (_ffi.CONV_FWD,)):
+                nb = int(lib.mcn_conv2d_packed_bytes(op, ctypes.byref(gm), self.dt))
+                if nb:
+                    offs[(id(n), op)] = total
+                    total += (nb + 255) // 256 * 256
+        shared = getattr(self.model, '_packed_store', None)
+        if shared is None or shared.numel() < total:
+            shared = torch.zeros(max(total, 256), dtype=torch.uint8, device=self.g.device)
+            self.model._packed_store = shared
+        self.packed_ptr = {k: shared.data_ptr() + o for k, o in offs.items()}
+        for n in self.g.nodes:
+            if n.op != 'conv':
+                continue
+            for op in (_ffi.CONV_FWD, _ffi.CONV_DGRAD):
+                if (id(n), op) in self.packed_ptr:
+                    jobs.append(_ffi.PackJob(self.vptr(n.attrs['w']), self.packed_ptr[(id(n), op)], n.attrs['geom'], op, 0))
+        if not jobs:
+            return
+        arr = (_ffi.PackJob * len(jobs))(*jobs)
+        nbytes = int(lib.mcn_conv2d_pack_table_bytes(arr, len(jobs)))
+        host = (ctypes.c_char * nbytes)()
+        ndesc = ctypes.c_int32(0)
+        _ffi.check(lib.mcn_conv2d_pack_table_build(arr, len(jobs), self.dt, ctypes.cast(host, ctypes.c_void_p), nbytes, ctypes.byref(ndesc)))
+        self.pack_table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.g.device)
+        self.prepack.add(lib.mcn_conv2d_pack_run, self.pack_table.data_ptr(), ndesc.value, self.dt)
+
+    def wp(self, n, op):
+        return self.packed_ptr.get((id(n), op), 0)
 
     # ---- input / labels ---------------------------------------------------------------------------------
     def fwd_input(self, n):
@@ -109,7 +150,7 @@ class Lowering(object):
         x, y = n.inputs[0], n.outputs[0]
         gm = n.attrs['geom']
         self.keep.append(gm)
-        self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
+        self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
                      ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
 
     def bwd_conv(self, n):
@@ -122,7 +163,7 @@ class Lowering(object):
                          b.grad.data_ptr() if b is not None else 0, ctypes.byref(gm), gs, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
             self.bwd.mark(('grad_ready', tuple(v.name for v in (w, b) if v is not None)))
         if x.needs_grad:
-            self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), dst,
+            self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), dst,
                                                              ctypes.byref(gm), acc, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes))
 
     # ---- batch norm --------------------------------------------------------------------------------------------

@@ -45,7 +45,24 @@ def workspace(nbytes):
     return torch.zeros(max(int(nbytes), 256) // 4 + 64, dtype=torch.float32, device=DEV)
 
 
-def conv_fwd(x, w, stride, padding, dilation=1, dtype='float32', bias=None, x_cs=0):
+def prepack(w, g, op, dtype):
+    """Packed operand through the batch API (one job); returns the device tensor or None when the op takes none."""
+    nb = int(lib.mcn_conv2d_packed_bytes(op, ctypes.byref(g), MDT[dtype]))
+    if nb == 0:
+        return None, None
+    wd = dev(w)
+    buf = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    job = (_ffi.PackJob * 1)(_ffi.PackJob(wd.data_ptr(), buf.data_ptr(), g, op, 0))
+    tb = int(lib.mcn_conv2d_pack_table_bytes(job, 1))
+    host = (ctypes.c_char * tb)()
+    nd = ctypes.c_int32(0)
+    _ffi.check(lib.mcn_conv2d_pack_table_build(job, 1, MDT[dtype], ctypes.cast(host, ctypes.c_void_p), tb, ctypes.byref(nd)))
+    table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(DEV)
+    _ffi.check(lib.mcn_conv2d_pack_run(table.data_ptr(), nd.value, MDT[dtype], stream()))
+    return buf, (wd, table)
+
+
+def conv_fwd(x, w, stride, padding, dilation=1, dtype='float32', bias=None, x_cs=0, use_prepack=False):
     g = geom(x.shape[:3] + (w.shape[2],), w.shape, stride, padding, dilation, x_cs)
     oh = O.out_size(x.shape[1], w.shape[0], O._pair(stride)[0], padding, O._pair(dilation)[0])
     ow = O.out_size(x.shape[2], w.shape[1], O._pair(stride)[1], padding, O._pair(dilation)[1])
@@ -53,12 +70,14 @@ def conv_fwd(x, w, stride, padding, dilation=1, dtype='float32', bias=None, x_cs
     bd = dev(bias) if bias is not None else None
     y = torch.full((x.shape[0], oh, ow, w.shape[3]), float('nan'), dtype=TDT[dtype], device=DEV)
     ws = workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), MDT[dtype]))
-    _ffi.check(lib.mcn_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if bd is not None else 0, y.data_ptr(), ctypes.byref(g),
+    pk, keep = prepack(w, g, _ffi.CONV_FWD, dtype) if use_prepack else (None, None)
+    packed = pk.data_ptr() if pk is not None else 0
+    _ffi.check(lib.mcn_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), packed, bd.data_ptr() if bd is not None else 0, y.data_ptr(), ctypes.byref(g),
                                   MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, stream()))
     return host(y)
 
 
-def conv_dgrad(dy, w, x_shape, stride, padding, dilation=1, dtype='float32', accumulate_into=None):
+def conv_dgrad(dy, w, x_shape, stride, padding, dilation=1, dtype='float32', accumulate_into=None, use_prepack=False):
     g = geom(x_shape, w.shape, stride, padding, dilation)
     dyd, wd = dev(dy, dtype), dev(w)
     if accumulate_into is not None:
@@ -66,7 +85,8 @@ def conv_dgrad(dy, w, x_shape, stride, padding, dilation=1, dtype='float32', acc
     else:
         dx = torch.full(tuple(x_shape), float('nan'), dtype=TDT[dtype], device=DEV)
     ws = workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), MDT[dtype]))
-    _ffi.check(lib.mcn_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), ctypes.byref(g), 1 if accumulate_into is not None else 0,
+    pk, keep = prepack(w, g, _ffi.CONV_DGRAD, dtype) if use_prepack else (None, None)
+    _ffi.check(lib.mcn_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), pk.data_ptr() if pk is not None else 0, dx.data_ptr(), ctypes.byref(g), 1 if accumulate_into is not None else 0,
                                     MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, stream()))
     return host(dx)
 

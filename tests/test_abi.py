@@ -39,14 +39,20 @@ def test_argument_validation_without_gpu():
     from myconvnet_amd import _ffi
     lib = _ffi.lib
     g = _ffi.conv_geom(1, 8, 8, 0, 16, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))       # Cin = 0
-    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
     assert 'bad geometry' in _ffi.last_error()
     g = _ffi.conv_geom(1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))
-    assert lib.mcn_conv2d_fwd(0, 0, 0, 0, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
-    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NCHW, 0, 0, 0) == _ffi.E_UNSUPPORTED
-    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F16, _ffi.NHWC, 0, 0, 0) == _ffi.E_UNSUPPORTED
+    assert lib.mcn_conv2d_fwd(0, 0, 0, 0, 0, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NCHW, 0, 0, 0) == _ffi.E_UNSUPPORTED
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F16, _ffi.NHWC, 0, 0, 0) == _ffi.E_UNSUPPORTED
     assert 'fp16' in _ffi.last_error()
-    assert lib.mcn_conv2d_fwd(1, 1, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_WORKSPACE
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_WORKSPACE
+    assert lib.mcn_conv2d_packed_bytes(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) >= 16 * 9 * 16 * 4
+    buf = ctypes.create_string_buffer(96)
+    assert lib.mcn_conv2d_kernel_name(_ffi.CONV_FWD, ctypes.byref(g), _ffi.BF16, buf, 96) == 1 and buf.value.startswith(b'conv_gemm_nt<bf16')
+    g2 = _ffi.conv_geom(4, 16, 16, 16, 16, 3, 3, 2, 2, 1, 1, (0, 1, 0, 1))
+    assert lib.mcn_conv2d_kernel_name(_ffi.CONV_DGRAD, ctypes.byref(g2), _ffi.F32, buf, 96) == 4        # one launch per stride-parity class
+    assert lib.mcn_conv2d_kernel_name(_ffi.CONV_WGRAD, ctypes.byref(g2), _ffi.F32, buf, 96) == 1 and buf.value.startswith(b'conv_gemm_tn<float')
     assert lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) >= 16 * 9 * 16 * 4
     assert lib.mcn_bn_fwd_train(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.9, 10, 4, 1e-3, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
     assert lib.mcn_bn_workspace_bytes(1000, 64) > 0

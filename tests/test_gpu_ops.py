@@ -78,6 +78,20 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_CASES[7], CONV_CASES[10]])
+def test_conv_prepacked_operands_equal_per_call_packing(case, dtype):
+    """Weights packed once by the batched launch (mcn_conv2d_pack_*) give bit-identical convolutions."""
+    u = _u()
+    n, h, w_, cin, cout, k, s, pad, dil = case
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    w = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    y0 = u.conv_fwd(x, w, s, pad, dil, dtype)
+    np.testing.assert_array_equal(u.conv_fwd(x, w, s, pad, dil, dtype, use_prepack=True), y0)
+    dy = RNG.standard_normal(y0.shape).astype(np.float32)
+    np.testing.assert_array_equal(u.conv_dgrad(dy, w, x.shape, s, pad, dil, dtype, use_prepack=True), u.conv_dgrad(dy, w, x.shape, s, pad, dil, dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_conv_stem_padded_channels(dtype):
     """Stem: 7x7/2 on 3 channels stored with a channel stride of one 16-byte chunk (pads (2,3))."""
     u = _u()
