@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
+    ap.add_argument('--no-autotune', action='store_true', help='keep the library tile heuristics (no per-layer timing at start-up)')
     ap.add_argument('--layers', action='store_true', help='print a per-launch table (stderr) from the instrumented pass')
     return ap.parse_args()
 
@@ -67,8 +68,11 @@ def run_steps(opt, n):
         opt.curr_step += 1
 
 
-def timed(opt, steps, warmup, world):
+def timed(opt, steps, warmup, world, autotune=True):
     import torch.distributed as dist
+    if autotune:                                       # untimed start-up: two steps to fill the buffers, then time the tile candidates
+        run_steps(opt, 2)
+        opt.model.autotune()
     run_steps(opt, warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -198,7 +202,7 @@ def main():
         init_process_group('cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
 
     model, opt = build_model(args, args.dtype, world)
-    dt = timed(opt, args.steps, args.warmup, world)
+    dt = timed(opt, args.steps, args.warmup, world, not args.no_autotune)
     ms = dt / args.steps * 1e3
     ips = args.batch * world * args.steps / dt
     out = {
@@ -235,7 +239,7 @@ def main():
             import argparse as _a
             a2 = _a.Namespace(**vars(args))
             m2, o2 = build_model(a2, 'bf16', 1)
-            dt2 = timed(o2, args.steps, args.warmup, 1)
+            dt2 = timed(o2, args.steps, args.warmup, 1, not args.no_autotune)
             ips2 = args.batch * args.steps / dt2
             out['bf16'] = {'value': round(ips2, 2), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
                            'e2e_mfma_frac': round(ips2 * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS['bf16'] * 1e12), 4)}

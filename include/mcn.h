@@ -54,10 +54,14 @@ typedef struct {
     int32_t KH, KW, SH, SW, DH, DW;
     int32_t padT, padB, padL, padR;
     int32_t x_cs; /* channel stride of x (0 => Cin).  Channels >= Cin must be finite (they meet zero weights) */
+    int32_t tile; /* 0 = library heuristic; k > 0 = force tile candidate k-1 of this op (1..mcn_conv2d_tile_candidates);
+                     results are identical up to fp32 summation order — used by callers that time the candidates */
 } mcn_conv_geom;
 
 typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_conv_op;
 
+/* number of tile shapes the given op can be forced to through mcn_conv_geom.tile (0: op takes no hint) */
+int mcn_conv2d_tile_candidates(mcn_conv_op op);
 /* bytes of workspace the given op needs for this geometry/dtype (0 is a valid answer) */
 size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
 

@@ -28,7 +28,7 @@ class McnError(RuntimeError):
 
 class ConvGeom(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW', 'DH', 'DW',
-                                       'padT', 'padB', 'padL', 'padR', 'x_cs')]
+                                       'padT', 'padB', 'padL', 'padR', 'x_cs', 'tile')]
 
 
 class PackJob(ctypes.Structure):
@@ -39,6 +39,7 @@ class PackJob(ctypes.Structure):
 SIGNATURES = {
     'mcn_version': (c_int, []),
     'mcn_last_error': (c_char_p, []),
+    'mcn_conv2d_tile_candidates': (c_int, [c_int]),
     'mcn_conv2d_workspace_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
     'mcn_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -102,6 +103,6 @@ def check(rc):
         raise McnError(rc, last_error())
 
 
-def conv_geom(N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pads, x_cs=0):
+def conv_geom(N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pads, x_cs=0, tile=0):
     pt, pb, pl, pr = pads
-    return ConvGeom(N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pt, pb, pl, pr, x_cs)
+    return ConvGeom(N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pt, pb, pl, pr, x_cs, tile)

@@ -28,7 +28,7 @@ static bool force_naive() {
 
 // ---- geometry helpers ----------------------------------------------------------------------------
 struct Geo {
-    int N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pT, pB, pL, pR, xcs, OH, OW;
+    int N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pT, pB, pL, pR, xcs, OH, OW, tile;
 };
 static int geo_from(const mcn_conv_geom* g, Geo* o) {
     if (!g) MCN_FAIL(MCN_E_BADARG, "conv: null geometry");
@@ -36,6 +36,7 @@ static int geo_from(const mcn_conv_geom* g, Geo* o) {
     o->KH = g->KH; o->KW = g->KW; o->SH = g->SH; o->SW = g->SW; o->DH = g->DH; o->DW = g->DW;
     o->pT = g->padT; o->pB = g->padB; o->pL = g->padL; o->pR = g->padR;
     o->xcs = g->x_cs > 0 ? g->x_cs : g->Cin;
+    o->tile = g->tile;
     if (o->N < 0 || o->H <= 0 || o->W <= 0 || o->Cin <= 0 || o->Cout <= 0 || o->KH <= 0 || o->KW <= 0 || o->SH <= 0 ||
         o->SW <= 0 || o->DH <= 0 || o->DW <= 0 || o->pT < 0 || o->pB < 0 || o->pL < 0 || o->pR < 0 || o->xcs < o->Cin)
         MCN_FAIL(MCN_E_BADARG, "conv: bad geometry N=%d H=%d W=%d Cin=%d Cout=%d K=%dx%d S=%dx%d D=%dx%d x_cs=%d", o->N, o->H,
@@ -78,7 +79,9 @@ static size_t dgrad_pack_bytes(const Geo& g, mcn_dtype dt) {
 // 128-row tiles unless the operand has no more than 64 rows / columns (1x1 convs on 64 channels)
 // (per-layer A/B on MI355X: fp32 1x1/stride-1 wgrads gain 5-55 % from 64x64 tiles, the gathered (3x3 / strided) ones lose
 // 8-25 % because the per-K-step pixel bookkeeping is amortised over fewer MFMAs)
-static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int* br, int* bn) {
+static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int forced, int* br, int* bn) {
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    if (forced >= 1 && forced <= 4) { *br = cand[forced - 1][0]; *bn = cand[forced - 1][1]; return; }
     if (dt == MCN_F32 && linear) { *br = 64; *bn = 64; return; }
     *br = rows <= 64 ? 64 : 128;
     *bn = Cout <= 64 ? 64 : 128;
@@ -92,7 +95,7 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
     const int nsteps = (int)((M + KP - 1) / KP);
     const int rows = g.KH * g.KW * round_up(g.Cin, ce_of(dt));
     int BR, BN;
-    tn_tile(rows, g.Cout, dt, conv_is_linear(g), &BR, &BN);
+    tn_tile(rows, g.Cout, dt, conv_is_linear(g), g.tile, &BR, &BN);
     const int tiles = ((rows + BR - 1) / BR) * ((g.Cout + BN - 1) / BN);
     int splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU in total
     if (splits > nsteps) splits = nsteps;
@@ -122,6 +125,8 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     b += align_up(colsum_parts((long)g.N * g.OH * g.OW) * g.Cout * 4, 256);
     return b;
 }
+
+extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 3; }
 
 extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
@@ -158,7 +163,8 @@ static inline double nt_tile_work(int c, size_t es) {
     return w[c] * (es == 4 ? f32[c] : bf16[c]);
 }
 template <typename T>
-static int pick_nt_tile(int M, int Nn) {
+static int pick_nt_tile(int M, int Nn, int hint = 0) {
+    if (hint >= 1 && hint <= 3) return hint - 1;
     static const int forced = [] { const char* e = getenv("MCN_NT_TILE"); return e ? atoi(e) : -1; }();
     const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
     int best = Nn <= 64 ? 1 : 0;
@@ -206,15 +212,15 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
 }
 
 template <typename T>
-static int launch_nt(const GemmNTParams& p, bool taps, hipStream_t st) {
+static int launch_nt(const GemmNTParams& p, bool taps, int tile_hint, hipStream_t st) {
     if (p.M <= 0 || p.Nn <= 0) return MCN_OK;
-    return launch_nt_range<T>(p, pick_nt_tile<T>(p.M, p.Nn), 0, p.M, taps, st);
+    return launch_nt_range<T>(p, pick_nt_tile<T>(p.M, p.Nn, tile_hint), 0, p.M, taps, st);
 }
 
 template <typename T>
-static int launch_tn(const GemmTNParams& p, bool linear, int splits, hipStream_t st) {
+static int launch_tn(const GemmTNParams& p, bool linear, int splits, int forced_tile, hipStream_t st) {
     int BR, BN;
-    tn_tile(p.rows, p.Nn, sizeof(T) == 4 ? MCN_F32 : MCN_BF16, linear, &BR, &BN);
+    tn_tile(p.rows, p.Nn, sizeof(T) == 4 ? MCN_F32 : MCN_BF16, linear, forced_tile, &BR, &BN);
     const int tiles = ((p.rows + BR - 1) / BR) * ((p.Nn + BN - 1) / BN);
     const dim3 grid(tiles, splits), block(256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
@@ -304,7 +310,7 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
     p.in_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(T));
     p.wt_bytes = (unsigned)((size_t)g.Cout * ntaps * Cp * sizeof(T));
     const bool linear = ntaps == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
-    return launch_nt<T>(p, !linear, st);
+    return launch_nt<T>(p, !linear, g.tile, st);
 }
 
 extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const mcn_conv_geom* gg,
@@ -395,7 +401,7 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         p.in_bytes = (unsigned)((size_t)g.N * g.OH * g.OW * g.Cout * sizeof(T));
         p.wt_bytes = (unsigned)((size_t)g.Cin * c.nt * Cp * sizeof(T));
         const bool linear = c.nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
-        rc = launch_nt<T>(p, !linear, st);
+        rc = launch_nt<T>(p, !linear, g.tile, st);
         if (rc) return rc;
         wsp += align_up((size_t)g.Cin * c.nt * Cp * sizeof(T), 256);
     }
@@ -460,7 +466,7 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         p.dy_bytes = (unsigned)((size_t)M * g.Cout * sizeof(T));
         const bool linear = conv_is_linear(g);
         if (M > 0) {
-            int rc = launch_tn<T>(p, linear, splits, st);
+            int rc = launch_tn<T>(p, linear, splits, g.tile, st);
             if (rc) return rc;
         }
         const long total = (long)ntaps * g.Cin * g.Cout;
@@ -582,7 +588,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (op == MCN_CONV_FWD) {
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
         const long M = (long)g.N * g.OH * g.OW;
-        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout) : pick_nt_tile<bf16_t>((int)M, g.Cout);
+        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
         snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
@@ -601,7 +607,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
             }
         const int OHs = (g.H + g.SH - 1) / g.SH, OWs = (g.W + g.SW - 1) / g.SW;
         const long M = (long)g.N * OHs * OWs;
-        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin) : pick_nt_tile<bf16_t>((int)M, g.Cin);
+        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
@@ -610,7 +616,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
-    tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), &br, &bn);
+    tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
     snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s>", tn, br, bn, conv_is_linear(g) ? "true" : "false");
     return 1;
 }

@@ -62,9 +62,10 @@ def plan_buckets(variables, ready_index, bucket_bytes):
 class GradientReducer(object):
     """Bucketed, overlapped all-reduce of a flat gradient tensor."""
 
-    def __init__(self, flat_grad, variables, ready_index, bucket_mb=25.0, group=None):
+    def __init__(self, flat_grad, variables, ready_index, bucket_mb=25.0, group=None, side_stream=None):
         self.flat = flat_grad
         self.group = group
+        self.side_stream = side_stream    # the stream the wgrad kernels run on (None: everything is on the current stream)
         self.plan = plan_buckets(variables, ready_index, int(bucket_mb * 1024 * 1024))
         self.works = []
         self._hooks = {}
@@ -74,6 +75,16 @@ class GradientReducer(object):
     def hooks(self):
         def make(spans):
             def fire():
+                if self.side_stream is not None:
+                    # the bucket's gradients come from both streams (wgrad: side, BN / fc: main): order the collective
+                    # after both without stalling the main stream's backward chain
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    self.side_stream.wait_event(ev)
+                    with torch.cuda.stream(self.side_stream):
+                        for s, e in spans:
+                            self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    return
                 for s, e in spans:
                     self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return fire
@@ -104,7 +115,7 @@ class DataParallel(object):
         variables = [(v.name, v.offset, (v.size + 3) // 4 * 4) for v in st.variables]
         missing = [v[0] for v in variables if v[0] not in ready]
         assert not missing, 'no backward completion point for {}'.format(missing[:3])
-        self.reducer = GradientReducer(st.grad, variables, ready, bucket_mb)
+        self.reducer = GradientReducer(st.grad, variables, ready, bucket_mb, side_stream=model._train_low.bwd.side_stream)
         assert self.reducer.covered_elements() == st.size
         self.gathered_stats = torch.zeros((self.world, model.batch_stats.numel()), dtype=torch.float32, device=model.device)
         self._loss_tmp = torch.zeros(1, dtype=torch.float32, device=model.device)

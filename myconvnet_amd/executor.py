@@ -39,9 +39,13 @@ class Lowering(object):
         need = 4096
         for n in self.g.nodes:
             if n.op == 'conv':
-                gm = n.attrs['geom']
                 for op in (_ffi.CONV_FWD, _ffi.CONV_DGRAD, _ffi.CONV_WGRAD):
-                    need = max(need, lib.mcn_conv2d_workspace_bytes(op, ctypes.byref(gm), self.dt))
+                    gm = self.op_geom(n, op)
+                    keep = gm.tile
+                    for t in range(lib.mcn_conv2d_tile_candidates(op) + 1):       # any tile the autotuner may pick
+                        gm.tile = t
+                        need = max(need, lib.mcn_conv2d_workspace_bytes(op, ctypes.byref(gm), self.dt))
+                    gm.tile = keep
             elif n.op == 'bn':
                 x = n.inputs[0]
                 need = max(need, lib.mcn_bn_workspace_bytes(x.numel // x.shape[-1], x.shape[-1]))
@@ -49,6 +53,17 @@ class Lowering(object):
                 x = n.inputs[0]
                 need = max(need, lib.mcn_fc_workspace_bytes(x.shape[0], x.shape[1], n.outputs[0].shape[1], self.dt))
         return int(need)
+
+    def op_geom(self, n, op):
+        """Each of fwd / dgrad / wgrad owns a copy of the node's geometry: the tile hint is tuned per op."""
+        key = 'geom_op'
+        if key not in n.attrs:
+            n.attrs[key] = {}
+        d = n.attrs[key]
+        if op not in d:
+            src = n.attrs['geom']
+            d[op] = _ffi.ConvGeom(*[getattr(src, f) for f, _ in _ffi.ConvGeom._fields_])
+        return d[op]
 
     def scratch_like(self, t, key):
         k = (key, t.shape, t.dtype)
@@ -83,6 +98,13 @@ class Lowering(object):
         ws_bytes = self.workspace_bytes()
         self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=self.g.device)
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel() * 4
+        # wgrad runs on a side stream (own workspace): it is MFMA-bound and independent of the dgrad -> BN-backward chain,
+        # whose BN kernels are HBM-bound, so the two overlap on the chip; the optimizer joins the side stream
+        self.overlap_wgrad = self.train and bool(self.model._parameters.get('overlap_wgrad', True)) and self.g.device.type == 'cuda'
+        if self.overlap_wgrad:
+            self.ws2 = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=self.g.device)
+            import os
+            self.bwd.side_stream = torch.cuda.Stream(device=self.g.device, priority=int(os.environ.get('MCN_SIDE_PRIO', '0')))
         self.plan_packed_weights()
         for n in self.g.nodes:
             getattr(self, 'fwd_' + n.op)(n)
@@ -132,6 +154,39 @@ class Lowering(object):
     def wp(self, n, op):
         return self.packed_ptr.get((id(n), op), 0)
 
+    def autotune(self, reps=3):
+        """Measure, don't guess: time every tile candidate of every conv launch of this lowering on the GPU (HIP events
+        on the launch stream, data already in the buffers) and pin the fastest through mcn_conv_geom.tile.  The result
+        of a conv does not depend on the tile except for the fp32 summation order of the split wgrad."""
+        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+        sp = torch.cuda.current_stream(self.g.device).cuda_stream
+        self.prepack.run(sp)
+        chosen = {}
+        for fn, args in self.fwd.calls + self.bwd.calls:
+            op = names.get(getattr(fn, '__name__', ''))
+            if op is None:
+                continue
+            gm = [a for a in args if hasattr(a, '_obj')][0]._obj
+            if id(gm) in chosen:
+                continue
+            args[-1] = sp
+            best, best_t = 0, None
+            for cand in range(lib.mcn_conv2d_tile_candidates(op) + 1):
+                gm.tile = cand
+                _ffi.check(fn(*args))                       # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    _ffi.check(fn(*args))
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if best_t is None or t < best_t * 0.985:    # keep the heuristic unless a candidate is clearly faster
+                    best, best_t = cand, t
+            gm.tile = best
+            chosen[id(gm)] = best
+        return chosen
+
     # ---- input / labels ---------------------------------------------------------------------------------
     def fwd_input(self, n):
         y = n.outputs[0]
@@ -148,19 +203,25 @@ class Lowering(object):
     # ---- conv -----------------------------------------------------------------------------------------------
     def fwd_conv(self, n):
         x, y = n.inputs[0], n.outputs[0]
-        gm = n.attrs['geom']
+        gm = self.op_geom(n, _ffi.CONV_FWD)
         self.keep.append(gm)
         self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
                      ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
 
     def bwd_conv(self, n):
         x, y = n.inputs[0], n.outputs[0]
-        gm = n.attrs['geom']
+        gm = self.op_geom(n, _ffi.CONV_DGRAD)
+        gw = self.op_geom(n, _ffi.CONV_WGRAD)
         w, b = n.attrs['w'], n.attrs.get('b')
         gs = 1.0 / self.loss_scale
         if w.trainable:
-            self.bwd.add(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(),
-                         b.grad.data_ptr() if b is not None else 0, ctypes.byref(gm), gs, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+            if self.overlap_wgrad:
+                self.bwd.add_side(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(),
+                                  b.grad.data_ptr() if b is not None else 0, ctypes.byref(gw), gs, self.dt, _ffi.NHWC, self.ws2.data_ptr(),
+                                  self.ws2.numel() * 4)
+            else:
+                self.bwd.add(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(),
+                             b.grad.data_ptr() if b is not None else 0, ctypes.byref(gw), gs, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
             self.bwd.mark(('grad_ready', tuple(v.name for v in (w, b) if v is not None)))
         if x.needs_grad:
             self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), dst,

@@ -131,13 +131,22 @@ class Node(object):
 
 
 class Program(object):
-    """A flat list of (fn, args) C-ABI launches; args[-1] is the stream slot."""
+    """A flat list of (fn, args) C-ABI launches; args[-1] is the stream slot.  Calls added with add_side() go to a second
+    HIP stream: each waits (event) for everything enqueued on the main stream before it and the main stream joins the
+    side stream at the end of run() — used to run the MFMA-bound wgrad kernels beside the HBM-bound BN-backward chain."""
 
     def __init__(self):
         self.calls = []
         self.marks = {}               # label -> index (used to place all-reduce hooks)
+        self.side = {}                # call index -> torch.cuda.Event (lazily created)
+        self.side_stream = None
+        self._join = None
 
     def add(self, fn, *args):
+        self.calls.append((fn, list(args) + [None]))
+
+    def add_side(self, fn, *args):
+        self.side[len(self.calls)] = None
         self.calls.append((fn, list(args) + [None]))
 
     def mark(self, label):
@@ -145,24 +154,42 @@ class Program(object):
 
     def run(self, stream_ptr, hooks=None):
         check = _ffi.check
-        if hooks:
-            for i, (fn, args) in enumerate(self.calls):
-                h = hooks.get(i)
-                if h is not None:
-                    h()
+        side = self.side if (self.side and self.side_stream is not None) else None
+        if side is None and not hooks:
+            for fn, args in self.calls:
                 args[-1] = stream_ptr
                 rc = fn(*args)
                 if rc:
                     check(rc)
-            h = hooks.get(len(self.calls))
-            if h is not None:
-                h()
             return
-        for fn, args in self.calls:
-            args[-1] = stream_ptr
+        main = torch.cuda.current_stream() if side is not None else None
+        side_ptr = self.side_stream.cuda_stream if side is not None else 0
+        for i, (fn, args) in enumerate(self.calls):
+            if hooks:
+                h = hooks.get(i)
+                if h is not None:
+                    h()
+            if side is not None and i in side:
+                ev = side[i]
+                if ev is None:
+                    ev = side[i] = torch.cuda.Event()
+                ev.record(main)
+                self.side_stream.wait_event(ev)
+                args[-1] = side_ptr
+            else:
+                args[-1] = stream_ptr
             rc = fn(*args)
             if rc:
                 check(rc)
+        if hooks:
+            h = hooks.get(len(self.calls))
+            if h is not None:
+                h()
+        if side is not None:
+            if self._join is None:
+                self._join = torch.cuda.Event()
+            self._join.record(self.side_stream)
+            main.wait_event(self._join)
 
     def __len__(self):
         return len(self.calls)
