@@ -39,7 +39,12 @@ typedef enum { MCN_NHWC = 0, MCN_NCHW = 1 } mcn_layout;
 typedef enum { MCN_OK = 0, MCN_E_BADARG = -1, MCN_E_UNSUPPORTED = -2, MCN_E_LAUNCH = -3, MCN_E_WORKSPACE = -4 } mcn_status;
 
 /* activation fused into a producer kernel */
-typedef enum { MCN_ACT_NONE = 0, MCN_ACT_RELU = 1 } mcn_act;
+typedef enum {
+    MCN_ACT_NONE = 0,
+    MCN_ACT_RELU = 1,
+    MCN_ACT_SWISH = 2,  /* x*sigmoid(x), convnet.py:2553-2556 */
+    MCN_ACT_SIGMOID = 3 /* convnet.py:2550; element-wise entry points only */
+} mcn_act;
 
 int mcn_version(void);
 const char* mcn_last_error(void);
@@ -135,12 +140,34 @@ int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const
  *   y != NULL : mask from the stored forward output (required when the forward fused a residual `skip`);
  *   y == NULL : mask recomputed from x as [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0], the expression the
  *               forward apply pass evaluated (saves one read of y per pass; forward without `skip` only).
+ * If act == SWISH (EfficientNet, models/efficientnet.py:66,142,150) z = bn(x) is recomputed the same way and
+ *   dz = dy * (s + z*s*(1-s)), s = sigmoid(z); no fused residual (dskip must be NULL), y is ignored.
  * dskip (may be NULL): receives the masked dy, i.e. the gradient of the residual branch.
  * dgamma/dbeta fp32 [C], multiplied by grad_scale. */
 int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta,
                float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
                size_t workspace_bytes, void* stream);
+
+/* ---- depthwise convolution ---------------------------------------------------
+ * replaces tf.nn.depthwise_conv2d (convnet.py:1645) with channel multiplier 1 (every EfficientNet call site,
+ * models/efficientnet.py:145) and its two gradients.  geom: Cin == Cout == C (multiple of the 16-byte chunk);
+ * w / dw: fp32 [KH][KW][C] (the reference's [kh,kw,cin,1] filter, rounded per use in bf16 mode, convnet.py:1421);
+ * x, y and their gradients NHWC in `dtype`.  HBM-bound: one pass over x and y.
+ * dgrad: accumulate != 0 adds into dx.  wgrad: deterministic two-stage reduction through `workspace`. */
+int mcn_dwconv2d_fwd(const void* x, const float* w, void* y, const mcn_conv_geom* geom, mcn_dtype dtype, void* stream);
+int mcn_dwconv2d_dgrad(const void* dy, const float* w, void* dx, const mcn_conv_geom* geom, int32_t accumulate,
+                       mcn_dtype dtype, void* stream);
+size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom* geom, mcn_dtype dtype);
+int mcn_dwconv2d_wgrad(const void* x, const void* dy, float* dw, const mcn_conv_geom* geom, float grad_scale,
+                       mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* squeeze-excite scale (models/efficientnet.py:161 `x = x*se_mask`): y[n,h,w,c] = x[n,h,w,c] * m[n,c];
+ * backward: dx = dy * m, dm[n,c] = sum_hw dy * x.  x/y/m in `dtype`, HW = H*W. */
+int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype,
+                          void* stream);
+int mcn_channel_scale_bwd(const void* dy, const void* x, const void* m, void* dx, void* dm, int32_t N, int64_t HW,
+                          int32_t C, mcn_dtype dtype, void* stream);
 
 /* per-channel affine y[m][c] = x[m][c]*scale[c] + shift[c] over [M][C] (the VGG input re-scaling,
  * reference models/vggnet.py:25; also the apply pass of batch norm). scale/shift fp32 [C]. */
@@ -154,6 +181,12 @@ int mcn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_dtype d
 int mcn_add_relu_fwd(const void* a, const void* b, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream);
 /* dx = dy * [y > 0] (written once; both branches of the add read it) */
 int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* stream);
+/* element-wise swish / sigmoid / relu on small tensors (the squeeze-excite branch, models/efficientnet.py:186-195;
+ * tf.nn.sigmoid convnet.py:2550, swish convnet.py:2553-2556).  Backward: relu and sigmoid differentiate through the
+ * stored output y (x may be NULL), swish through its input x (y may be NULL). */
+int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream);
+int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype,
+                void* stream);
 /* a += b (gradient accumulation at fan-out points) */
 int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void* stream);
 /* dtype conversion (tf.cast, convnet.py:469-471, 477-480) */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libmcn_hip.so')
 
 F32, BF16, F16 = 0, 1, 2
 NHWC, NCHW = 0, 1
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 OK, E_BADARG, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -54,6 +54,14 @@ SIGNATURES = {
     'mcn_bn_fwd_infer': (c_int, [c_void_p] * 7 + [c_int64, c_int32, c_float, c_int, c_int, c_void_p]),
     'mcn_bn_bwd': (c_int, [c_void_p] * 11 + [c_float, c_int64, c_int32, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_channel_affine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    'mcn_dwconv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_void_p]),
+    'mcn_dwconv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int32, c_int, c_void_p]),
+    'mcn_dwconv2d_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom), c_int]),
+    'mcn_dwconv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_channel_scale_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
+    'mcn_channel_scale_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
+    'mcn_act_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mcn_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'mcn_relu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'mcn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'mcn_add_relu_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_kernel(
     shift[c] = bt - fmean * sc;
 }
 
-// y = act(x*scale + shift [+ skip])
-template <typename T, int VEC, bool SKIP, bool RELU>
+// y = act(x*scale + shift [+ skip]); ACT: 0 none, 1 relu, 2 swish
+template <typename T, int VEC, bool SKIP, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, long M, int C,
                                                        int TX, int TY, long rpb) {
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         for (int i = 0; i < VEC; ++i) {
             float o = fmaf(v[i], sc[i], sh[i]);
             if (SKIP) o += s[i];
-            if (RELU) o = fmaxf(o, 0.f);
+            if (ACT == 1) o = fmaxf(o, 0.f);
+            if (ACT == 2) o = o / (1.f + expf(-o));          // swish = z*sigmoid(z) (convnet.py:2553)
             v[i] = o;
         }
         stv<T, VEC>(y + off, v);
@@ -220,10 +221,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---- backward --------------------------------------------------------------------------------------
+__device__ __forceinline__ float swish_grad(float z) {
+    const float sg = 1.f / (1.f + expf(-z));
+    return sg * (1.f + z * (1.f - sg));
+}
 // part[(rb*2+0)*C + c] = sum dy', part[(rb*2+1)*C + c] = sum dy' * xhat   (dy' = dy*[y>0] if RELU)
 // RELU: 0 = no activation, 1 = mask from the stored forward output y, 2 = mask RECOMPUTED from x as
 // [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0] — the same fp32 expression the forward apply pass evaluated, so
 // the mask is the forward's; saves one full read of y in each backward pass (only valid without a fused residual).
+// RELU == 3: swish, dz = dy * (s + z*s*(1-s)), s = sigmoid(z), z recomputed from x the same way (no residual).
 template <typename T, int VEC, int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int i = 0; i < VEC; ++i) {
             mu[i] = mean[col * VEC + i];
             is[i] = invstd[col * VEC + i];
-            if (RELU == 2) {
+            if (RELU >= 2) {
                 sc[i] = (gamma ? gamma[col * VEC + i] : 1.f) * is[i];
                 sh[i] = (beta ? beta[col * VEC + i] : 0.f) - mu[i] * sc[i];
             }
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 float gg = g[i];
                 if (RELU == 1) gg = o[i] > 0.f ? gg : 0.f;
                 if (RELU == 2) gg = fmaf(v[i], sc[i], sh[i]) > 0.f ? gg : 0.f;
+                if (RELU == 3) gg *= swish_grad(fmaf(v[i], sc[i], sh[i]));
                 s1[i] += gg;
                 s2[i] = fmaf(gg, (v[i] - mu[i]) * is[i], s2[i]);
             }
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         ca[i] = coef[col * VEC + i];
         cb[i] = coef[C + col * VEC + i];
         cc[i] = coef[2 * C + col * VEC + i];
-        if (RELU == 2) {
+        if (RELU >= 2) {
             sc[i] = (gamma ? gamma[col * VEC + i] : 1.f) * is[i];
             sh[i] = (beta ? beta[col * VEC + i] : 0.f) - mu[i] * sc[i];
         }
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int i = 0; i < VEC; ++i) {
             if (RELU == 1) g[i] = o[i] > 0.f ? g[i] : 0.f;
             if (RELU == 2) g[i] = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+            if (RELU == 3) g[i] *= swish_grad(fmaf(v[i], sc[i], sh[i]));
             const float xh = (v[i] - mu[i]) * is[i];
             v[i] = ca[i] * (g[i] - cb[i] - xh * cc[i]);
         }
@@ -372,12 +380,12 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     hipLaunchKernelGGL((bn_fwd_finalize_kernel<T>), dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const T*)x, (const float*)part, L.gy, M, C, gamma,
                        beta, eps, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
     MCN_CHECK_LAUNCH();
-    const bool relu = act == MCN_ACT_RELU;
+    const int a = (int)act;
 #define BN_APPLY(SK, RL)                                                                                                   \
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, (const float*)scale, \
                        (const float*)shift, M, C, L.TX, L.TY, L.rpb)
-    if (skip) { if (relu) BN_APPLY(true, true); else BN_APPLY(true, false); }
-    else { if (relu) BN_APPLY(false, true); else BN_APPLY(false, false); }
+    if (skip) { if (a == 1) BN_APPLY(true, 1); else if (a == 2) BN_APPLY(true, 2); else BN_APPLY(true, 0); }
+    else { if (a == 1) BN_APPLY(false, 1); else if (a == 2) BN_APPLY(false, 2); else BN_APPLY(false, 0); }
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -406,7 +414,7 @@ static int channel_affine_t(const void* x, const float* scale, const float* shif
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     const dim3 grid(L.gx, L.gy), block(256);
     const void* skip = nullptr;
-    BN_APPLY(false, false);
+    BN_APPLY(false, 0);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -422,7 +430,7 @@ extern "C" int mcn_channel_affine(const void* x, const float* scale, const float
 
 // inference: the caller owns all memory and passes no workspace, so the per-channel scale/shift are
 // computed in the kernel prologue (registers) instead of a separate finalize launch.
-template <typename T, int VEC, bool SKIP, bool RELU>
+template <typename T, int VEC, bool SKIP, int ACT>
 __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ var, float eps, long M,
@@ -448,7 +456,8 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
         for (int i = 0; i < VEC; ++i) {
             float o = fmaf(v[i], sc[i], sh[i]);
             if (SKIP) o += s[i];
-            if (RELU) o = fmaxf(o, 0.f);
+            if (ACT == 1) o = fmaxf(o, 0.f);
+            if (ACT == 2) o = o / (1.f + expf(-o));          // swish = z*sigmoid(z) (convnet.py:2553)
             v[i] = o;
         }
         stv<T, VEC>(y + off, v);
@@ -459,12 +468,12 @@ static int bn_infer_t(const void* x, const float* gamma, const float* beta, cons
                       long M, int C, float eps, mcn_act act, hipStream_t st) {
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     const dim3 grid(L.gx, L.gy), block(256);
-    const bool relu = act == MCN_ACT_RELU;
+    const int a = (int)act;
 #define BN_INFER(SK, RL)                                                                                                     \
     hipLaunchKernelGGL((bn_infer_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, gamma, beta, mean, var, \
                        eps, M, C, L.TX, L.TY, L.rpb)
-    if (skip) { if (relu) BN_INFER(true, true); else BN_INFER(true, false); }
-    else { if (relu) BN_INFER(false, true); else BN_INFER(false, false); }
+    if (skip) { if (a == 1) BN_INFER(true, 1); else if (a == 2) BN_INFER(true, 2); else BN_INFER(true, 0); }
+    else { if (a == 1) BN_INFER(false, 1); else if (a == 2) BN_INFER(false, 2); else BN_INFER(false, 0); }
 #undef BN_INFER
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -488,11 +497,11 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
     const dim3 grid(L.gx, L.gy), block(256);
-    const int relu = act != MCN_ACT_RELU ? 0 : (y ? 1 : 2);
+    const int relu = act == MCN_ACT_SWISH ? 3 : (act != MCN_ACT_RELU ? 0 : (y ? 1 : 2));
 #define BN_BWD_REDUCE(RL)                                                                                                          \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, RL>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x, \
                        (const T*)y, save_mean, save_invstd, gamma, beta, part, M, C, L.TX, L.TY, L.rpb)
-    if (relu == 0) BN_BWD_REDUCE(0); else if (relu == 1) BN_BWD_REDUCE(1); else BN_BWD_REDUCE(2);
+    if (relu == 0) BN_BWD_REDUCE(0); else if (relu == 1) BN_BWD_REDUCE(1); else if (relu == 2) BN_BWD_REDUCE(2); else BN_BWD_REDUCE(3);
 #undef BN_BWD_REDUCE
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
@@ -503,6 +512,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
                        save_invstd, gamma, beta, (const float*)coef, (T*)dx, (T*)dskip, M, C, L.TX, L.TY, L.rpb)
     if (relu == 1) { if (dskip) BN_BWD_APPLY(1, true); else BN_BWD_APPLY(1, false); }
     else if (relu == 2) { if (dskip) BN_BWD_APPLY(2, true); else BN_BWD_APPLY(2, false); }
+    else if (relu == 3) BN_BWD_APPLY(3, false);
     else { if (dskip) BN_BWD_APPLY(0, true); else BN_BWD_APPLY(0, false); }
 #undef BN_BWD_APPLY
     MCN_CHECK_LAUNCH();
@@ -513,6 +523,7 @@ extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const fl
                           int32_t C, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !dx || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd: workspace too small");
+    if (act == MCN_ACT_SWISH && dskip) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: swish with a fused residual is not built");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
                                             : bn_bwd_t<float, 1>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);

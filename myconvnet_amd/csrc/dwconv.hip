@@ -1,0 +1,475 @@
+// dwconv.hip — depthwise convolution (channel multiplier 1) and the squeeze-excite channel scale: the HBM-bound
+// kernels of the EfficientNet MBConv unit (reference models/efficientnet.py:126-197, convnet.py:1634-1650).
+//
+// Layout NHWC.  A thread owns one channel chunk (16 bytes forward / dgrad, 4 channels in wgrad) of one pixel; the
+// TX threads of a row cover TX consecutive chunks, so every tap read / write is a contiguous run of TX*16 bytes.
+// The K*K taps of one output re-read their neighbours' inputs from L1/L2 (every input byte leaves HBM once).
+// Filters are the fp32 masters [KH][KW][C]; in bf16 mode they are rounded per use (convnet.py:1421) on the fly.
+#include "common.h"
+
+struct DwParams {
+    int N, H, W, C, OH, OW;
+    int KH, KW, SH, SW, DH, DW, padT, padL;
+    int TX, TY;          // threads per row of chunks / rows per block
+    long npix;           // pixels of the tensor the thread grid walks (output: fwd, wgrad; input: dgrad)
+    int accumulate;
+};
+
+template <typename T>
+__device__ __forceinline__ float round_w(float w) {
+    return sizeof(T) == 2 ? (float)(bf16_t)w : w;
+}
+
+// largest divisor of n that is <= cap (>= 1)
+static int best_tx(int n, int cap) {
+    int best = 1;
+    for (int d = 1; d <= cap && d <= n; ++d)
+        if (n % d == 0) best = d;
+    if (best < 8 && n > cap) best = cap < 32 ? cap : 32;      // awkward (prime-ish) chunk counts: accept idle lanes
+    return best;
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, const DwParams p) {
+    constexpr int CE = VecTraits<T>::CE;
+    extern __shared__ float sw[];                                // [taps][TX*CE]
+    const int KH = K ? K : p.KH, KW = K ? K : p.KW;
+    const int taps = KH * KW;
+    const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+    const int cch = p.C / CE;
+    const int chunk0 = blockIdx.x * p.TX;
+    const int wcols = p.TX * CE;
+    for (int i = threadIdx.x; i < taps * wcols; i += 256) {
+        const int t = i / wcols, c = chunk0 * CE + (i - t * wcols);
+        sw[i] = c < p.C ? round_w<T>(w[(long)t * p.C + c]) : 0.f;
+    }
+    __syncthreads();
+    const int chunk = chunk0 + tx;
+    if (ty >= p.TY || chunk >= cch) return;
+    const float* wl = sw + tx * CE;
+    for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
+        const int ox = (int)(q % p.OW);
+        const long t1 = q / p.OW;
+        const int oy = (int)(t1 % p.OH);
+        const long n = t1 / p.OH;
+        float acc[CE];
+#pragma unroll
+        for (int i = 0; i < CE; ++i) acc[i] = 0.f;
+        const int iy0 = oy * p.SH - p.padT, ix0 = ox * p.SW - p.padL;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int iy = iy0 + ky * p.DH;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int ix = ix0 + kx * p.DW;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const Chunk<T> c = load_chunk<T>(x + ((n * p.H + iy) * p.W + ix) * p.C + (long)chunk * CE);
+                const float* wt = wl + (ky * KW + kx) * wcols;
+#pragma unroll
+                for (int i = 0; i < CE; ++i) acc[i] = fmaf(c.get(i), wt[i], acc[i]);
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int i = 0; i < CE; ++i) o.set(i, acc[i]);
+        store_chunk<T>(y + q * p.C + (long)chunk * CE, o);
+    }
+}
+
+// ---- dgrad: dx[n,iy,ix,c] = sum_{ky,kx} dy[n,(iy+pt-ky*d)/s,(ix+pl-kx*d)/s,c] * w[ky,kx,c] (where divisible, in range) ----
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, const DwParams p) {
+    constexpr int CE = VecTraits<T>::CE;
+    extern __shared__ float sw[];
+    const int KH = K ? K : p.KH, KW = K ? K : p.KW;
+    const int taps = KH * KW;
+    const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+    const int cch = p.C / CE;
+    const int chunk0 = blockIdx.x * p.TX;
+    const int wcols = p.TX * CE;
+    for (int i = threadIdx.x; i < taps * wcols; i += 256) {
+        const int t = i / wcols, c = chunk0 * CE + (i - t * wcols);
+        sw[i] = c < p.C ? round_w<T>(w[(long)t * p.C + c]) : 0.f;
+    }
+    __syncthreads();
+    const int chunk = chunk0 + tx;
+    if (ty >= p.TY || chunk >= cch) return;
+    const float* wl = sw + tx * CE;
+    for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
+        const int ix = (int)(q % p.W);
+        const long t1 = q / p.W;
+        const int iy = (int)(t1 % p.H);
+        const long n = t1 / p.H;
+        float acc[CE];
+#pragma unroll
+        for (int i = 0; i < CE; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int ny = iy + p.padT - ky * p.DH;
+            if (ny < 0 || ny % p.SH) continue;
+            const int oy = ny / p.SH;
+            if (oy >= p.OH) continue;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int nx = ix + p.padL - kx * p.DW;
+                if (nx < 0 || nx % p.SW) continue;
+                const int ox = nx / p.SW;
+                if (ox >= p.OW) continue;
+                const Chunk<T> c = load_chunk<T>(dy + ((n * p.OH + oy) * p.OW + ox) * p.C + (long)chunk * CE);
+                const float* wt = wl + (ky * KW + kx) * wcols;
+#pragma unroll
+                for (int i = 0; i < CE; ++i) acc[i] = fmaf(c.get(i), wt[i], acc[i]);
+            }
+        }
+        T* dst = dx + q * p.C + (long)chunk * CE;
+        Chunk<T> o;
+        if (p.accumulate) {
+            const Chunk<T> old = load_chunk<T>(dst);
+#pragma unroll
+            for (int i = 0; i < CE; ++i) acc[i] += old.get(i);
+        }
+#pragma unroll
+        for (int i = 0; i < CE; ++i) o.set(i, acc[i]);
+        store_chunk<T>(dst, o);
+    }
+}
+
+// ---- wgrad: dw[ky,kx,c] = sum_{n,oy,ox} x[n,oy*s+ky*d-pt,ox*s+kx*d-pl,c] * dy[n,oy,ox,c] ---------------------------
+// A thread owns 4 channels and all K*K taps (registers) over its share of the output pixels; the block folds its TY
+// pixel rows through LDS and writes one partial [taps][C] slab; a second kernel sums the slabs in a fixed order.
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float* v);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float* v) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const DwParams p) {
+    extern __shared__ float red[];                               // [TY][TX*4]
+    constexpr int TAPS = K * K;
+    const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+    const int c4 = p.C / 4;
+    const int grp = blockIdx.x * p.TX + tx;
+    const bool active = ty < p.TY && grp < c4;
+    float acc[TAPS][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
+    if (active) {
+        for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
+            const int ox = (int)(q % p.OW);
+            const long t1 = q / p.OW;
+            const int oy = (int)(t1 % p.OH);
+            const long n = t1 / p.OH;
+            float g[4];
+            load4<T>(dy + q * p.C + (long)grp * 4, g);
+            const int iy0 = oy * p.SH - p.padT, ix0 = ox * p.SW - p.padL;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = iy0 + ky * p.DH;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int ix = ix0 + kx * p.DW;
+                    if ((unsigned)ix >= (unsigned)p.W) continue;
+                    float v[4];
+                    load4<T>(x + ((n * p.H + iy) * p.W + ix) * p.C + (long)grp * 4, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[ky * K + kx][i] = fmaf(v[i], g[i], acc[ky * K + kx][i]);
+                }
+            }
+        }
+    }
+    const int cols = p.TX * 4;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        if (ty < p.TY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[ty * cols + tx * 4 + i] = acc[t][i];
+        }
+        __syncthreads();
+        if (ty == 0 && grp < c4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+                for (int k = 0; k < p.TY; ++k) s += red[k * cols + tx * 4 + i];
+                part[((long)blockIdx.y * TAPS + t) * p.C + (long)grp * 4 + i] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// generic filter sizes: one tap per blockIdx.z (K*K passes over the data; not on the EfficientNet path)
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_tap_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const DwParams p) {
+    extern __shared__ float red[];
+    const int tap = blockIdx.z, ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int taps = p.KH * p.KW;
+    const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+    const int c4 = p.C / 4;
+    const int grp = blockIdx.x * p.TX + tx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ty < p.TY && grp < c4) {
+        for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
+            const int ox = (int)(q % p.OW);
+            const long t1 = q / p.OW;
+            const int oy = (int)(t1 % p.OH);
+            const long n = t1 / p.OH;
+            const int iy = oy * p.SH - p.padT + ky * p.DH, ix = ox * p.SW - p.padL + kx * p.DW;
+            if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+            float g[4], v[4];
+            load4<T>(dy + q * p.C + (long)grp * 4, g);
+            load4<T>(x + ((n * p.H + iy) * p.W + ix) * p.C + (long)grp * 4, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(v[i], g[i], acc[i]);
+        }
+    }
+    const int cols = p.TX * 4;
+    if (ty < p.TY) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[ty * cols + tx * 4 + i] = acc[i];
+    }
+    __syncthreads();
+    if (ty == 0 && grp < c4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < p.TY; ++k) s += red[k * cols + tx * 4 + i];
+            part[((long)blockIdx.y * taps + tap) * p.C + (long)grp * 4 + i] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int slabs, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < slabs; ++b) s += (double)part[(long)b * n + i];
+    dw[i] = (float)s * scale;
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+static int dw_check(const mcn_conv_geom* g, mcn_dtype dt, const char* what) {
+    if (!g) MCN_FAIL(MCN_E_BADARG, "%s: null geometry", what);
+    if (g->N < 0 || g->H <= 0 || g->W <= 0 || g->Cin <= 0 || g->KH <= 0 || g->KW <= 0 || g->SH <= 0 || g->SW <= 0 || g->DH <= 0 || g->DW <= 0)
+        MCN_FAIL(MCN_E_BADARG, "%s: bad geometry", what);
+    if (g->Cout != g->Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: channel multiplier %d/%d != 1 is not built", what, g->Cout, g->Cin);
+    if (dt != MCN_F32 && dt != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", what, (int)dt);
+    if (g->Cin % (dt == MCN_F32 ? 4 : 8)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: C=%d must be a multiple of the 16-byte chunk", what, g->Cin);
+    if (g->x_cs && g->x_cs != g->Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: strided input channels are not built", what);
+    if (g->KH * g->KW > 121) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: filter too large", what);
+    return MCN_OK;
+}
+static inline int dw_out(int in, int k, int s, int d, int pa, int pb) { return (in + pa + pb - (k - 1) * d - 1) / s + 1; }
+
+static DwParams dw_params(const mcn_conv_geom* g, int ce, bool walk_input, unsigned* gx, unsigned* gy) {
+    DwParams p;
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->Cin;
+    p.OH = dw_out(g->H, g->KH, g->SH, g->DH, g->padT, g->padB);
+    p.OW = dw_out(g->W, g->KW, g->SW, g->DW, g->padL, g->padR);
+    p.KH = g->KH; p.KW = g->KW; p.SH = g->SH; p.SW = g->SW; p.DH = g->DH; p.DW = g->DW; p.padT = g->padT; p.padL = g->padL;
+    const int cch = p.C / ce;
+    p.TX = best_tx(cch, 32);
+    p.TY = 256 / p.TX;
+    p.npix = walk_input ? (long)p.N * p.H * p.W : (long)p.N * p.OH * p.OW;
+    p.accumulate = 0;
+    *gx = (unsigned)((cch + p.TX - 1) / p.TX);
+    long rows = (p.npix + p.TY - 1) / p.TY;
+    long want = 4096 / *gx;
+    if (want < 1) want = 1;
+    *gy = (unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want);
+    return p;
+}
+
+template <typename T>
+static int dw_fwd_t(const void* x, const float* w, void* y, const mcn_conv_geom* g, hipStream_t st) {
+    unsigned gx, gy;
+    const DwParams p = dw_params(g, VecTraits<T>::CE, false, &gx, &gy);
+    if (p.npix == 0) return MCN_OK;
+    const size_t lds = (size_t)p.KH * p.KW * p.TX * VecTraits<T>::CE * sizeof(float);
+    const dim3 grid(gx, gy), block(256);
+    if (p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((dw_fwd_kernel<T, 3>), grid, block, lds, st, (const T*)x, w, (T*)y, p);
+    else if (p.KH == 5 && p.KW == 5) hipLaunchKernelGGL((dw_fwd_kernel<T, 5>), grid, block, lds, st, (const T*)x, w, (T*)y, p);
+    else hipLaunchKernelGGL((dw_fwd_kernel<T, 0>), grid, block, lds, st, (const T*)x, w, (T*)y, p);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_dwconv2d_fwd(const void* x, const float* w, void* y, const mcn_conv_geom* g, mcn_dtype dtype, void* stream) {
+    if (int rc = dw_check(g, dtype, "dwconv2d_fwd")) return rc;
+    if (!x || !w || !y) MCN_FAIL(MCN_E_BADARG, "dwconv2d_fwd: null pointer");
+    return dtype == MCN_F32 ? dw_fwd_t<float>(x, w, y, g, (hipStream_t)stream) : dw_fwd_t<bf16_t>(x, w, y, g, (hipStream_t)stream);
+}
+
+template <typename T>
+static int dw_dgrad_t(const void* dy, const float* w, void* dx, const mcn_conv_geom* g, int accumulate, hipStream_t st) {
+    unsigned gx, gy;
+    DwParams p = dw_params(g, VecTraits<T>::CE, true, &gx, &gy);
+    p.accumulate = accumulate;
+    if (p.npix == 0) return MCN_OK;
+    const size_t lds = (size_t)p.KH * p.KW * p.TX * VecTraits<T>::CE * sizeof(float);
+    const dim3 grid(gx, gy), block(256);
+    if (p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((dw_dgrad_kernel<T, 3>), grid, block, lds, st, (const T*)dy, w, (T*)dx, p);
+    else if (p.KH == 5 && p.KW == 5) hipLaunchKernelGGL((dw_dgrad_kernel<T, 5>), grid, block, lds, st, (const T*)dy, w, (T*)dx, p);
+    else hipLaunchKernelGGL((dw_dgrad_kernel<T, 0>), grid, block, lds, st, (const T*)dy, w, (T*)dx, p);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_dwconv2d_dgrad(const void* dy, const float* w, void* dx, const mcn_conv_geom* g, int32_t accumulate, mcn_dtype dtype,
+                                  void* stream) {
+    if (int rc = dw_check(g, dtype, "dwconv2d_dgrad")) return rc;
+    if (!dy || !w || !dx) MCN_FAIL(MCN_E_BADARG, "dwconv2d_dgrad: null pointer");
+    return dtype == MCN_F32 ? dw_dgrad_t<float>(dy, w, dx, g, accumulate, (hipStream_t)stream)
+                            : dw_dgrad_t<bf16_t>(dy, w, dx, g, accumulate, (hipStream_t)stream);
+}
+
+static DwParams dw_wgrad_params(const mcn_conv_geom* g, unsigned* gx, unsigned* gy) {
+    unsigned a, b;
+    DwParams p = dw_params(g, 4, false, &a, &b);
+    const int c4 = p.C / 4;
+    p.TX = best_tx(c4, 64);
+    p.TY = 256 / p.TX;
+    *gx = (unsigned)((c4 + p.TX - 1) / p.TX);
+    long rows = (p.npix + p.TY - 1) / p.TY;
+    long want = 1024 / *gx;
+    if (want < 1) want = 1;
+    *gy = (unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want);
+    return p;
+}
+extern "C" size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom* g, mcn_dtype dtype) {
+    if (!g || g->Cin <= 0 || g->Cin % 4 || g->KH <= 0 || g->KW <= 0 || g->N < 0) return 0;
+    (void)dtype;
+    unsigned gx, gy;
+    dw_wgrad_params(g, &gx, &gy);
+    return align_up((size_t)gy * g->KH * g->KW * g->Cin * sizeof(float), 256);
+}
+template <typename T>
+static int dw_wgrad_t(const void* x, const void* dy, float* dw, const mcn_conv_geom* g, float scale, void* ws, hipStream_t st) {
+    unsigned gx, gy;
+    const DwParams p = dw_wgrad_params(g, &gx, &gy);
+    const long n = (long)p.KH * p.KW * p.C;
+    if (p.npix == 0) {
+        if (hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "dwconv2d_wgrad: memset failed");
+        return MCN_OK;
+    }
+    float* part = (float*)ws;
+    const size_t lds = (size_t)p.TY * p.TX * 4 * sizeof(float);
+    const dim3 block(256);
+    if (p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((dw_wgrad_kernel<T, 3>), dim3(gx, gy), block, lds, st, (const T*)x, (const T*)dy, part, p);
+    else if (p.KH == 5 && p.KW == 5) hipLaunchKernelGGL((dw_wgrad_kernel<T, 5>), dim3(gx, gy), block, lds, st, (const T*)x, (const T*)dy, part, p);
+    else hipLaunchKernelGGL((dw_wgrad_tap_kernel<T>), dim3(gx, gy, p.KH * p.KW), block, lds, st, (const T*)x, (const T*)dy, part, p);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, (const float*)part, dw, n, (int)gy, scale);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_dwconv2d_wgrad(const void* x, const void* dy, float* dw, const mcn_conv_geom* g, float grad_scale, mcn_dtype dtype, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    if (int rc = dw_check(g, dtype, "dwconv2d_wgrad")) return rc;
+    if (!x || !dy || !dw) MCN_FAIL(MCN_E_BADARG, "dwconv2d_wgrad: null pointer");
+    if (!ws || ws_bytes < mcn_dwconv2d_workspace_bytes(g, dtype)) MCN_FAIL(MCN_E_WORKSPACE, "dwconv2d_wgrad: workspace too small");
+    return dtype == MCN_F32 ? dw_wgrad_t<float>(x, dy, dw, g, grad_scale, ws, (hipStream_t)stream)
+                            : dw_wgrad_t<bf16_t>(x, dy, dw, g, grad_scale, ws, (hipStream_t)stream);
+}
+
+// ---- squeeze-excite channel scale: y[n,h,w,c] = x[n,h,w,c] * m[n,c] (models/efficientnet.py:161) ---------------------
+template <typename T>
+__global__ __launch_bounds__(256) void chscale_fwd_kernel(const T* __restrict__ x, const T* __restrict__ m, T* __restrict__ y, long total, long HW, int cch) {
+    constexpr int CE = VecTraits<T>::CE;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pix = i / cch;
+        const int ch = (int)(i - pix * cch);
+        const long n = pix / HW;
+        const Chunk<T> a = load_chunk<T>(x + i * CE), b = load_chunk<T>(m + (n * cch + ch) * CE);
+        Chunk<T> o;
+#pragma unroll
+        for (int k = 0; k < CE; ++k) o.set(k, a.get(k) * b.get(k));
+        store_chunk<T>(y + i * CE, o);
+    }
+}
+extern "C" int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream) {
+    if (!x || !m || !y || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_fwd: bad argument");
+    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: dtype %d unsupported", (int)dtype);
+    const int ce = dtype == MCN_F32 ? 4 : 8;
+    if (C % ce) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: C=%d must be a multiple of the 16-byte chunk", C);
+    const long total = (long)N * HW * (C / ce);
+    if (total == 0) return MCN_OK;
+    long b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (dtype == MCN_F32) hipLaunchKernelGGL((chscale_fwd_kernel<float>), dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)m, (float*)y, total, (long)HW, C / ce);
+    else hipLaunchKernelGGL((chscale_fwd_kernel<bf16_t>), dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)m, (bf16_t*)y, total, (long)HW, C / ce);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// dx = dy * m ; dm[n,c] = sum_hw dy * x  (one block per image x group of TX chunks)
+template <typename T>
+__global__ __launch_bounds__(256) void chscale_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ m, T* __restrict__ dx,
+                                                          T* __restrict__ dm, long HW, int C, int TX, int TY) {
+    constexpr int CE = VecTraits<T>::CE;
+    extern __shared__ float red[];                               // [TY][TX*CE]
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int cch = C / CE;
+    const int chunk = blockIdx.x * TX + tx;
+    const long n = blockIdx.y;
+    const bool active = ty < TY && chunk < cch;
+    float acc[CE];
+#pragma unroll
+    for (int i = 0; i < CE; ++i) acc[i] = 0.f;
+    if (active) {
+        const Chunk<T> mm = load_chunk<T>(m + (n * cch + chunk) * CE);
+        for (long r = ty; r < HW; r += TY) {
+            const long off = ((n * HW + r) * cch + chunk) * CE;
+            const Chunk<T> g = load_chunk<T>(dy + off), v = load_chunk<T>(x + off);
+            Chunk<T> o;
+#pragma unroll
+            for (int i = 0; i < CE; ++i) {
+                o.set(i, g.get(i) * mm.get(i));
+                acc[i] = fmaf(g.get(i), v.get(i), acc[i]);
+            }
+            store_chunk<T>(dx + off, o);
+        }
+    }
+    const int cols = TX * CE;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < CE; ++i) red[ty * cols + tx * CE + i] = acc[i];
+    }
+    __syncthreads();
+    if (ty == 0 && chunk < cch) {
+        Chunk<T> o;
+#pragma unroll
+        for (int i = 0; i < CE; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < TY; ++k) s += red[k * cols + tx * CE + i];
+            o.set(i, s);
+        }
+        store_chunk<T>(dm + (n * cch + chunk) * CE, o);
+    }
+}
+extern "C" int mcn_channel_scale_bwd(const void* dy, const void* x, const void* m, void* dx, void* dm, int32_t N, int64_t HW, int32_t C,
+                                     mcn_dtype dtype, void* stream) {
+    if (!dy || !x || !m || !dx || !dm || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_bwd: bad argument");
+    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd: dtype %d unsupported", (int)dtype);
+    const int ce = dtype == MCN_F32 ? 4 : 8;
+    if (C % ce) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd: C=%d must be a multiple of the 16-byte chunk", C);
+    if (N == 0) return MCN_OK;
+    const int cch = C / ce;
+    const int TX = best_tx(cch, 32), TY = 256 / TX;
+    const dim3 grid((unsigned)((cch + TX - 1) / TX), (unsigned)N), block(256);
+    const size_t lds = (size_t)TY * TX * ce * sizeof(float);
+    if (dtype == MCN_F32) hipLaunchKernelGGL((chscale_bwd_kernel<float>), grid, block, lds, (hipStream_t)stream, (const float*)dy, (const float*)x, (const float*)m, (float*)dx, (float*)dm, (long)HW, C, TX, TY);
+    else hipLaunchKernelGGL((chscale_bwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)m, (bf16_t*)dx, (bf16_t*)dm, (long)HW, C, TX, TY);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}

@@ -10,7 +10,24 @@ static inline unsigned ew_blocks(long nvec) {
     return (unsigned)b;
 }
 
-enum { EW_RELU = 0, EW_RELU_BWD = 1, EW_ADD = 2, EW_ADD_RELU = 3, EW_ACC = 4 };
+enum { EW_RELU = 0, EW_RELU_BWD = 1, EW_ADD = 2, EW_ADD_RELU = 3, EW_ACC = 4, EW_SWISH = 5, EW_SIGMOID = 6, EW_SWISH_BWD = 7, EW_SIGMOID_BWD = 8 };
+
+template <int OP>
+__device__ __forceinline__ float ew_apply(float va, float vb) {
+    if (OP == EW_RELU) return fmaxf(va, 0.f);
+    if (OP == EW_RELU_BWD) return vb > 0.f ? va : 0.f;                       // a = dy, b = y
+    if (OP == EW_ADD || OP == EW_ACC) return va + vb;
+    if (OP == EW_ADD_RELU) return fmaxf(va + vb, 0.f);
+    if (OP == EW_SWISH) return va / (1.f + expf(-va));                       // x*sigmoid(x), convnet.py:2553-2556
+    if (OP == EW_SIGMOID) return 1.f / (1.f + expf(-va));                    // convnet.py:2550
+    if (OP == EW_SWISH_BWD) {                                                // a = dy, b = x
+        const float sg = 1.f / (1.f + expf(-vb));
+        return va * sg * (1.f + vb * (1.f - sg));
+    }
+    return va * vb * (1.f - vb);                                             // EW_SIGMOID_BWD: a = dy, b = y
+}
+template <int OP>
+struct EwUnary { static constexpr bool value = OP == EW_RELU || OP == EW_SWISH || OP == EW_SIGMOID; };
 
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n) {
@@ -19,30 +36,15 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const 
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
         Chunk<T> ca = load_chunk<T>(a + i * CE), cb, co;
-        if (OP != EW_RELU) cb = load_chunk<T>(b + i * CE);
+        if (!EwUnary<OP>::value) cb = load_chunk<T>(b + i * CE);
 #pragma unroll
-        for (int k = 0; k < CE; ++k) {
-            const float va = ca.get(k);
-            float o;
-            if (OP == EW_RELU) o = fmaxf(va, 0.f);
-            else if (OP == EW_RELU_BWD) o = cb.get(k) > 0.f ? va : 0.f;       // a = dy, b = y
-            else if (OP == EW_ADD || OP == EW_ACC) o = va + cb.get(k);
-            else o = fmaxf(va + cb.get(k), 0.f);
-            co.set(k, o);
-        }
+        for (int k = 0; k < CE; ++k) co.set(k, ew_apply<OP>(ca.get(k), EwUnary<OP>::value ? 0.f : cb.get(k)));
         store_chunk<T>(y + i * CE, co);
     }
     // scalar tail
     const long t0 = nvec * CE;
-    for (long i = t0 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float va = to_f32(a[i]);
-        float o;
-        if (OP == EW_RELU) o = fmaxf(va, 0.f);
-        else if (OP == EW_RELU_BWD) o = to_f32(b[i]) > 0.f ? va : 0.f;
-        else if (OP == EW_ADD || OP == EW_ACC) o = va + to_f32(b[i]);
-        else o = fmaxf(va + to_f32(b[i]), 0.f);
-        y[i] = from_f32<T>(o);
-    }
+    for (long i = t0 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = from_f32<T>(ew_apply<OP>(to_f32(a[i]), EwUnary<OP>::value ? 0.f : to_f32(b[i])));
 }
 
 template <int OP>
@@ -81,6 +83,31 @@ extern "C" int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t
             MCN_FAIL(MCN_E_LAUNCH, "add_relu_bwd: copy failed");
     }
     return MCN_OK;
+}
+/* element-wise activations on small tensors (SE branch): swish / sigmoid / relu */
+extern "C" int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (act == MCN_ACT_RELU) return ew_dispatch<EW_RELU>(x, nullptr, y, n, dtype, st, "act_fwd");
+    if (act == MCN_ACT_SWISH) return ew_dispatch<EW_SWISH>(x, nullptr, y, n, dtype, st, "act_fwd");
+    if (act == MCN_ACT_SIGMOID) return ew_dispatch<EW_SIGMOID>(x, nullptr, y, n, dtype, st, "act_fwd");
+    MCN_FAIL(MCN_E_UNSUPPORTED, "act_fwd: activation %d unsupported", (int)act);
+}
+/* dx = dy * act'(.)  — relu and sigmoid differentiate through the stored output y, swish through the input x */
+extern "C" int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (act == MCN_ACT_RELU) {
+        if (!y) MCN_FAIL(MCN_E_BADARG, "act_bwd: relu needs y");
+        return ew_dispatch<EW_RELU_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
+    }
+    if (act == MCN_ACT_SWISH) {
+        if (!x) MCN_FAIL(MCN_E_BADARG, "act_bwd: swish needs x");
+        return ew_dispatch<EW_SWISH_BWD>(dy, x, dx, n, dtype, st, "act_bwd");
+    }
+    if (act == MCN_ACT_SIGMOID) {
+        if (!y) MCN_FAIL(MCN_E_BADARG, "act_bwd: sigmoid needs y");
+        return ew_dispatch<EW_SIGMOID_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
+    }
+    MCN_FAIL(MCN_E_UNSUPPORTED, "act_bwd: activation %d unsupported", (int)act);
 }
 extern "C" int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void* stream) {
     if (!b) MCN_FAIL(MCN_E_BADARG, "accumulate: null b");

@@ -113,6 +113,53 @@ class Tape(object):
         self.bw.append(bw)
         return y
 
+    def dwconv(self, x, scope, stride, padding='SAME', dilation=1):
+        w = self.p(scope + '/weights')
+        q = self.quant
+        wq = w.a if q is None else q(w.a)
+        y = V(ops.depthwise_conv2d_fwd(x.a, wq, stride, padding, dilation), q)
+
+        def bw():
+            w.acc(ops.depthwise_conv2d_wgrad(x.a, y.g, w.a.shape, stride, padding, dilation))
+            if x.g is not False:
+                x.acc(ops.depthwise_conv2d_dgrad(y.g, wq, x.a.shape, stride, padding, dilation))
+        self.bw.append(bw)
+        return y
+
+    def swish(self, x):
+        y = V(ops.swish_fwd(x.a), self.quant)
+        self.bw.append(lambda: x.acc(ops.swish_bwd(y.g, x.a)))
+        return y
+
+    def sigmoid(self, x):
+        y = V(ops.sigmoid_fwd(x.a), self.quant)
+        self.bw.append(lambda: x.acc(ops.sigmoid_bwd(y.g, y.a)))
+        return y
+
+    def scale_channels(self, x, m):
+        """x * m, m: [N,1,1,C] (SE mask)."""
+        y = V(ops.channel_scale_fwd(x.a, m.a), self.quant)
+
+        def bw():
+            dx, dm = ops.channel_scale_bwd(y.g, x.a, m.a)
+            x.acc(dx)
+            m.acc(dm.reshape(m.a.shape))
+        self.bw.append(bw)
+        return y
+
+    def scale_samples(self, x, s):
+        """x * s[n] with a constant per-sample factor (stochastic depth survival / (1 - rate))."""
+        y = V(ops.sample_scale_fwd(x.a, s.astype(x.a.dtype)), self.quant)
+        self.bw.append(lambda: x.acc(ops.sample_scale_fwd(y.g, s.astype(x.a.dtype))))
+        return y
+
+    def mean_keepdims(self, x):
+        """tf.reduce_mean(x, [1,2], keepdims=True) (models/efficientnet.py:183)."""
+        n, c = x.a.shape[0], x.a.shape[-1]
+        y = V(ops.global_avgpool_fwd(x.a).reshape(n, 1, 1, c), self.quant)
+        self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g.reshape(n, c), x.a.shape)))
+        return y
+
     def max_pool(self, x, k, s, padding='SAME'):
         ya, arg = ops.maxpool_fwd(x.a, k, s, padding)
         y = V(ya, self.quant)
@@ -268,6 +315,120 @@ class ResNetSpec(object):
 
 
 # ------------------------------------------------------------------------------------------------
+# EfficientNet  (models/efficientnet.py) — SURVEY §8f-2
+# ------------------------------------------------------------------------------------------------
+class EfficientNetSpec(object):
+    def __init__(self, channels=(32, 16, 24, 40, 80, 112, 192, 320, 1280), kernels=(3, 3, 3, 5, 3, 5, 5, 3, None),
+                 strides=(2, 1, 2, 2, 2, 1, 2, 1, None), conv_units=(None, 1, 2, 2, 3, 3, 4, 1, None),
+                 multipliers=(None, 1, 6, 6, 6, 6, 6, 6, None), se_reduction=4, num_classes=1000, in_channels=3,
+                 backbone_only=False, initial_drop_rate=0.0, final_drop_rate=0.0):
+        self.channels, self.kernels, self.strides = list(channels), list(kernels), list(strides)
+        self.conv_units, self.multipliers = list(conv_units), list(multipliers)
+        self.se_reduction = se_reduction
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+        self.backbone_only = backbone_only
+        self.initial_drop_rate, self.final_drop_rate = initial_drop_rate, final_drop_rate
+        self.survival = {}            # unit name -> per-sample factor array (set by the test when drop rates > 0)
+
+    @staticmethod
+    def b0(num_classes=1000, width_div=1, depth_div=1):
+        """width_div / depth_div shrink the net for tests (not reference options)."""
+        ch = [max(8, c // width_div) if c is not None else None for c in (32, 16, 24, 40, 80, 112, 192, 320, 1280)]
+        units = [None if u is None else max(1, u // depth_div) for u in (None, 1, 2, 2, 3, 3, 4, 1, None)]
+        return EfficientNetSpec(channels=ch, conv_units=units, num_classes=num_classes)
+
+    def units(self):
+        """[(name, kernel, stride, cin, cout, multiplier, drop_rate)] in build order (efficientnet.py:72-88)."""
+        out = []
+        nb = len(self.channels)
+        cin = self.channels[0]
+        for i in range(1, nb - 1):
+            dr = self.initial_drop_rate + (self.final_drop_rate - self.initial_drop_rate) * i / (nb - 2)
+            for j in range(self.conv_units[i]):
+                s = self.strides[i] if j == 0 else 1
+                out.append(('block_{}/mbconv_{}'.format(i, j), self.kernels[i], s, cin, self.channels[i], self.multipliers[i], dr))
+                cin = self.channels[i]
+        return out
+
+    def variables(self):
+        out = []
+
+        def conv(scope, k, cin, cout, biased=False):
+            out.append((scope + '/weights', (k, k, cin, cout), 'weight_fanout'))
+            if biased:
+                out.append((scope + '/biases', (cout,), 'bias'))
+
+        def bn(scope, c, zero=False):
+            out.append((scope + '/mu', (c,), 'mu'))
+            out.append((scope + '/sigma', (c,), 'sigma'))
+            out.append((scope + '/gamma', (c,), 'gamma0' if zero else 'gamma'))
+            out.append((scope + '/beta', (c,), 'beta'))
+
+        conv('block_0/conv_0', self.kernels[0], self.in_channels, self.channels[0])
+        bn('block_0/conv_0/norm', self.channels[0])
+        for name, k, s, cin, cout, mult, _ in self.units():
+            mid = cin * mult
+            has_skip = s == 1 and cin == cout
+            if mult > 1:
+                conv(name + '/conv_0', 1, cin, mid)
+                bn(name + '/conv_0/norm', mid)
+            out.append((name + '/conv_1/weights', (k, k, mid, 1), 'weight_fanout'))
+            bn(name + '/conv_1/norm', mid)
+            red = mid // (mult * self.se_reduction)
+            conv(name + '/se_mask/conv_0', 1, mid, red, biased=True)
+            conv(name + '/se_mask/conv_1', 1, red, mid, biased=True)
+            conv(name + '/conv_2', 1, mid, cout)
+            bn(name + '/conv_2/norm', cout, zero=has_skip)
+        last = 'block_{}'.format(len(self.channels) - 1)
+        conv(last + '/conv_0', 1, self.channels[-2], self.channels[-1])
+        bn(last + '/conv_0/norm', self.channels[-1])
+        if not self.backbone_only:
+            out.append(('block_None/logits/weights', (self.channels[-1], self.num_classes), 'weight_fc_uniform'))
+            out.append(('block_None/logits/biases', (self.num_classes,), 'bias'))
+        return out
+
+    def forward(self, t, x):
+        d = t.d
+        h = t.conv(x, 'block_0/conv_0', self.strides[0])
+        h = t.swish(t.bn(h, 'block_0/conv_0/norm'))
+        d['block_0'] = h
+        for name, k, s, cin, cout, mult, dr in self.units():
+            skip = h if (s == 1 and cin == cout) else None
+            y = h
+            if mult > 1:
+                y = t.conv(y, name + '/conv_0', 1)
+                y = t.swish(t.bn(y, name + '/conv_0/norm'))
+            y = t.dwconv(y, name + '/conv_1', s)
+            d[name + '/conv_1'] = y
+            y = t.swish(t.bn(y, name + '/conv_1/norm'))
+            m = t.mean_keepdims(y)
+            m = t.swish(t.conv(m, name + '/se_mask/conv_0', 1, biased=True))
+            m = t.sigmoid(t.conv(m, name + '/se_mask/conv_1', 1, biased=True))
+            d[name + '/se_mask'] = m
+            y = t.scale_channels(y, m)
+            y = t.conv(y, name + '/conv_2', 1)
+            y = t.bn(y, name + '/conv_2/norm')
+            if skip is not None:
+                if dr > 0.0 and t.train:
+                    y = t.scale_samples(y, self.survival[name])
+                y = t.add(y, skip)
+            d[name] = y
+            h = y
+        last = 'block_{}'.format(len(self.channels) - 1)
+        h = t.conv(h, last + '/conv_0', 1)
+        h = t.swish(t.bn(h, last + '/conv_0/norm'))
+        d[last] = h
+        if self.backbone_only:
+            return h
+        h = t.global_avgpool(h)
+        d['logits/avgpool'] = h
+        logits = t.fc(h, 'block_None/logits')
+        d['logits'] = logits
+        return logits
+
+
+# ------------------------------------------------------------------------------------------------
 # VGG  (models/vggnet.py)
 # ------------------------------------------------------------------------------------------------
 VGG_MEAN = np.array([123.68, 116.78, 103.94])
@@ -324,6 +485,21 @@ def init_variables(var_list, seed=0, dtype=np.float32):
                 w[bad] = rng.standard_normal(int(bad.sum()))
                 bad = np.abs(w) > 2
             params[name] = (w * std).astype(dtype)
+        elif kind == 'weight_fanout':
+            # tf.initializers.variance_scaling(mode='fan_out'): truncated normal, std = sqrt(1/fan_out)/0.8796
+            # (models/efficientnet.py:20); fan_out = shape[-1] * receptive field
+            fan_out = int(np.prod(shape[:-2])) * shape[-1]
+            std = np.sqrt(1.0 / fan_out) / 0.87962566103423978
+            w = rng.standard_normal(shape)
+            bad = np.abs(w) > 2
+            while bad.any():
+                w[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(w) > 2
+            params[name] = (w * std).astype(dtype)
+        elif kind == 'weight_fc_uniform':
+            # variance_scaling(scale=1/3, mode='fan_out', distribution='uniform') (models/efficientnet.py:21-23)
+            limit = np.sqrt(3.0 * (1.0 / 3.0) / shape[-1])
+            params[name] = rng.uniform(-limit, limit, shape).astype(dtype)
         elif kind in ('bias', 'beta'):
             params[name] = np.zeros(shape, dtype)
         elif kind == 'gamma':

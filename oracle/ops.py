@@ -128,6 +128,62 @@ def bias_add_bwd(dy):
 
 
 # --------------------------------------------------------------------------------------------
+# depthwise conv2d  (tf.nn.depthwise_conv2d at convnet.py:1645; filter [kh,kw,cin,mult], output channel
+# c*mult + m; gradients DepthwiseConv2dNativeBackpropInput / BackpropFilter) — SURVEY §8f-2
+# --------------------------------------------------------------------------------------------
+def depthwise_conv2d_fwd(x, w, stride=1, padding='SAME', dilation=1):
+    """y[n,oy,ox,c*mult+m] = sum_{r,s} x[n, oy*sh + r*dh - pt, ox*sw + s*dw - pl, c] * w[r,s,c,m]."""
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
+    n, h, wd, c = x.shape
+    kh, kw, c2, mult = w.shape
+    assert c == c2
+    pt, pb, pl, pr = resolve_pads(h, wd, kh, kw, sh, sw, padding, dh, dw)
+    oh = out_size(h, kh, sh, padding, dh)
+    ow = out_size(wd, kw, sw, padding, dw)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    y = np.zeros((n, oh, ow, c, mult), dtype=x.dtype)
+    for r in range(kh):
+        for s in range(kw):
+            v = _tap_view(xp, r, s, oh, ow, sh, sw, dh, dw)
+            y += v[..., None] * w[r, s]
+    return y.reshape(n, oh, ow, c * mult)
+
+
+def depthwise_conv2d_dgrad(dy, w, x_shape, stride=1, padding='SAME', dilation=1):
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
+    n, h, wd, c = x_shape
+    kh, kw, _, mult = w.shape
+    pt, pb, pl, pr = resolve_pads(h, wd, kh, kw, sh, sw, padding, dh, dw)
+    oh, ow = dy.shape[1:3]
+    dxp = np.zeros((n, h + pt + pb, wd + pl + pr, c), dtype=dy.dtype)
+    dy5 = dy.reshape(n, oh, ow, c, mult)
+    for r in range(kh):
+        for s in range(kw):
+            v = _tap_view(dxp, r, s, oh, ow, sh, sw, dh, dw)
+            v += (dy5 * w[r, s]).sum(axis=-1)
+    return np.ascontiguousarray(dxp[:, pt:pt + h, pl:pl + wd, :])
+
+
+def depthwise_conv2d_wgrad(x, dy, w_shape, stride=1, padding='SAME', dilation=1):
+    sh, sw = _pair(stride)
+    dh, dw_ = _pair(dilation)
+    n, h, wd, c = x.shape
+    kh, kw, _, mult = w_shape
+    pt, pb, pl, pr = resolve_pads(h, wd, kh, kw, sh, sw, padding, dh, dw_)
+    oh, ow = dy.shape[1:3]
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    dwt = np.zeros(w_shape, dtype=x.dtype)
+    dy5 = dy.reshape(n, oh, ow, c, mult)
+    for r in range(kh):
+        for s in range(kw):
+            v = _tap_view(xp, r, s, oh, ow, sh, sw, dh, dw_)
+            dwt[r, s] = (v[..., None] * dy5).sum(axis=(0, 1, 2))
+    return dwt
+
+
+# --------------------------------------------------------------------------------------------
 # batch norm  (tf.nn.fused_batch_norm, convnet.py:1883-1896; running stats convnet.py:1898-1914)
 # --------------------------------------------------------------------------------------------
 def bn_fwd_train(x, gamma, beta, eps=1e-3):
@@ -187,6 +243,43 @@ def relu_fwd(x):
 def relu_bwd(dy, y):
     """ReluGrad: dy * [y > 0]."""
     return dy * (y > 0)
+
+
+def sigmoid_fwd(x):
+    """tf.nn.sigmoid (convnet.py:2550)."""
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def sigmoid_bwd(dy, y):
+    return dy * y * (1.0 - y)
+
+
+def swish_fwd(x):
+    """x * sigmoid(x) (convnet.py:2553-2556)."""
+    return x * sigmoid_fwd(x)
+
+
+def swish_bwd(dy, x):
+    """d/dx [x*s(x)] = s + x*s*(1-s)  (what TF autodiff of x*sigmoid(x) evaluates to)."""
+    s = sigmoid_fwd(x)
+    return dy * (s + x * s * (1.0 - s))
+
+
+def channel_scale_fwd(x, m):
+    """x * se_mask with the mask broadcast over H, W (models/efficientnet.py:161); m: [N,1,1,C] or [N,C]."""
+    return x * m.reshape(x.shape[0], 1, 1, x.shape[-1])
+
+
+def channel_scale_bwd(dy, x, m):
+    """Returns dx, dm ([N,C])."""
+    dx = dy * m.reshape(x.shape[0], 1, 1, x.shape[-1])
+    dm = (dy * x).sum(axis=(1, 2))
+    return dx, dm
+
+
+def sample_scale_fwd(x, s):
+    """x * survived[n] (stochastic depth, convnet.py:2503-2509); s: [N]."""
+    return x * s.reshape(-1, 1, 1, 1)
 
 
 def add_fwd(x, skip):

@@ -138,3 +138,72 @@ def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want
                               dx.data_ptr(), dsk.data_ptr() if dsk is not None else 0, dg.data_ptr(), db.data_ptr(), float(scale), m, c, act,
                               MDT[dtype], ws.data_ptr(), ws.numel() * 4, stream()))
     return host(dx), host(dg), host(db), (host(dsk) if dsk is not None else None)
+
+
+# ---- EfficientNet row ---------------------------------------------------------------------------------
+def dw_geom(x_shape, k, stride, padding, dilation=1):
+    n, h, w, c = x_shape
+    sh, sw = O._pair(stride)
+    dh, dw = O._pair(dilation)
+    pads = O.resolve_pads(h, w, k, k, sh, sw, padding, dh, dw)
+    return _ffi.conv_geom(n, h, w, c, c, k, k, sh, sw, dh, dw, pads, 0)
+
+
+def dwconv_fwd(x, w, stride, padding, dilation=1, dtype='float32'):
+    k = w.shape[0]
+    g = dw_geom(x.shape, k, stride, padding, dilation)
+    oh = O.out_size(x.shape[1], k, O._pair(stride)[0], padding, O._pair(dilation)[0])
+    ow = O.out_size(x.shape[2], k, O._pair(stride)[1], padding, O._pair(dilation)[1])
+    xd, wd = dev(x, dtype), dev(w.reshape(k, k, -1))
+    y = torch.full((x.shape[0], oh, ow, x.shape[3]), float('nan'), dtype=TDT[dtype], device=DEV)
+    _ffi.check(lib.mcn_dwconv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), ctypes.byref(g), MDT[dtype], stream()))
+    return host(y)
+
+
+def dwconv_dgrad(dy, w, x_shape, stride, padding, dilation=1, dtype='float32', accumulate_into=None):
+    k = w.shape[0]
+    g = dw_geom(x_shape, k, stride, padding, dilation)
+    dyd, wd = dev(dy, dtype), dev(w.reshape(k, k, -1))
+    dx = dev(accumulate_into, dtype) if accumulate_into is not None else torch.full(tuple(x_shape), float('nan'), dtype=TDT[dtype], device=DEV)
+    _ffi.check(lib.mcn_dwconv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), ctypes.byref(g), 1 if accumulate_into is not None else 0,
+                                      MDT[dtype], stream()))
+    return host(dx)
+
+
+def dwconv_wgrad(x, dy, k, stride, padding, dilation=1, dtype='float32', scale=1.0):
+    g = dw_geom(x.shape, k, stride, padding, dilation)
+    xd, dyd = dev(x, dtype), dev(dy, dtype)
+    dw = torch.full((k, k, x.shape[3], 1), float('nan'), dtype=torch.float32, device=DEV)
+    ws = workspace(lib.mcn_dwconv2d_workspace_bytes(ctypes.byref(g), MDT[dtype]))
+    _ffi.check(lib.mcn_dwconv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(g), float(scale), MDT[dtype], ws.data_ptr(),
+                                      ws.numel() * 4, stream()))
+    return host(dw)
+
+
+def channel_scale(x, m, dy, dtype='float32'):
+    n, h, w, c = x.shape
+    xd, md, dyd = dev(x, dtype), dev(m.reshape(n, c), dtype), dev(dy, dtype)
+    y = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    dx = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    dm = torch.full((n, c), float('nan'), dtype=TDT[dtype], device=DEV)
+    _ffi.check(lib.mcn_channel_scale_fwd(xd.data_ptr(), md.data_ptr(), y.data_ptr(), n, h * w, c, MDT[dtype], stream()))
+    _ffi.check(lib.mcn_channel_scale_bwd(dyd.data_ptr(), xd.data_ptr(), md.data_ptr(), dx.data_ptr(), dm.data_ptr(), n, h * w, c, MDT[dtype], stream()))
+    return host(y), host(dx), host(dm)
+
+
+def act(x, dy, kind, dtype='float32'):
+    xd, dyd = dev(x, dtype), dev(dy, dtype)
+    y = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    dx = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    _ffi.check(lib.mcn_act_fwd(xd.data_ptr(), y.data_ptr(), x.size, kind, MDT[dtype], stream()))
+    _ffi.check(lib.mcn_act_bwd(dyd.data_ptr(), xd.data_ptr(), y.data_ptr(), dx.data_ptr(), x.size, kind, MDT[dtype], stream()))
+    return host(y), host(dx)
+
+
+def bn_fwd_infer(x, gamma, beta, mean, var, eps=1e-3, dtype='float32', act=0):
+    c = x.shape[-1]
+    xd, gd, bd, md, vd = dev(x, dtype), dev(gamma), dev(beta), dev(mean), dev(var)
+    y = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
+    _ffi.check(lib.mcn_bn_fwd_infer(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), md.data_ptr(), vd.data_ptr(), 0, y.data_ptr(), x.size // c, c,
+                                    eps, act, MDT[dtype], stream()))
+    return host(y)

@@ -1,0 +1,121 @@
+"""GPU parity, EfficientNet MBConv row: depthwise conv fwd / dgrad / wgrad, BN+swish, swish / sigmoid,
+squeeze-excite channel scale — HIP kernels through the C-ABI vs the NumPy oracle.  Tolerances as in test_gpu_ops.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O  # noqa: E402
+from test_gpu_ops import check, q, DTYPES  # noqa: E402
+
+
+def _u():
+    import abi_util
+    return abi_util
+
+
+RNG = np.random.default_rng(23)
+
+# n, h, w, c, k, stride, padding, dilation  (EfficientNet-B0 uses k in {3,5}, s in {1,2}, C in {32..1152})
+DW_CASES = [
+    (2, 12, 12, 32, 3, 1, 'SAME', 1),
+    (2, 12, 12, 96, 3, 2, 'SAME', 1),            # even H stride 2: pads (0,1)
+    (2, 9, 9, 144, 5, 2, 'SAME', 1),             # odd H stride 2 5x5: pads (2,2)
+    (3, 14, 14, 240, 5, 1, 'SAME', 1),
+    (2, 7, 7, 1152, 3, 1, 'SAME', 1),            # widest B0 layer
+    (2, 7, 5, 672, 5, 1, 'SAME', 1),             # non-square
+    (1, 10, 10, 40, 7, 1, 'SAME', 1),            # generic filter size (tap-per-block wgrad)
+    (2, 9, 9, 16, 3, 1, 'VALID', 2),             # VALID + dilation
+    (1, 1, 1, 8, 3, 1, 'SAME', 1),               # 1x1 map
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', DW_CASES)
+def test_depthwise_fwd_dgrad_wgrad(case, dtype):
+    u = _u()
+    n, h, w_, c, k, s, pad, dil = case
+    x = RNG.standard_normal((n, h, w_, c)).astype(np.float32)
+    w = (RNG.standard_normal((k, k, c, 1)) / k).astype(np.float32)
+    xq, wq = q(x, dtype), q(w, dtype)
+    y_ref = O.depthwise_conv2d_fwd(xq, wq, s, pad, dil)
+    check(u.dwconv_fwd(x, w, s, pad, dil, dtype), y_ref, dtype, 'dw_fwd')
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dyq = q(dy, dtype)
+    check(u.dwconv_dgrad(dy, w, x.shape, s, pad, dil, dtype), O.depthwise_conv2d_dgrad(dyq, wq, x.shape, s, pad, dil), dtype, 'dw_dgrad')
+    base = RNG.standard_normal(x.shape).astype(np.float32)
+    check(u.dwconv_dgrad(dy, w, x.shape, s, pad, dil, dtype, accumulate_into=base),
+          q(base, dtype) + O.depthwise_conv2d_dgrad(dyq, wq, x.shape, s, pad, dil), dtype, 'dw_dgrad accumulate')
+    dw_ref = O.depthwise_conv2d_wgrad(xq, dyq, w.shape, s, pad, dil)
+    check(u.dwconv_wgrad(x, dy, k, s, pad, dil, dtype, scale=0.5), 0.5 * dw_ref, 'float32', 'dw_wgrad', rel=2e-5)   # fp32 sums of exact products
+
+
+def test_depthwise_rejects_unbuilt_options():
+    import ctypes
+    import torch
+    from myconvnet_amd import _ffi
+    g = _ffi.conv_geom(1, 4, 4, 8, 16, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1), 0)      # channel multiplier 2
+    t = torch.zeros(1024, device='cuda')
+    assert _ffi.lib.mcn_dwconv2d_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), ctypes.byref(g), _ffi.F32, 0) == _ffi.E_UNSUPPORTED
+    g = _ffi.conv_geom(1, 4, 4, 6, 6, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1), 0)       # C not a chunk multiple
+    assert _ffi.lib.mcn_dwconv2d_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), ctypes.byref(g), _ffi.F32, 0) == _ffi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(4, 6, 6, 16), (8, 9, 9, 96), (2, 3, 3, 1152)])
+def test_bn_swish_fwd_bwd(shape, dtype):
+    """normalization + swish of every EfficientNet conv (models/efficientnet.py:62-67): fused apply and backward."""
+    u = _u()
+    c = shape[-1]
+    x = (1.5 * RNG.standard_normal(shape) + 0.3).astype(np.float32)
+    g = (0.5 + RNG.random(c)).astype(np.float32)
+    b = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    xq = q(x, dtype)
+    z_ref, bm, bv, sm, si = O.bn_fwd_train(xq, g.astype(np.float64), b.astype(np.float64), 1e-3)
+    out = u.bn_fwd_train(x, g, b, 1e-3, dtype, act=2)
+    check(out['y'], O.swish_fwd(z_ref), dtype, 'bn+swish y')
+    check(out['batch_mean'], bm, 'float32', 'batch_mean', rel=1e-5)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    dz = O.swish_bwd(q(dy, dtype), z_ref)
+    dx_ref, dg_ref, db_ref = O.bn_bwd(dz, xq, g.astype(np.float64), sm, si)
+    dx, dg, db, _ = u.bn_bwd(dy, x, None, g, out['save_mean'], out['save_invstd'], dtype, act=2, beta=b)
+    check(dx, dx_ref, dtype, 'bn+swish dx', rel=None if dtype == 'float32' else 1.2e-2)
+    check(dg, dg_ref, 'float32', 'dgamma', rel=1e-4 if dtype == 'float32' else 5e-3, mx=5e-2)
+    check(db, db_ref, 'float32', 'dbeta', rel=1e-4 if dtype == 'float32' else 5e-3, mx=5e-2)
+    # inference path with the same activation
+    mean, var = RNG.standard_normal(c).astype(np.float32) * 0.1, (0.5 + RNG.random(c)).astype(np.float32)
+    yi = u.bn_fwd_infer(x, g, b, mean, var, 1e-3, dtype, act=2)
+    check(yi, O.swish_fwd(O.bn_fwd_infer(xq, g.astype(np.float64), b.astype(np.float64), mean.astype(np.float64), var.astype(np.float64), 1e-3)), dtype, 'bn infer + swish')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_swish_sigmoid_elementwise(dtype):
+    u = _u()
+    from myconvnet_amd import _ffi
+    x = (3.0 * RNG.standard_normal((37, 24))).astype(np.float32)          # 888 elements: vector body + scalar tail
+    dy = RNG.standard_normal(x.shape).astype(np.float32)
+    xq, dyq = q(x, dtype), q(dy, dtype)
+    y, dx = u.act(x, dy, _ffi.ACT_SWISH, dtype)
+    check(y, O.swish_fwd(xq), dtype, 'swish')
+    check(dx, O.swish_bwd(dyq, xq), dtype, 'swish bwd')
+    y, dx = u.act(x, dy, _ffi.ACT_SIGMOID, dtype)
+    check(y, O.sigmoid_fwd(xq), dtype, 'sigmoid')
+    check(dx, O.sigmoid_bwd(dyq, q(y, dtype)), dtype, 'sigmoid bwd')        # differentiates through the stored (rounded) y
+    y, dx = u.act(x, dy, _ffi.ACT_RELU, dtype)
+    check(y, O.relu_fwd(xq), dtype, 'relu')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 7, 7, 32), (4, 5, 9, 144), (2, 14, 14, 480), (2, 1, 1, 8)])
+def test_se_channel_scale(shape, dtype):
+    u = _u()
+    n, h, w, c = shape
+    x = RNG.standard_normal(shape).astype(np.float32)
+    m = RNG.random((n, 1, 1, c)).astype(np.float32)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    xq, mq, dyq = q(x, dtype), q(m, dtype), q(dy, dtype)
+    y, dx, dm = u.channel_scale(x, m, dy, dtype)
+    check(y, O.channel_scale_fwd(xq, mq), dtype, 'se scale')
+    dx_ref, dm_ref = O.channel_scale_bwd(dyq, xq, mq)
+    check(dx, dx_ref, dtype, 'se dx')
+    check(dm, dm_ref, dtype, 'se dm')
