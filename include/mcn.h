@@ -253,6 +253,12 @@ int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* works
  * over n contiguous fp32 elements. */
 int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum,
                            float l2, float wd, float ema_decay, float grad_scale, void* stream);
+/* replaces tf.clip_by_global_norm(grads, gradient_threshold) (optimizers.py:112-113) over the flat gradient buffer:
+ * first g[i] += l2 * w[i] for i < n_l2 (the gradient of the L2 term, which the reference's loss contains and which
+ * otherwise rides in mcn_sgd_nesterov_fused — pass l2 = 0 there when clipping), then g *= t / max(||g||_2, t).
+ * norm_out (device, may be NULL) receives the pre-clip norm.  workspace >= 1028 floats. */
+int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int64_t n_l2, float l2, float threshold, float* norm_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* shadow <- d*shadow + (1-d)*v (EMA of BN running statistics, convnet.py:1812,1826) */
 int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream);
 /* chained running-statistics update over `towers` ranks (convnet.py:1899-1909):

@@ -1,8 +1,10 @@
 """myconvnet_amd — MI355X-native (gfx950) implementation of MyConvNet's conv / batch-norm / ReLU / pooling
 training hot path behind the reference's own Python surface.  See DESIGN.md and include/mcn.h."""
 from . import _ffi  # noqa: F401  (raises if libmcn_hip.so is missing: there is no CPU fallback)
-from .convnet import ConvNet, he_normal, ones, zeros  # noqa: F401
+from .convnet import ConvNet, he_normal, ones, variance_scaling, zeros  # noqa: F401
 from .dataset import DataSet, synthetic  # noqa: F401
+from .efficientnet import (EfficientNet, EfficientNetB0, EfficientNetB1, EfficientNetB2, EfficientNetB3, EfficientNetB4,  # noqa: F401
+                           EfficientNetB5, EfficientNetB6, EfficientNetB7)
 from .evaluators import AccuracyEvaluator  # noqa: F401
 from .optimizers import MomentumOptimizer, Optimizer  # noqa: F401
 from .resnet_v1_5 import ResNet18, ResNet34, ResNet50, ResNet101  # noqa: F401

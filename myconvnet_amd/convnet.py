@@ -34,6 +34,25 @@ def he_normal():
     return init
 
 
+def variance_scaling(scale=1.0, mode='fan_in', distribution='truncated_normal'):
+    """tf.initializers.variance_scaling (models/efficientnet.py:20-23): n = fan_in | fan_out | their mean with
+    fan_out = shape[-1] * receptive field; truncated normal std = sqrt(scale/n)/0.8796, uniform limit = sqrt(3*scale/n)."""
+    def init(shape, gen):
+        rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        fan_in = (shape[-2] if len(shape) > 1 else shape[0]) * rf
+        fan_out = shape[-1] * rf
+        n = {'fan_in': fan_in, 'fan_out': fan_out, 'fan_avg': (fan_in + fan_out) / 2.0}[mode]
+        t = torch.empty(shape, dtype=torch.float32)
+        if distribution == 'uniform':
+            lim = math.sqrt(3.0 * scale / max(n, 1))
+            t.uniform_(-lim, lim, generator=gen)
+        else:
+            std = math.sqrt(scale / max(n, 1)) / 0.87962566103423978
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+        return t
+    return init
+
+
 def zeros():
     return lambda shape, gen: torch.zeros(shape, dtype=torch.float32)
 
@@ -105,6 +124,8 @@ class ConvNet(object):
         self._collections = {}
         self.variables = {}             # name -> Variable (trainables and BN statistics)
         self._var_order = []
+        self._random_nodes = []         # dropout / stochastic-depth nodes whose masks are drawn on the host per step
+        self._mask_rng = np.random.default_rng([int(kwargs.get('seed', 0)), self.rank, 0x5eed])
         self.graph = None
         self.compiled = False
         self.seed = int(kwargs.get('seed', 0))
@@ -116,6 +137,7 @@ class ConvNet(object):
     name = 'ConvNet'
     input_size = property(lambda self: self._input_size)
     num_classes = property(lambda self: self._num_classes)
+    feature_reduction = property(lambda self: self._parameters.get('feature_reduction_factor', 0))   # convnet.py:109
     loss_weights = property(lambda self: self._loss_weights)
     model_scope = property(lambda self: self._model_scope)
     backbone_only = property(lambda self: self._backbone_only)
@@ -308,6 +330,11 @@ class ConvNet(object):
                 mu, sg = a['mu'], a['sigma']
                 a['saved'] = dict(mean=torch.zeros(c, dtype=torch.float32, device=dev), invstd=torch.zeros(c, dtype=torch.float32, device=dev),
                                   bmean=self.batch_stats[mu.offset:mu.offset + c], bvar=self.batch_stats[sg.offset:sg.offset + c])
+            elif n.op == 'mulmask':
+                x = n.inputs[0]
+                ce = 8 if x.dtype == 'bfloat16' else 4
+                cols = ce if n.attrs['kind'] == 'sample' else x.shape[-1]
+                n.attrs['mask'] = torch.ones((x.shape[0], cols), dtype=torch.bfloat16 if x.dtype == 'bfloat16' else torch.float32, device=dev)
             elif n.op == 'loss':
                 a = n.attrs
                 a['pred'] = self.pred
@@ -424,12 +451,13 @@ class ConvNet(object):
                    dilation=(1, 1), ws=False, kernel_paddings=((0, 0), (0, 0)), weight_initializer=None, bias_initializer=None,
                    verbose=False):
         """reference convnet.py:1597-1706 -> tf.nn.conv2d (:1659) [+ tf.nn.bias_add (:1694)]."""
-        if depthwise:
-            raise NotImplementedError('depthwise convolution is a SURVEY §8f-2 row, not built yet')
         kernel, stride, dilation = _pair(kernel), _pair(stride), _pair(dilation)
         n, h, w, cin = x.shape
         if out_channels is None:
             out_channels = cin
+        if depthwise:
+            return self._depthwise_conv_layer(x, kernel, stride, out_channels, padding, biased, scope, dilation, ws, kernel_paddings,
+                                              weight_initializer, bias_initializer)
         oh = out_size(h, kernel[0], stride[0], padding, dilation[0])
         ow = out_size(w, kernel[1], stride[1], padding, dilation[1])
         if padding.upper() == 'SAME':
@@ -454,6 +482,33 @@ class ConvNet(object):
             flops += oh * ow * out_channels
             params += out_channels
         self._log_layer(name, [None, oh, ow, out_channels], flops, params, oh * ow * out_channels)
+        return y
+
+    def _depthwise_conv_layer(self, x, kernel, stride, out_channels, padding, biased, scope, dilation, ws, kernel_paddings,
+                              weight_initializer, bias_initializer):
+        """reference convnet.py:1634-1650 -> tf.nn.depthwise_conv2d (:1645), filter [kh, kw, cin, multiplier]."""
+        n, h, w, cin = x.shape
+        mult = max(out_channels // cin, 1)
+        if mult != 1:
+            raise NotImplementedError('depthwise channel multiplier {} (only 1, the EfficientNet case, is built)'.format(mult))
+        if biased:
+            raise NotImplementedError('biased depthwise convolution is outside the built path')
+        oh = out_size(h, kernel[0], stride[0], padding, dilation[0])
+        ow = out_size(w, kernel[1], stride[1], padding, dilation[1])
+        if padding.upper() == 'SAME':
+            pt, pb = same_pads(h, kernel[0], stride[0], dilation[0])
+            pl, pr = same_pads(w, kernel[1], stride[1], dilation[1])
+        else:
+            pt = pb = pl = pr = 0
+        with self.variable_scope(scope) if scope is not None else nullcontext():
+            wv = self.weight_variable([kernel[0], kernel[1], cin, mult], initializer=weight_initializer, weight_standardization=ws,
+                                      paddings=kernel_paddings)
+            name = self.scope_name()
+        y = self.graph.tensor((n, oh, ow, cin * mult), x.dtype, name + '/dwconv', self._channel_first)
+        geom = _ffi.conv_geom(n, h, w, cin, cin, kernel[0], kernel[1], stride[0], stride[1], dilation[0], dilation[1], (pt, pb, pl, pr), 0)
+        self.graph.node('dwconv', [x], [y], scope=name, geom=geom, w=wv, has_params=True)
+        flops = oh * ow * kernel[0] * kernel[1] * cin * mult
+        self._log_layer(name, [None, oh, ow, cin * mult], flops, kernel[0] * kernel[1] * cin * mult, oh * ow * cin * mult)
         return y
 
     def conv_bn_act(self, x, kernel, stride, out_channels=None, padding='SAME', biased=False, depthwise=False, scope=None,
@@ -557,17 +612,58 @@ class ConvNet(object):
             return self.max_pool(x, kernel, stride, padding=padding)
         raise ValueError('Pooling type of {} is not supported'.format(pooling_type))
 
-    def global_avg_pool(self, x):
-        """Stand-in for tf.reduce_mean(x, axis=[1, 2]) at models/resnet_v1_5.py:72-73."""
+    def global_avg_pool(self, x, keepdims=False):
+        """Stand-in for tf.reduce_mean(x, axis=[1, 2][, keepdims=True]) at models/resnet_v1_5.py:72-73 and
+        models/efficientnet.py:183."""
         n, h, w, c = x.shape
-        y = self.graph.tensor((n, c), x.dtype, self.scope_name('avgpool'))
+        y = self.graph.tensor((n, 1, 1, c) if keepdims else (n, c), x.dtype, self.scope_name('avgpool'))
         self.graph.node('gap', [x], [y], scope=self.scope_name())
         return y
 
+    def channel_scale(self, x, mask):
+        """Stand-in for `x = x*se_mask` (models/efficientnet.py:161): mask [N,1,1,C] broadcast over H, W."""
+        assert mask.shape[0] == x.shape[0] and mask.shape[-1] == x.shape[-1] and mask.numel == x.shape[0] * x.shape[-1]
+        y = self.graph.tensor(x.shape, x.dtype, self.scope_name('se_scale'), self._channel_first)
+        self.graph.node('chscale', [x, mask], [y], scope=self.scope_name())
+        return y
+
+    def _random_mask(self, x, kind, rate, name):
+        """y = x * mask, mask drawn on the host each training step (sample_random_masks); identity in evaluation.
+        kind 'sample': survived[n]/(1-rate) (stochastic depth); 'element': keep[n,c]/(1-rate) (dropout on [N,C])."""
+        y = self.graph.tensor(x.shape, x.dtype, self.scope_name(name), self._channel_first)
+        nd = self.graph.node('mulmask', [x], [y], scope=self.scope_name(name), kind=kind, rate=float(rate))
+        self._random_nodes.append(nd)
+        return y
+
+    def sample_random_masks(self, masks=None):
+        """Draw the dropout / stochastic-depth masks of the next training step (tf.random.uniform at convnet.py:2507,
+        tf.nn.dropout) and upload them.  `masks` ({node scope: array}) overrides the draw (parity tests feed the
+        oracle's masks)."""
+        if masks is None:
+            masks = getattr(self, 'fixed_random_masks', None)      # tests pin the draw
+        for nd in self._random_nodes:
+            x = nd.inputs[0]
+            rate = nd.attrs['rate']
+            if masks is not None and nd.scope in masks:
+                keep = np.asarray(masks[nd.scope], dtype=np.float32)
+            elif nd.attrs['kind'] == 'sample':
+                keep = (self._mask_rng.random(x.shape[0]) >= rate).astype(np.float32) / (1.0 - rate)
+            else:
+                keep = (self._mask_rng.random((x.shape[0], x.shape[-1])) >= rate).astype(np.float32) / (1.0 - rate)
+            dev = nd.attrs.get('mask')
+            if dev is None:
+                continue                                               # not compiled yet
+            if nd.attrs['kind'] == 'sample':
+                keep = np.repeat(keep.reshape(-1, 1), dev.shape[1], axis=1)
+            dev.copy_(torch.from_numpy(np.ascontiguousarray(keep)).to(dev.dtype))
+
     def dropout(self, x, rate):
-        """Stand-in for tf.nn.dropout at models/resnet_v1_5.py:75; rate 0 (the default) is the identity."""
+        """Stand-in for tf.nn.dropout at models/resnet_v1_5.py:75 / models/efficientnet.py:121 (on the pooled [N,C]
+        features); rate 0 (the default) is the identity."""
         if rate and rate > 0.0:
-            raise NotImplementedError('dropout with rate > 0 is not built yet (SURVEY §8f-4)')
+            if len(x.shape) != 2:
+                raise NotImplementedError('dropout is built for the pooled [N, C] features only')
+            return self._random_mask(x, 'element', rate, 'dropout')
         return x
 
     def softmax(self, x):
@@ -577,7 +673,8 @@ class ConvNet(object):
     def stochastic_depth(self, x, skip, drop_rate=0.0, name='drop'):
         """reference convnet.py:2500-2512; drop_rate 0 -> x + skip."""
         if drop_rate > 0.0:
-            raise NotImplementedError('stochastic depth with drop_rate > 0 is a SURVEY §8f-2 row')
+            with self.variable_scope(name):
+                x = self._random_mask(x, 'sample', drop_rate, 'survived')
         assert x.shape == skip.shape, 'residual shapes differ: {} vs {}'.format(x.shape, skip.shape)
         y = self.graph.tensor(x.shape, x.dtype, self.scope_name('add'), self._channel_first)
         self.graph.node('add', [x, skip], [y], scope=self.scope_name())
@@ -587,9 +684,27 @@ class ConvNet(object):
         """reference convnet.py:2514-2534."""
         if activation_type is None:
             return x
-        if activation_type.lower() == 'relu':
+        act = activation_type.lower()
+        if act == 'relu':
             return self.relu(x, name=activation_type)
-        raise NotImplementedError('activation {} is outside the built path (supported: relu)'.format(activation_type))
+        if act == 'swish':
+            return self.swish(x, name=activation_type)
+        if act == 'sigmoid':
+            return self.sigmoid(x, name=activation_type)
+        raise NotImplementedError('activation {} is outside the built path (supported: relu, swish, sigmoid)'.format(activation_type))
+
+    def _act(self, x, kind, name):
+        y = self.graph.tensor(x.shape, x.dtype, self.scope_name(name), self._channel_first)
+        self.graph.node('act', [x], [y], scope=self.scope_name(), kind=kind)
+        return y
+
+    def sigmoid(self, x, name=None):
+        """reference convnet.py:2549-2550 -> tf.nn.sigmoid."""
+        return self._act(x, _ffi.ACT_SIGMOID, name or 'sigmoid')
+
+    def swish(self, x, name='swish'):
+        """reference convnet.py:2552-2556: x*sigmoid(x)."""
+        return self._act(x, _ffi.ACT_SWISH, name)
 
     def relu(self, x, name='relu'):
         """reference convnet.py:2536-2537 -> tf.nn.relu."""

@@ -127,6 +127,65 @@ extern "C" int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, 
     return MCN_OK;
 }
 
+// ---- gradient clipping by global norm (tf.clip_by_global_norm, optimizers.py:112-113) ------------------------
+// The reference clips the gradient of the FULL loss (cross-entropy + L2 term), per tower, before the tower mean; here
+// the L2 gradient normally rides in the optimizer kernel, so with clipping it is folded into g first.
+__global__ __launch_bounds__(256) void clip_prepare_kernel(float* __restrict__ g, const float* __restrict__ w, long n, long n_l2, float l2,
+                                                           float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = g[i];
+        if (i < n_l2) {
+            v = fmaf(l2, w[i], v);
+            g[i] = v;
+        }
+        s = fmaf(v, v, s);
+    }
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void clip_final_kernel(const float* __restrict__ part, int nparts, float thr, float* __restrict__ out) {
+    __shared__ double shd[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += (double)part[i];
+    shd[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(shd[0]);
+        out[0] = thr / fmaxf(norm, thr);
+        out[1] = norm;
+    }
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ sc, float* __restrict__ norm_out) {
+    const float f = sc[0];
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = sc[1];
+    if (f == 1.f) return;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= f;
+}
+extern "C" int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int64_t n_l2, float l2, float threshold, float* norm_out, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    if (!g || n < 0 || n_l2 < 0 || n_l2 > n || !(threshold > 0.f) || (n_l2 > 0 && l2 != 0.f && !w)) MCN_FAIL(MCN_E_BADARG, "clip_by_global_norm: bad argument");
+    if (!ws || ws_bytes < (L2_BLOCKS + 4) * sizeof(float)) MCN_FAIL(MCN_E_WORKSPACE, "clip_by_global_norm: workspace needs %zu bytes", (size_t)(L2_BLOCKS + 4) * sizeof(float));
+    if (n == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* sc = part + L2_BLOCKS;
+    hipLaunchKernelGGL(clip_prepare_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, g, w, (long)n, (long)(l2 != 0.f ? n_l2 : 0), l2, part);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(clip_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, L2_BLOCKS, threshold, sc);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, g, (long)n, (const float*)sc, norm_out);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
 // ---- fused Nesterov momentum + L2 + EMA + decoupled decay ----------------------------------------------------
 template <bool EMA>
 __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ a,

@@ -129,6 +129,11 @@ class DataParallel(object):
     def finish(self):
         self.reducer.finish()
 
+    def reduce_all(self):
+        """One blocking all-reduce of the whole flat gradient (used when the gradients must be complete before the
+        exchange: per-tower clipping by global norm, optimizers.py:112-113)."""
+        dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM)
+
     def gather_bn_stats(self):
         if dist.get_backend() == 'nccl':
             dist.all_gather_into_tensor(self.gathered_stats.view(-1), self.model.batch_stats)

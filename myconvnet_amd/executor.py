@@ -46,6 +46,8 @@ class Lowering(object):
                         gm.tile = t
                         need = max(need, lib.mcn_conv2d_workspace_bytes(op, ctypes.byref(gm), self.dt))
                     gm.tile = keep
+            elif n.op == 'dwconv':
+                need = max(need, lib.mcn_dwconv2d_workspace_bytes(ctypes.byref(n.attrs['geom']), self.dt))
             elif n.op == 'bn':
                 x = n.inputs[0]
                 need = max(need, lib.mcn_bn_workspace_bytes(x.numel // x.shape[-1], x.shape[-1]))
@@ -226,6 +228,79 @@ class Lowering(object):
         if x.needs_grad:
             self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), dst,
                                                              ctypes.byref(gm), acc, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes))
+
+    # ---- depthwise conv / squeeze-excite (EfficientNet MBConv, models/efficientnet.py:126-197) ----------------------
+    def fwd_dwconv(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.fwd.add(lib.mcn_dwconv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), y.buf.data_ptr(), ctypes.byref(n.attrs['geom']), self.dt)
+
+    def bwd_dwconv(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        w = n.attrs['w']
+        gm = n.attrs['geom']
+        if w.trainable:
+            self.bwd.add(lib.mcn_dwconv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(), ctypes.byref(gm), 1.0 / self.loss_scale,
+                         self.dt, self.ws_ptr, self.ws_bytes)
+            self.bwd.mark(('grad_ready', (w.name,)))
+        if x.needs_grad:
+            self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_dwconv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), dst, ctypes.byref(gm), acc,
+                                                             self.dt))
+
+    def fwd_chscale(self, n):
+        x, m, y = n.inputs[0], n.inputs[1], n.outputs[0]
+        N, H, W, C = x.shape
+        self.fwd.add(lib.mcn_channel_scale_fwd, x.buf.data_ptr(), m.buf.data_ptr(), y.buf.data_ptr(), N, H * W, C, MCN_DT[x.dtype])
+
+    def bwd_chscale(self, n):
+        x, m, y = n.inputs[0], n.inputs[1], n.outputs[0]
+        N, H, W, C = x.shape
+        dt = MCN_DT[x.dtype]
+        post = []
+
+        def target(t, key):
+            if t.id not in self.written:
+                self.written.add(t.id)
+                return t.grad.data_ptr()
+            s = self.scratch_like(t, key)
+            post.append((t.grad.data_ptr(), s.data_ptr(), t.grad.numel(), MCN_DT[t.dtype]))
+            return s.data_ptr()
+        dx = target(x, 'chscale_dx') if x.needs_grad else self.scratch_like(x, 'chscale_dx').data_ptr()
+        dm = target(m, 'chscale_dm') if m.needs_grad else self.scratch_like(m, 'chscale_dm').data_ptr()
+        self.bwd.add(lib.mcn_channel_scale_bwd, y.grad.data_ptr(), x.buf.data_ptr(), m.buf.data_ptr(), dx, dm, N, H * W, C, dt)
+        for a in post:
+            self.bwd.add(lib.mcn_accumulate, *a)
+
+    def fwd_act(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.fwd.add(lib.mcn_act_fwd, x.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel(), n.attrs['kind'], MCN_DT[x.dtype])
+
+    def bwd_act(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_act_bwd, y.grad.data_ptr(), x.buf.data_ptr(), y.buf.data_ptr(), dst,
+                                                                y.buf.numel(), n.attrs['kind'], MCN_DT[x.dtype]))
+
+    def _mulmask_args(self, n):
+        """dropout / stochastic depth through the channel-scale kernel: [N, HW, C] * mask[N, C] with, for the per-sample
+        factor, the tensor viewed as [N, numel/N/ce, ce] and the factor replicated over one 16-byte chunk."""
+        x = n.inputs[0]
+        mask = n.attrs['mask']
+        N = x.shape[0]
+        cols = mask.shape[1]
+        return mask.data_ptr(), N, x.numel // N // cols, cols
+
+    def fwd_mulmask(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        dt = MCN_DT[x.dtype]
+        if not self.train:                                           # evaluation: rate 0 (convnet.py:155-158, 2505)
+            self.fwd.add(lib.mcn_cast, x.buf.data_ptr(), dt, y.buf.data_ptr(), dt, y.buf.numel())
+            return
+        mp, N, HW, C = self._mulmask_args(n)
+        self.fwd.add(lib.mcn_channel_scale_fwd, x.buf.data_ptr(), mp, y.buf.data_ptr(), N, HW, C, dt)
+
+    def bwd_mulmask(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        mp, N, HW, C = self._mulmask_args(n)
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_channel_scale_fwd, y.grad.data_ptr(), mp, dst, N, HW, C, MCN_DT[x.dtype]))
 
     # ---- batch norm --------------------------------------------------------------------------------------------
     def fwd_bn(self, n):

@@ -219,7 +219,7 @@ class Graph(object):
 
     # ---- fusion -----------------------------------------------------------------------------------
     def fuse(self):
-        """bn -> relu, bn -> add(skip) [-> relu]: the activation and the residual add run inside the
+        """bn -> relu, bn -> swish, bn -> add(skip) [-> relu]: the activation and the residual add run inside the
         BN apply pass (one read + one write instead of three / five)."""
         alive = list(self.nodes)
 
@@ -249,6 +249,15 @@ class Graph(object):
                         alive.remove(add)
                         changed = True
                         break
+                if n.attrs.get('skip') is None and sole_consumer(y, 'act') and y.consumers[0].attrs['kind'] == _ffi.ACT_SWISH:
+                    sw = y.consumers[0]                     # bn -> swish (every EfficientNet conv): one apply pass
+                    n.attrs['act'] = _ffi.ACT_SWISH
+                    y.alias_of = sw.outputs[0]
+                    n.outputs[0] = sw.outputs[0]
+                    sw.outputs[0].producer = n
+                    alive.remove(sw)
+                    changed = True
+                    break
                 if sole_consumer(y, 'relu'):
                     relu = y.consumers[0]
                     n.attrs['act'] = _ffi.ACT_RELU

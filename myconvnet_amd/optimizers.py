@@ -35,8 +35,6 @@ class Optimizer(object):
         self.augment_train = kwargs.get('augment_train', False)
         self.init_learning_rate = kwargs.get('base_learning_rate', 0.1) * self.batch_size / 256
         self.gradient_threshold = kwargs.get('gradient_threshold', None)
-        if self.gradient_threshold is not None:
-            raise NotImplementedError('gradient clipping is a SURVEY §8f-4 row, not built yet')
         self.warmup_epoch = kwargs.get('learning_warmup_epochs', kwargs.get('learning_warmup_epoch', 1.0))
         self.decay_method = kwargs.get('learning_rate_decay_method', None)
         self.decay_params = kwargs.get('learning_rate_decay_params', (0.94, 2))
@@ -90,6 +88,13 @@ class Optimizer(object):
             P.add(lib.mcn_sgd_nesterov_fused, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
                   (ema_w + off) if ema_w else 0, n - nw, 0.0, self.momentum, 0.0, 0.0, 0.0, 1.0)
         self._sgd_calls = [args for _, args in P.calls]
+        # per-tower clipping by global norm (optimizers.py:112-113): folds the L2 gradient into g, then scales
+        self._clip = Program()
+        if self.gradient_threshold is not None:
+            self.grad_norm = torch.zeros(1, dtype=torch.float32, device=m.device)
+            low = m._train_low
+            self._clip.add(lib.mcn_clip_by_global_norm, st.grad.data_ptr(), st.data.data_ptr(), n, nw, self.l2_reg, float(self.gradient_threshold),
+                           self.grad_norm.data_ptr(), low.ws_ptr, low.ws_bytes)
         # EMA of the BN running statistics (pre-assign value), launched before the forward pass
         self._pre = Program()
         if self.use_ema and m.stats.size > 0:
@@ -116,6 +121,8 @@ class Optimizer(object):
             args[9] = d
             args[10] = gscale
             args[8] = wd if (i == 0 and m.n_l2_elems > 0) else 0.0
+            if self.gradient_threshold is not None:
+                args[7] = 0.0                            # the L2 gradient was folded into g by mcn_clip_by_global_norm
         if len(self._pre):
             self._pre.calls[0][1][3] = d
         return lr
@@ -129,14 +136,24 @@ class Optimizer(object):
         self._set_hyper()
         sp = m.stream_ptr()
         self._pre.run(sp)
+        if m._random_nodes:
+            m.sample_random_masks()
         m.forward(train=True)
+        clip = len(self._clip) > 0
         if self.dp is not None:
             self.dp.gather_bn_stats()
             self._post_fwd.run(sp)
-            m.backward(self.dp.hooks())
-            self.dp.finish()
+            if clip:                                     # towers clip their own gradient before the mean
+                m.backward()
+                self._clip.run(sp)
+                self.dp.reduce_all()
+            else:
+                m.backward(self.dp.hooks())
+                self.dp.finish()
         else:
             m.backward()
+            if clip:
+                self._clip.run(sp)
         self.optimization_operation.run(sp)
         m.global_step += 1
         if fetch:

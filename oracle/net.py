@@ -153,6 +153,13 @@ class Tape(object):
         self.bw.append(lambda: x.acc(ops.sample_scale_fwd(y.g, s.astype(x.a.dtype))))
         return y
 
+    def mul_const(self, x, m):
+        """x * m with a constant mask of x's shape (tf.nn.dropout with the keep mask already scaled by 1/(1-rate))."""
+        m = m.astype(x.a.dtype)
+        y = V(x.a * m, self.quant)
+        self.bw.append(lambda: x.acc(y.g * m))
+        return y
+
     def mean_keepdims(self, x):
         """tf.reduce_mean(x, [1,2], keepdims=True) (models/efficientnet.py:183)."""
         n, c = x.a.shape[0], x.a.shape[-1]
@@ -330,6 +337,7 @@ class EfficientNetSpec(object):
         self.backbone_only = backbone_only
         self.initial_drop_rate, self.final_drop_rate = initial_drop_rate, final_drop_rate
         self.survival = {}            # unit name -> per-sample factor array (set by the test when drop rates > 0)
+        self.dropout_mask = None      # [N, C] keep/(1-rate) mask on the pooled features (models/efficientnet.py:121)
 
     @staticmethod
     def b0(num_classes=1000, width_div=1, depth_div=1):
@@ -423,6 +431,8 @@ class EfficientNetSpec(object):
             return h
         h = t.global_avgpool(h)
         d['logits/avgpool'] = h
+        if self.dropout_mask is not None and t.train:
+            h = t.mul_const(h, self.dropout_mask)
         logits = t.fc(h, 'block_None/logits')
         d['logits'] = logits
         return logits
@@ -566,6 +576,10 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
     for (xr, yf) in towers:
         t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant)
         g = t.backward()
+        if hp.get('gradient_threshold') is not None:
+            # the reference differentiates the full loss (CE + L2) and clips per tower (optimizers.py:106-113)
+            g = {k: (v + hp['l2_reg'] * state.params[k] if k.endswith('/weights') else v) for k, v in g.items()}
+            g, _ = ops.clip_by_global_norm(g, hp['gradient_threshold'])
         grads_sum = g if grads_sum is None else {k: grads_sum[k] + g[k] for k in g}
         losses.append(loss)
         preds.append(pred)
@@ -587,7 +601,7 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
     for k in state.params:
         is_w = k.endswith('/weights')
         w, a, e = ops.sgd_nesterov_step(state.params[k], grads[k], state.accum[k], lr, hp['momentum'],
-                                        l2=hp['l2_reg'] if is_w else 0.0, ema=state.ema[k], ema_d=d,
+                                        l2=hp['l2_reg'] if (is_w and hp.get('gradient_threshold') is None) else 0.0, ema=state.ema[k], ema_d=d,
                                         wd=wd if is_w else 0.0)
         dt = state.params[k].dtype
         state.params[k], state.accum[k], state.ema[k] = w.astype(dt), a.astype(dt), e.astype(dt)

@@ -472,6 +472,13 @@ def sgd_nesterov_step(w, g, accum, lr, momentum=0.9, l2=0.0, ema=None, ema_d=Non
     return w, accum, ema
 
 
+def clip_by_global_norm(grads, threshold):
+    """tf.clip_by_global_norm (optimizers.py:113): g * t / max(||g||, t) with ||g|| over ALL arrays of the dict."""
+    norm = np.sqrt(sum(float((np.asarray(g, dtype=np.float64) ** 2).sum()) for g in grads.values()))
+    f = threshold / max(norm, threshold)
+    return {k: g * f for k, g in grads.items()}, norm
+
+
 def lr_multiplier(curr_step, steps_per_epoch, num_epochs, warmup_epoch=1.0, decay_method=None,
                   decay_params=(0.94, 2), curr_epoch=1):
     """optimizers.py:608-632."""

@@ -78,10 +78,31 @@ def test_unbuilt_features_fail_loudly():
     with pytest.raises(NotImplementedError):
         M.ResNet50([32, 32, 3], 10, batch_size=2, norm_type='group', auto_compile=False)
     with pytest.raises(NotImplementedError):
-        M.ResNet50([32, 32, 3], 10, batch_size=2, dropout_rate=0.3, auto_compile=False)
+        M.ResNet50([32, 32, 3], 10, batch_size=2, dropout_rate=0.3, dropout_weights=True, auto_compile=False)
+    net = M.ResNet50([32, 32, 3], 10, batch_size=2, dropout_rate=0.3, auto_compile=False)     # feature dropout is built
+    assert [n.attrs['kind'] for n in net._random_nodes] == ['element']
     net = M.ResNet50([32, 32, 3], 10, batch_size=2, auto_compile=False)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         net.compile()
+
+
+def test_efficientnet_b0_inventory_matches_reference_counts():
+    """EfficientNet-B0: 5,288,548 parameters is the published count for the architecture the reference
+    builds (models/efficientnet.py:10-17); variable names / shapes are the oracle's independent restatement."""
+    from oracle import net as ON
+    m = M.EfficientNetB0([224, 224, 3], 1000, batch_size=4, auto_compile=False, device='cpu')
+    assert m.params == 5288548
+    spec = ON.EfficientNetSpec.b0(1000)
+    assert sorted((n, tuple(s)) for n, s, _ in spec.variables()) == sorted((v.name, tuple(v.shape)) for v in m._var_order)
+    assert m.block_list == [None, 0, 1, 2, 3, 4, 5, 6, 7, 8]
+    ops = [n.op for n in m.graph.nodes]
+    assert ops.count('dwconv') == 16 and ops.count('chscale') == 16 and ops.count("conv") == 1 + 15 + 16 + 32 + 1
+    b3 = M.EfficientNetB3([300, 300, 3], 1000, batch_size=2, auto_compile=False, device='cpu')
+    assert b3.channels == [40, 24, 32, 48, 96, 136, 232, 384, 1536] and b3.conv_units == [None, 2, 3, 3, 5, 5, 6, 2, None]
+    # stochastic depth: linearly increasing drop rate, one per-sample mask per residual unit
+    sd = M.EfficientNetB0([64, 64, 3], 10, batch_size=4, final_drop_rate=0.2, auto_compile=False, device='cpu')
+    rates = [n.attrs['rate'] for n in sd._random_nodes]
+    assert len(rates) == 9 and rates[0] == pytest.approx(0.2 * 2 / 7) and rates[-1] == pytest.approx(0.2 * 6 / 7)
 
 
 def test_lr_schedule_matches_reference_formulas():
