@@ -273,6 +273,9 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     };
 
     const int nk = (p.nchunks + 7) >> 3;
+#ifdef MCN_ABL_NOCOMMIT
+    int abl_sink = 0;
+#endif
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     issue(0, S0{});
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     // one K-step: LDS buffer `buf` holds step ks, register set CS holds step ks+1 (in flight), set IS is free
     auto kstep = [&](int ks, int buf, auto cs, auto is) {
         const char* base = smem + buf * TILE_BYTES;
-#ifndef MCN_ABL_NOLOAD
+#if !defined(MCN_ABL_NOLOAD) && !defined(MCN_ABL_NOISSUE)
         if (ks + 2 < nk) issue(ks + 2, is);
 #endif
 #pragma unroll
@@ -294,7 +297,15 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
             load_frags((s + 1) & 1, s + 1, base);
             mma_set(s & 1);
         }
-#ifndef MCN_ABL_NOLOAD
+#if defined(MCN_ABL_NOCOMMIT)
+        if (ks + 1 < nk) {                                   // ablation: keep the global loads alive without the LDS writes
+            constexpr int S = decltype(cs)::value;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) abl_sink ^= ra[S][i][0] ^ ra[S][i][3];
+#pragma unroll
+            for (int i = 0; i < BR; ++i) abl_sink ^= rb[S][i][0] ^ rb[S][i][3];
+        }
+#elif !defined(MCN_ABL_NOLOAD)
         if (ks + 1 < nk) commit(buf ^ 1, cs);
 #endif
 #ifndef MCN_ABL_NOBARRIER
@@ -308,6 +319,9 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
         if (ks + 1 < nk) kstep(ks + 1, 1, S0{}, S1{});
     }
 
+#ifdef MCN_ABL_NOCOMMIT
+    if (abl_sink == 0x12345678) acc[0][0][0] += 1.f;
+#endif
 #ifdef MCN_ABL_STAMP
     st_t2 = __builtin_amdgcn_s_memtime();
 #endif

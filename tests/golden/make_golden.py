@@ -1,6 +1,6 @@
 """Generates tests/golden/*.npz from the NumPy oracle (float64 math, stored as float32/float64).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [ops] [resnet50_w8] [mbconv]
 
 PARITY UNPINNED: the reference has no golden vectors and cannot run here, so these fixtures freeze
 the oracle's answers — they guard the oracle against regressions and give the GPU tests fixed inputs/outputs that
@@ -125,8 +125,78 @@ def golden_net():
     return out
 
 
+# name: (n, h, w, c, k, stride, padding)  — EfficientNet row
+DW_CASES = {
+    'dw3x3_s1': (2, 8, 8, 16, 3, 1, 'SAME'),
+    'dw3x3_s2_even': (2, 12, 12, 24, 3, 2, 'SAME'),
+    'dw5x5_s2_odd': (2, 9, 9, 16, 5, 2, 'SAME'),
+    'dw5x5_s1': (1, 7, 7, 40, 5, 1, 'SAME'),
+}
+
+
+def effnet_params(spec, seed=4):
+    params, stats = ON.init_variables(spec.variables(), seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(10)
+    for k in params:
+        if k.endswith('gamma'):
+            lo, span = (0.1, 0.2) if 'conv_2/norm' in k else (0.8, 0.4)
+            params[k] = (lo + span * rng.random(params[k].shape)).astype(np.float32)
+        if k.endswith('beta') or k.endswith('biases'):
+            params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    return params, stats
+
+
+def golden_mbconv():
+    """Depthwise conv, swish / sigmoid, squeeze-excite scale and two training steps of EfficientNet-B0 (width/2, depth/2,
+    10 classes, N=8, 64x64) with stochastic depth and dropout masks stored in the fixture."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    for name, (n, h, w, c, k, s, pad) in DW_CASES.items():
+        x = f32(rng.standard_normal((n, h, w, c)))
+        wt = f32(rng.standard_normal((k, k, c, 1)) / k)
+        y = O.depthwise_conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), s, pad)
+        dy = f32(rng.standard_normal(y.shape))
+        out.update({name + '/x': x, name + '/w': wt, name + '/dy': dy, name + '/y': f32(y),
+                    name + '/dx': f32(O.depthwise_conv2d_dgrad(dy.astype(np.float64), wt.astype(np.float64), x.shape, s, pad)),
+                    name + '/dw': f32(O.depthwise_conv2d_wgrad(x.astype(np.float64), dy.astype(np.float64), wt.shape, s, pad))})
+    x = f32(3 * rng.standard_normal((4, 40)))
+    dy = f32(rng.standard_normal(x.shape))
+    out.update({'act/x': x, 'act/dy': dy, 'act/swish': f32(O.swish_fwd(x.astype(np.float64))), 'act/swish_dx': f32(O.swish_bwd(dy.astype(np.float64), x.astype(np.float64))),
+                'act/sigmoid': f32(O.sigmoid_fwd(x.astype(np.float64)))})
+    x, m, dy = f32(rng.standard_normal((3, 5, 5, 16))), f32(rng.random((3, 1, 1, 16))), f32(rng.standard_normal((3, 5, 5, 16)))
+    dx, dm = O.channel_scale_bwd(dy.astype(np.float64), x.astype(np.float64), m.astype(np.float64))
+    out.update({'se/x': x, 'se/m': m, 'se/dy': dy, 'se/y': f32(O.channel_scale_fwd(x.astype(np.float64), m.astype(np.float64))), 'se/dx': f32(dx), 'se/dm': f32(dm)})
+    # whole network
+    spec = ON.EfficientNetSpec.b0(10, width_div=2, depth_div=2)
+    spec.final_drop_rate = 0.3
+    params, stats = effnet_params(spec)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    out['net/param_checksum'] = np.array([sum(float(v.astype(np.float64).sum()) for v in params.values()),
+                                          sum(float((v.astype(np.float64) ** 2).sum()) for v in params.values())])
+    keys = sorted(params)
+    units = [(name, dr) for name, k, s, cin, cout, mult, dr in spec.units() if s == 1 and cin == cout]
+    for step in range(2):
+        x8 = rng.integers(0, 256, (8, 64, 64, 3)).astype(np.uint8)
+        x = f32(x8) / np.float32(255)
+        y = rng.integers(0, 10, 8).astype(np.float32)
+        surv = np.stack([(rng.random(8) >= dr).astype(np.float32) / np.float32(1.0 - dr) for _, dr in units])
+        drop = (rng.random((8, spec.channels[-1])) >= 0.25).astype(np.float32) / np.float32(0.75)
+        spec.survival = {name: surv[i].astype(np.float64) for i, (name, _) in enumerate(units)}
+        spec.dropout_mask = drop.astype(np.float64)
+        loss, pred, grads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=8)
+        p = 'net/step{}/'.format(step)
+        out.update({p + 'x_u8': x8, p + 'y': y, p + 'survival': surv, p + 'dropout': drop, p + 'loss': np.float64(loss), p + 'pred': f32(pred),
+                    p + 'argmax': pred.argmax(-1).astype(np.int32), p + 'grad_norms': np.array([np.linalg.norm(grads[k]) for k in keys]),
+                    p + 'param_norms': np.array([np.linalg.norm(state.params[k]) for k in keys])})
+    out['net/keys'] = np.array(keys)
+    out['net/units'] = np.array([u for u, _ in units])
+    return out
+
+
 if __name__ == '__main__':
-    np.savez_compressed(os.path.join(HERE, 'ops.npz'), **golden_ops())
-    np.savez_compressed(os.path.join(HERE, 'resnet50_w8.npz'), **golden_net())
-    for f in ('ops.npz', 'resnet50_w8.npz'):
+    which = sys.argv[1:] or ['ops', 'resnet50_w8', 'mbconv']
+    makers = {'ops': golden_ops, 'resnet50_w8': golden_net, 'mbconv': golden_mbconv}
+    for w in which:
+        np.savez_compressed(os.path.join(HERE, w + '.npz'), **makers[w]())
+    for f in [w + '.npz' for w in which]:
         print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

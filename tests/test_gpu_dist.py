@@ -23,17 +23,30 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      MCN_DIST_BACKEND='gloo')
+def _build(kind, world, rank, B):
     import make_golden as MG
     import myconvnet_amd as M
     from oracle import net as ON
-    spec = ON.ResNetSpec.resnet50(10, 8)
-    params, stats = MG.net_params(spec)
+    if kind == 'resnet':
+        spec = ON.ResNetSpec.resnet50(10, 8)
+        params, stats = MG.net_params(spec)
+        model = M.ResNet50([64, 64, 3], 10, batch_size=B * world, width_div=8, num_gpus=world, device='cuda:0', seed=rank) if rank is not None else None
+        hp = {}
+    else:                                              # EfficientNet + per-tower gradient clipping (single blocking all-reduce path)
+        spec = ON.EfficientNetSpec.b0(10, width_div=2, depth_div=2)
+        params, stats = MG.effnet_params(spec)
+        model = M.EfficientNetB0([64, 64, 3], 10, batch_size=B * world, width_div=2, depth_div=2, num_gpus=world, device='cuda:0', seed=rank) if rank is not None else None
+        hp = dict(gradient_threshold=0.5)
+    return spec, params, stats, model, hp
+
+
+def _worker(rank, world, port, q, kind='resnet'):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      MCN_DIST_BACKEND='gloo')
+    import myconvnet_amd as M
     B = 8                                              # per rank; total batch 16 (B=4 towers make the tiny net ill-conditioned in fp32)
-    model = M.ResNet50([64, 64, 3], 10, batch_size=B * world, width_div=8, num_gpus=world, device='cuda:0', seed=rank)  # different init per rank:
-    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, allreduce_bucket_mb=0.2)
+    spec, params, stats, model, hp = _build(kind, world, rank, B)                       # different init per rank (seed=rank):
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, allreduce_bucket_mb=0.2, **hp)
     if rank == 0:                                      # rank 0's variables are broadcast at DataParallel construction...
         pass
     model.set_variables(dict(params, **stats))         # ...then every rank gets the same injected weights
@@ -49,22 +62,21 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_step_matches_multi_tower_oracle():
-    import make_golden as MG
+@pytest.mark.parametrize('kind', ['resnet', 'efficientnet_clip'])
+def test_two_rank_step_matches_multi_tower_oracle(kind):
     from oracle import net as ON
     world = 2
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    spec = ON.ResNetSpec.resnet50(10, 8)
-    params, stats = MG.net_params(spec)
+    spec, params, stats, _, hp = _build(kind, world, None, 8)
     state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
     rng = np.random.default_rng(123)
     B = 8
@@ -72,7 +84,7 @@ def test_two_rank_step_matches_multi_tower_oracle():
         x = rng.random((B * world, 64, 64, 3)).astype(np.float32)
         y = rng.integers(0, 10, B * world).astype(np.float32)
         towers = [(x[r * B:(r + 1) * B].astype(np.float64), y[r * B:(r + 1) * B].astype(np.float64)) for r in range(world)]
-        rloss, rpred, _ = ON.train_step(spec, state, None, None, batch_total=B * world, tower_batches=towers)
+        rloss, rpred, _ = ON.train_step(spec, state, None, None, batch_total=B * world, tower_batches=towers, hp=hp or None)
         for r in range(world):
             loss, pred = res[r][1][step]
             assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, r, loss, rloss)        # mean of tower losses on every rank

@@ -93,3 +93,51 @@ def test_resnet_two_step_golden():
                 assert rel_l2(grads[k], gnet[p + 'grad/' + k]) <= 1e-3, k
     assert rel_l2(data['block_4/res_2/conv_2/bn/mu'], gnet['final/block_4_mu']) <= 1e-4
     assert rel_l2(model.get_variables('ema')['block_None/logits/weights'], gnet['final/ema_logits_w']) <= 1e-5
+
+
+# ---- EfficientNet row (tests/golden/mbconv.npz) ----------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def gmb():
+    return np.load(os.path.join(HERE, 'golden', 'mbconv.npz'))
+
+
+@pytest.mark.parametrize('name', sorted(MG.DW_CASES))
+def test_depthwise_golden(gmb, name):
+    import abi_util as u
+    n, h, w, c, k, s, pad = MG.DW_CASES[name]
+    x, wt, dy = gmb[name + '/x'], gmb[name + '/w'], gmb[name + '/dy']
+    assert rel_l2(u.dwconv_fwd(x, wt, s, pad), gmb[name + '/y']) <= 2e-5
+    assert rel_l2(u.dwconv_dgrad(dy, wt, x.shape, s, pad), gmb[name + '/dx']) <= 2e-5
+    assert rel_l2(u.dwconv_wgrad(x, dy, k, s, pad), gmb[name + '/dw']) <= 2e-5
+
+
+def test_efficientnet_two_step_golden(gmb):
+    """Fixed inputs, labels and stochastic-depth / dropout masks from the fixture; loss, predictions, arg-max and the
+    norms of all 109 gradients / parameters after each step."""
+    import myconvnet_amd as M
+    from oracle import net as ON
+    spec = ON.EfficientNetSpec.b0(10, width_div=2, depth_div=2)
+    params, stats = MG.effnet_params(spec)
+    model = M.EfficientNetB0([64, 64, 3], 10, batch_size=8, width_div=2, depth_div=2, final_drop_rate=0.3, dropout_rate=0.25, num_gpus=1)
+    model.set_variables(dict(params, **stats))
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    keys = [str(k) for k in gmb['net/keys']]
+    units = [str(k) for k in gmb['net/units']]
+    for step in range(2):
+        p = 'net/step{}/'.format(step)
+        masks = {u + '/drop/survived': gmb[p + 'survival'][i] for i, u in enumerate(units)}
+        masks['block_None/logits/dropout'] = gmb[p + 'dropout']
+        assert set(masks) == set(n.scope for n in model._random_nodes)
+        model.fixed_random_masks = masks
+        model.feed(gmb[p + 'x_u8'].astype(np.float32) / np.float32(255), gmb[p + 'y'])
+        loss, _, pred = opt._step(None)
+        assert abs(loss - float(gmb[p + 'loss'])) <= 1e-4 * abs(float(gmb[p + 'loss']))
+        assert rel_l2(pred, gmb[p + 'pred']) <= 1e-4
+        np.testing.assert_array_equal(pred.argmax(-1), gmb[p + 'argmax'])
+        grads, data = model.get_variables('grad'), model.get_variables('data')
+        ref = gmb[p + 'grad_norms']
+        got = np.array([np.linalg.norm(grads[k]) for k in keys])
+        live = ref > 1e-6 * np.median(ref)                     # exact-zero gradients (see test_gpu_efficientnet.worst_grad)
+        np.testing.assert_allclose(got[live], ref[live], rtol=1e-3)
+        assert (got[~live] <= 1e-4 * np.median(ref)).all()
+        np.testing.assert_allclose([np.linalg.norm(data[k]) for k in keys], gmb[p + 'param_norms'], rtol=1e-5)
