@@ -37,19 +37,25 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32')
-    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 256; 512 for --model efficientnet_b0)')
+    ap.add_argument('--model', default='resnet50', choices=['resnet50', 'efficientnet_b0'],
+                    help='resnet50 = the headline workload (BASELINE configs[1]/[2]); efficientnet_b0 = configs[3] (secondary, SURVEY 8f-2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per layer at start-up (untimed) instead of the library heuristic')
     ap.add_argument('--no-overlap', action='store_true', help='run wgrad on the main stream (serial kernels: the rocprofv3 per-kernel averages then equal the roofline object)')
     ap.add_argument('--layers', action='store_true', help='print a per-launch table (stderr) from the instrumented pass')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 512 if args.model == 'efficientnet_b0' else 256
+    return args
 
 
 def build_model(args, dtype, world):
     import myconvnet_amd as M
-    model = M.ResNet50([224, 224, 3], 1000, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
+    cls = M.EfficientNetB0 if args.model == 'efficientnet_b0' else M.ResNet50
+    model = cls([224, 224, 3], 1000, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
                        seed=0, overlap_wgrad=not args.no_overlap, device='cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90,
                               update_ema=not args.no_ema)
@@ -229,6 +235,22 @@ def main():
     dt = timed(opt, args.steps, args.warmup, world, args.autotune)
     ms = dt / args.steps * 1e3
     ips = args.batch * world * args.steps / dt
+    if args.model == 'efficientnet_b0':
+        # secondary workload: no MFMA roofline claim (depthwise / BN / SE are HBM-bound); per-call times from the instrumented pass
+        out = {'metric': 'images/sec EfficientNet-B0 224x224 synthetic training step', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+               'config': {'workload': 'EfficientNet-B0 {} 224x224 synthetic ImageNet-1k training step (BASELINE configs[3]), batch={}/GPU'.format(args.dtype, args.batch),
+                          'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world), 'ema': not args.no_ema},
+               'conv_macs_per_image': int(model.conv_macs), 'params': int(model.params)}
+        if world == 1:
+            table = instrumented_pass(model, args.dtype, layers=args.layers)
+            table.pop('_bracket_us')
+            out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:14]}
+            out['kernel_ms_total'] = round(sum(v[1] for v in table.values()), 3)
+        if rank == 0:
+            print(json.dumps(out))
+        return
     out = {
         'metric': 'images/sec ResNet-v1.5-50 224x224 synthetic training step',
         'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -446,7 +446,7 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
     if (!mfma_path_ok(g, dt)) {
         NaiveConvParams p = naive_params(g);
         p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
-        hipLaunchKernelGGL((naive_conv_wgrad<T>), dim3(nblocks((long)g.KH * g.KW * g.Cin * g.Cout)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((naive_conv_wgrad<T>), dim3(nblocks((long)g.KH * g.KW * g.Cin * g.Cout * 8)), dim3(256), 0, st, p);
         MCN_CHECK_LAUNCH();
     } else {
         int nsteps, sps;

@@ -782,30 +782,45 @@ __global__ void naive_conv_dgrad(const NaiveConvParams p) {
         dx[idx] = from_f32<T>(acc);
     }
 }
+// blockDim = (32 weight elements, 8 image slices): the reduction over the batch is split 8 ways and folded through LDS
+// (the squeeze-excite 1x1 convs of EfficientNet land here when their channel counts are not chunk multiples)
 template <typename T>
-__global__ void naive_conv_wgrad(const NaiveConvParams p) {
+__global__ __launch_bounds__(256) void naive_conv_wgrad(const NaiveConvParams p) {
+    __shared__ float red[8][32];
     const long total = (long)p.KH * p.KW * p.Cin * p.Cout;
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* dy = reinterpret_cast<const T*>(p.dy);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % p.Cout);
-        long r = idx / p.Cout;
-        const int c = (int)(r % p.Cin);
-        r /= p.Cin;
-        const int ks = (int)(r % p.KW), kr = (int)(r / p.KW);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (long base = (long)blockIdx.x * 32; base < total; base += (long)gridDim.x * 32) {
+        const long idx = base + tx;
         float acc = 0.f;
-        for (int n = 0; n < p.N; ++n)
-            for (int oy = 0; oy < p.OH; ++oy) {
-                const int iy = oy * p.SH + kr * p.DH - p.padT;
-                if (iy < 0 || iy >= p.H) continue;
-                for (int ox = 0; ox < p.OW; ++ox) {
-                    const int ix = ox * p.SW + ks * p.DW - p.padL;
-                    if (ix < 0 || ix >= p.W) continue;
-                    acc = fmaf(to_f32(x[(((long)n * p.H + iy) * p.W + ix) * p.x_cs + c]),
-                               to_f32(dy[(((long)n * p.OH + oy) * p.OW + ox) * p.Cout + k]), acc);
+        if (idx < total) {
+            const int k = (int)(idx % p.Cout);
+            long r = idx / p.Cout;
+            const int c = (int)(r % p.Cin);
+            r /= p.Cin;
+            const int ks = (int)(r % p.KW), kr = (int)(r / p.KW);
+            for (int n = ty; n < p.N; n += 8)
+                for (int oy = 0; oy < p.OH; ++oy) {
+                    const int iy = oy * p.SH + kr * p.DH - p.padT;
+                    if (iy < 0 || iy >= p.H) continue;
+                    for (int ox = 0; ox < p.OW; ++ox) {
+                        const int ix = ox * p.SW + ks * p.DW - p.padL;
+                        if (ix < 0 || ix >= p.W) continue;
+                        acc = fmaf(to_f32(x[(((long)n * p.H + iy) * p.W + ix) * p.x_cs + c]),
+                                   to_f32(dy[(((long)n * p.OH + oy) * p.OW + ox) * p.Cout + k]), acc);
+                    }
                 }
-            }
-        p.dw[idx] = acc * p.scale;
+        }
+        red[ty][tx] = acc;
+        __syncthreads();
+        if (ty == 0 && idx < total) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += red[j][tx];
+            p.dw[idx] = s * p.scale;
+        }
+        __syncthreads();
     }
 }
 

@@ -177,27 +177,43 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
     }
 }
 
-// global average over HW: [N][HW][C] -> [N][C]
+// global average over HW: [N][HW][C] -> [N][C].  One block per (image, group of TX channel chunks): TY rows of the
+// image are summed in parallel and folded through LDS (the squeeze-excite means of EfficientNet reduce up to 112x112
+// pixels per image; a thread per output would serialise them).
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C, int TX, int TY) {
+    extern __shared__ float gap_red[];                           // [TY][TX*VEC]
     const int cv = C / VEC;
-    const long total = (long)N * cv;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cv) * VEC;
-        const long n = idx / cv;
-        float acc[VEC];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int chunk = blockIdx.x * TX + tx;
+    const long n = blockIdx.y;
+    float acc[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        for (int q = 0; q < HW; ++q) {
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (ty < TY && chunk < cv) {
+        const T* base = x + n * HW * C + (long)chunk * VEC;
+        for (int q = ty; q < HW; q += TY) {
             float v[VEC];
-            pld<T, VEC>(x + (n * HW + q) * C + c, v);
+            pld<T, VEC>(base + (long)q * C, v);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] += v[i];
         }
+    }
+    const int cols = TX * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gap_red[ty * cols + tx * VEC + i] = acc[i];
+    }
+    __syncthreads();
+    if (ty == 0 && chunk < cv) {
         const float inv = 1.f / (float)HW;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] *= inv;
-        pst<T, VEC>(y + n * C + c, acc);
+        for (int i = 0; i < VEC; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < TY; ++k) s += gap_red[k * cols + tx * VEC + i];
+            acc[i] = s * inv;
+        }
+        pst<T, VEC>(y + n * C + (long)chunk * VEC, acc);
     }
 }
 template <typename T, int VEC>
@@ -318,14 +334,21 @@ extern "C" int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t
     if (!x || !y || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "global_avgpool_fwd: bad argument");
     if (N == 0) return MCN_OK;
     hipStream_t st = (hipStream_t)stream;
-    const long total = (long)N * C;
+#define GAP_FWD(T, VEC)                                                                                                        \
+    do {                                                                                                                       \
+        const int cv = C / VEC;                                                                                                \
+        int TX = cv < 32 ? cv : 32;                                                                                            \
+        int TY = 256 / TX;                                                                                                     \
+        if (TY > HW) TY = HW;                                                                                                  \
+        hipLaunchKernelGGL((gap_fwd_kernel<T, VEC>), dim3((unsigned)((cv + TX - 1) / TX), (unsigned)N), dim3(256),           \
+                           (size_t)TY * TX * VEC * sizeof(float), st, (const T*)x, (T*)y, N, HW, C, TX, TY);                   \
+    } while (0)
     if (dtype == MCN_F32) {
-        if (C % 4 == 0) hipLaunchKernelGGL((gap_fwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, N, HW, C);
-        else hipLaunchKernelGGL((gap_fwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, N, HW, C);
+        if (C % 4 == 0) GAP_FWD(float, 4); else GAP_FWD(float, 1);
     } else if (dtype == MCN_BF16) {
-        if (C % 8 == 0) hipLaunchKernelGGL((gap_fwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
-        else hipLaunchKernelGGL((gap_fwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
+        if (C % 8 == 0) GAP_FWD(bf16_t, 8); else GAP_FWD(bf16_t, 1);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_fwd: dtype %d unsupported", (int)dtype);
+#undef GAP_FWD
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
