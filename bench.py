@@ -127,7 +127,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     from myconvnet_amd._ffi import lib, check
     low = model._train_low
     sp = model.stream_ptr()
-    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
     mdt = _ffi.F32 if dtype == 'fp32' else _ffi.BF16
     buf = ctypes.create_string_buffer(128)
     table, rows = {}, {}

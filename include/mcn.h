@@ -130,6 +130,21 @@ int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const
                      float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
                      mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv -> batch-norm fusion: the forward conv accumulates, in its epilogue, the column sums and sums of squares of the
+ * values it stores and writes them as mcn_conv2d_bnstats_rows() partial rows — [rows][3][Cout] fp32: sum(y-p),
+ * sum((y-p)^2) and the shift p over rows_per_partial consecutive pixels each (0 rows = geometry not eligible, use the
+ * plain calls); mcn_bn_fwd_train_fused merges them in double precision and skips the statistics pass over x (one read
+ * of the layer output less per BN; same tf.nn.fused_batch_norm semantics, convnet.py:1883-1914).  Caller-owned buffer. */
+int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* geom, mcn_dtype dtype, int32_t* rows_per_partial);
+int mcn_conv2d_fwd_bnstats(const void* x, const float* w_hwio, const void* w_packed, const float* bias, void* y,
+                           float* stats_partials, const mcn_conv_geom* geom, mcn_dtype dtype, mcn_layout layout,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma,
+                           const float* beta, const void* skip, void* y, float* save_mean, float* save_invstd,
+                           float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum,
+                           int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* replaces tf.nn.fused_batch_norm(is_training=False) (convnet.py:1889-1896, 1916-1923) */
 int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
                      const void* skip, void* y, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype,

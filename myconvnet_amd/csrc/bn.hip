@@ -390,6 +390,131 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     return MCN_OK;
 }
 
+// ---- statistics from conv-epilogue partials -----------------------------------------------------------------------
+// part[(k*3 + {0,1,2})*C + c] = sum(y - p), sum((y - p)^2), p over the rows [k*rpp, min(M, (k+1)*rpp)) of y.
+// Each partial is an accurate fp32 (count, mean, M2) thanks to its own pivot; partials are merged in double as
+// sum n*mean and sum (M2 + n*mean^2).
+#define BN_FOLD_ROWS 512
+__device__ __forceinline__ void fused_partial(const float* __restrict__ part, int k, int C, int c, long M, int rpp, double& sm, double& sq) {
+    long n = M - (long)k * rpp;
+    if (n > rpp) n = rpp;
+    if (n <= 0) return;
+    const double s1 = (double)part[((long)k * 3 + 0) * C + c], s2 = (double)part[((long)k * 3 + 1) * C + c];
+    const double pv = (double)part[((long)k * 3 + 2) * C + c];
+    const double mean = pv + s1 / (double)n;
+    const double m2 = s2 - s1 * s1 / (double)n;
+    sm += (double)n * mean;
+    sq += m2 + (double)n * mean * mean;
+}
+// stage 1 (only for many partials): groups of rpg partial rows -> fold[(g*2 + {0,1})*C + c] (double)
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ part, double* __restrict__ fold, int nparts, int C, long M, int rpp,
+                                                               int rpg) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rpg, r1 = min(nparts, r0 + rpg);
+    double sm = 0.0, sq = 0.0;
+    for (int r = r0; r < r1; ++r) fused_partial(part, r, C, c, M, rpp, sm, sq);
+    fold[((long)blockIdx.y * 2 + 0) * C + c] = sm;
+    fold[((long)blockIdx.y * 2 + 1) * C + c] = sq;
+}
+// stage 2: FOLDED reads the doubles of stage 1, otherwise the raw partials
+template <bool FOLDED>
+__global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kernel(
+    const float* __restrict__ part, const double* __restrict__ fold, int nrows, int rpp, long M, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ batch_mean,
+    float* __restrict__ batch_var, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float* __restrict__ scale,
+    float* __restrict__ shift) {
+    __shared__ double sh[FIN_CH * FIN_LANES * 2];
+    const int cl = threadIdx.x % FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl;
+    const int lane = threadIdx.x / FIN_CH;
+    double sm = 0.0, sq = 0.0;
+    if (c < C) {
+        for (int k = lane; k < nrows; k += FIN_LANES) {
+            if (FOLDED) {
+                sm += fold[((long)k * 2 + 0) * C + c];
+                sq += fold[((long)k * 2 + 1) * C + c];
+            } else {
+                fused_partial(part, k, C, c, M, rpp, sm, sq);
+            }
+        }
+    }
+    sh[(lane * FIN_CH + cl) * 2 + 0] = sm;
+    sh[(lane * FIN_CH + cl) * 2 + 1] = sq;
+    __syncthreads();
+    if (lane != 0 || c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int l = 0; l < FIN_LANES; ++l) {
+        a += sh[(l * FIN_CH + cl) * 2 + 0];
+        b += sh[(l * FIN_CH + cl) * 2 + 1];
+    }
+    const double inv_m = 1.0 / (double)M;
+    const double mean = a * inv_m;
+    double var = b * inv_m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float fmean = (float)mean, finv = (float)invstd;
+    save_mean[c] = fmean;
+    save_invstd[c] = finv;
+    const double ub = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+    if (batch_mean) batch_mean[c] = fmean;
+    if (batch_var) batch_var[c] = (float)ub;
+    if (running_mean) running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * fmean;
+    if (running_var) running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)ub;
+    const float sc = g * finv;
+    scale[c] = sc;
+    shift[c] = bt - fmean * sc;
+}
+
+template <typename T, int VEC>
+static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp, const float* gamma, const float* beta, const void* skip, void* y,
+                          float* save_mean, float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
+                          float momentum, long M, int C, float eps, mcn_act act, void* ws, hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    double* fold = (double*)ws;                                  // BN_FOLD_ROWS*2*C doubles fit the partial area of the workspace
+    float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
+    float* shift = scale + C;
+    const dim3 grid(L.gx, L.gy), block(256);
+    const dim3 fgrid((C + FIN_CH - 1) / FIN_CH), fblock(FIN_CH * FIN_LANES);
+    if (nparts > BN_FOLD_ROWS) {
+        const int rpg = (nparts + BN_FOLD_ROWS - 1) / BN_FOLD_ROWS;
+        const int n = (nparts + rpg - 1) / rpg;
+        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 255) / 256, n), dim3(256), 0, st, parts, fold, nparts, C, M, rpp, rpg);
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL((bn_fwd_finalize_fused_kernel<true>), fgrid, fblock, 0, st, parts, (const double*)fold, n, rpp, M, C, gamma, beta, eps, save_mean,
+                           save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
+    } else {
+        hipLaunchKernelGGL((bn_fwd_finalize_fused_kernel<false>), fgrid, fblock, 0, st, parts, (const double*)nullptr, nparts, rpp, M, C, gamma, beta, eps,
+                           save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
+    }
+    MCN_CHECK_LAUNCH();
+    const int a = (int)act;
+#define BN_APPLY_F(SK, RL)                                                                                                   \
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, (const float*)scale, \
+                       (const float*)shift, M, C, L.TX, L.TY, L.rpb)
+    if (skip) { if (a == 1) BN_APPLY_F(true, 1); else if (a == 2) BN_APPLY_F(true, 2); else BN_APPLY_F(true, 0); }
+    else { if (a == 1) BN_APPLY_F(false, 1); else if (a == 2) BN_APPLY_F(false, 2); else BN_APPLY_F(false, 0); }
+#undef BN_APPLY_F
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta,
+                                      const void* skip, void* y, float* save_mean, float* save_invstd, float* batch_mean, float* batch_var,
+                                      float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps, mcn_act act,
+                                      mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (rows_per_partial <= 0 || (int64_t)nparts * rows_per_partial < M) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: partials do not cover M rows");
+    if (!x || !y || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 4) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: bad argument");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return bn_fwd_fused_t<float, 4>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+    if (dtype == MCN_BF16) {
+        if (C % 8 == 0) return bn_fwd_fused_t<bf16_t, 8>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: bf16 needs C %% 8 == 0");
+    }
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: dtype %d unsupported", (int)dtype);
+}
+
 extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* skip, void* y, float* save_mean,
                                 float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
                                 float momentum, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes,

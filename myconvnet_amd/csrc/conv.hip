@@ -274,10 +274,11 @@ static inline unsigned nblocks(long total, int cap = 8192) {
 // ---- forward -------------------------------------------------------------------------------------------
 template <typename T>
 static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const Geo& g, mcn_dtype dt,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, float* stats = nullptr) {
     const long M = (long)g.N * g.OH * g.OW;
     if (M == 0) return MCN_OK;
     if (!mfma_path_ok(g, dt)) {
+        if (stats) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd_bnstats: geometry takes the fallback kernel (mcn_conv2d_bnstats_rows() == 0)");
         NaiveConvParams p = naive_params(g);
         p.x = x; p.w = w; p.y = y; p.bias = bias;
         hipLaunchKernelGGL((naive_conv_fwd<T>), dim3(nblocks(M * g.Cout)), dim3(256), 0, st, p);
@@ -303,7 +304,7 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
         int rc = launch_pack<T>(pk, st);
         if (rc) return rc;
     }
-    p.in = x; p.wt = w_packed ? w_packed : ws; p.out = y; p.bias = bias;
+    p.in = x; p.wt = w_packed ? w_packed : ws; p.out = y; p.bias = bias; p.stats = stats;
     p.M = (int)M; p.OH = g.OH; p.OW = g.OW; p.IH = g.H; p.IW = g.W; p.Cs = g.xcs;
     p.cpt = Cp / ce; p.ntaps = ntaps; p.nchunks = ntaps * p.cpt; p.sy = g.SH; p.sx = g.SW; p.Nn = g.Cout;
     p.OHf = g.OH; p.OWf = g.OW; p.ldo = g.Cout; p.osy = 1; p.osx = 1; p.oy0 = 0; p.ox0 = 0; p.accumulate = 0;
@@ -327,6 +328,32 @@ extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const void* w_packe
     if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
     if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd: dtype %d unsupported (fp16 reserved; use bf16)", (int)dtype);
+}
+
+// forward conv that also emits the batch-norm statistics partials of its output (consumed by mcn_bn_fwd_train_fused)
+extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dtype, int32_t* rows_per_partial) {
+    Geo g;
+    if (rows_per_partial) *rows_per_partial = 0;
+    if (!gg || geo_from(gg, &g)) return 0;
+    if ((dtype != MCN_F32 && dtype != MCN_BF16) || !mfma_path_ok(g, dtype)) return 0;
+    const long M = (long)g.N * g.OH * g.OW;
+    if (M <= 0) return 0;
+    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
+    if (rows_per_partial) *rows_per_partial = cand[t].bm / 2;
+    return (int32_t)(2 * ((M + cand[t].bm - 1) / cand[t].bm));
+}
+extern "C" int mcn_conv2d_fwd_bnstats(const void* x, const float* w, const void* w_packed, const float* bias, void* y, float* stats_partials,
+                                      const mcn_conv_geom* gg, mcn_dtype dtype, mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd_bnstats: only NHWC activations");
+    if (!x || !w || !y || !stats_partials) MCN_FAIL(MCN_E_BADARG, "conv2d_fwd_bnstats: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st, stats_partials);
+    if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st, stats_partials);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd_bnstats: dtype %d unsupported", (int)dtype);
 }
 
 // ---- dgrad -----------------------------------------------------------------------------------------------

@@ -30,6 +30,8 @@ struct GemmNTParams {
     const void* wt;
     void* out;
     const float* bias;
+    float* stats;           // optional [2*ntm][3][Nn] per-wave-row (sum(y-p), sum((y-p)^2), p) of the stored output y, p = the
+                            // wave row's first pixel (BN statistics; the shift keeps E[y^2]-E[y]^2 cancellation out of fp32)
 #ifdef MCN_ABL_STAMP
     const float* bias_stamp;
 #endif
@@ -108,6 +110,36 @@ struct MmaNT<float> {
 
 // LDS image of an NT tile: rows of 128 bytes, 16-byte chunk c of row r at r*128 + ((c ^ ((r>>1)&7))<<4)
 __device__ __forceinline__ int nt_lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// Halving butterfly over lanes (see the statistics epilogue of conv_gemm_nt): C values left, partner offset O.  All array
+// indices are compile-time constants (a run-time count makes the compiler index the register arrays with select chains).
+template <int C, int O>
+struct LaneFold {
+    static __device__ __forceinline__ void run(float* a, float* b, int lane, int& base, bool& writer) {
+        const bool hi = (lane & O) != 0;
+        if constexpr (C > 1) {
+            constexpr int H = C / 2;
+#pragma unroll
+            for (int t = 0; t < H; ++t) {
+                const float sa = hi ? a[t] : a[t + H], sb = hi ? b[t] : b[t + H];
+                const float ka = hi ? a[t + H] : a[t], kb = hi ? b[t + H] : b[t];
+                a[t] = ka + __shfl_xor(sa, O);
+                b[t] = kb + __shfl_xor(sb, O);
+            }
+            base += hi ? H : 0;
+            LaneFold<H, O / 2>::run(a, b, lane, base, writer);
+        } else {
+            a[0] += __shfl_xor(a[0], O);
+            b[0] += __shfl_xor(b[0], O);
+            writer = writer && !hi;
+            LaneFold<1, O / 2>::run(a, b, lane, base, writer);
+        }
+    }
+};
+template <int C>
+struct LaneFold<C, 0> {
+    static __device__ __forceinline__ void run(float*, float*, int, int&, bool&) {}
+};
 
 // ------------------------------------------------------------------------------------------------
 // conv_gemm_nt
@@ -326,7 +358,30 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     st_t2 = __builtin_amdgcn_s_memtime();
 #endif
     // ---- epilogue: lane holds 4 consecutive output channels of one pixel per register group ----
+    // p.stats: the batch-norm statistics of the layer's output ride here — per-lane sums of the STORED (rounded) values
+    // and of their squares over the wave's pixel tiles, folded across the 16 / 32 lanes that share a channel group and
+    // written as one partial row per (M tile, wave row): the separate read of y by the BN statistics pass disappears.
     T* out = reinterpret_cast<T*>(p.out);
+    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
+    float s1[TN][NG][4], s2[TN][NG][4], piv[TN][NG][4];
+    const bool do_stats = p.stats != nullptr;
+    if (do_stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                const int n = n0 + wn * WTN + j * MM::MT + nl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[j][0][g * 4 + e];
+                    if (p.bias && n < p.Nn) v += p.bias[n + e];
+                    v = to_f32(from_f32<T>(v));                                  // the value as stored
+                    piv[j][g][e] = __shfl(v, lane & ~(MM::MT - 1));            // pixel row 0 of the wave row
+                    s1[j][g][e] = s2[j][g][e] = 0.f;
+                }
+            }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * MM::MT + fr;
@@ -343,7 +398,6 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
         T* orow = out + pix * p.ldo;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
@@ -366,6 +420,14 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
                         o += old;
                     }
                     *dst = o;
+                    if (do_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = o[e] - piv[j][g][e];
+                            s1[j][g][e] += d;
+                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
+                        }
+                    }
                 } else {
                     bf16x4* dst = reinterpret_cast<bf16x4*>(orow + n);
                     if (p.accumulate) {
@@ -375,8 +437,55 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
                     }
                     bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                     *dst = o;
+                    if (do_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = (float)o[e] - piv[j][g][e];
+                            s1[j][g][e] += d;
+                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
+                        }
+                    }
                 }
             }
+        }
+    }
+    if (do_stats) {
+        // Fold over the MT lanes that hold different pixel rows of the same channels with a halving butterfly: at each
+        // step a lane keeps half of its values and receives the partner's copies of that half (V/2 + V/4 + ... shuffles
+        // instead of V per step); when one value is left the remaining steps are plain all-reduce steps.  At the end lane
+        // (lane & (MT-1)) owns the total of flat value index `base` (j, g, e order).
+        constexpr int V = TN * NG * 4;
+        float a[V], b[V];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[(j * NG + g) * 4 + e] = s1[j][g][e];
+                    b[(j * NG + g) * 4 + e] = s2[j][g][e];
+                }
+        int base = 0;
+        bool writer = true;
+        LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
+        const int prow = ((m0 - p.m_begin) / BM) * 2 + wm;
+        const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
+        const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+        const int n = n0 + wn * WTN + j * MM::MT + nl + e;
+        if (writer && n < p.Nn) {
+            p.stats[((long)prow * 3 + 0) * p.Nn + n] = a[0];
+            p.stats[((long)prow * 3 + 1) * p.Nn + n] = b[0];
+        }
+        if (fr == 0) {                                                          // the pivots: 4 consecutive channels per (j, g)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    const int nl2 = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * gg + 4 * (lane >> 5));
+                    const int n2 = n0 + wn * WTN + jj * MM::MT + nl2;
+                    if (n2 < p.Nn)
+                        *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 3 + 2) * p.Nn + n2) = f32x4{piv[jj][gg][0], piv[jj][gg][1], piv[jj][gg][2], piv[jj][gg][3]};
+                }
         }
     }
 #ifdef MCN_ABL_STAMP

@@ -24,6 +24,7 @@ class Lowering(object):
         self.prepack = Program()       # one launch: cast / re-pack every conv weight from its fp32 master (or EMA shadow)
         self.ws = None
         self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
+        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', True))   # BN statistics in the conv epilogue
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.scratch = {}
 
@@ -160,7 +161,7 @@ class Lowering(object):
         """Measure, don't guess: time every tile candidate of every conv launch of this lowering on the GPU (HIP events
         on the launch stream, data already in the buffers) and pin the fastest through mcn_conv_geom.tile.  The result
         of a conv does not depend on the tile except for the fp32 summation order of the split wgrad."""
-        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
         sp = torch.cuda.current_stream(self.g.device).cuda_stream
         self.prepack.run(sp)
         chosen = {}
@@ -187,6 +188,14 @@ class Lowering(object):
                     best, best_t = cand, t
             gm.tile = best
             chosen[id(gm)] = best
+        for fn, args in self.fwd.calls:                     # the partial-row count of a fused conv -> BN pair follows the tile
+            if getattr(fn, '__name__', '') == 'mcn_bn_fwd_train_fused':
+                for nd in self.g.nodes:
+                    fs = nd.attrs.get('fused_stats') if nd.op == 'bn' else None
+                    if fs is not None and fs[0].data_ptr() == args[1]:
+                        rpp = ctypes.c_int32(0)
+                        args[2] = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(fs[1]), self.dt, ctypes.byref(rpp)))
+                        args[3] = rpp.value
         return chosen
 
     # ---- input / labels ---------------------------------------------------------------------------------
@@ -203,10 +212,35 @@ class Lowering(object):
         self.fwd.add(lib.mcn_one_hot, self.model.Y_in.data_ptr(), y.buf.data_ptr(), y.shape[0], y.shape[1])
 
     # ---- conv -----------------------------------------------------------------------------------------------
+    def _bn_consumer(self, n):
+        """The training-mode batch norm that is the only reader of this conv's output (its statistics can then be
+        accumulated in the conv epilogue), else None."""
+        y = n.outputs[0]
+        if not (self.train and self.fuse_bn_stats and len(y.consumers) == 1):
+            return None
+        c = y.consumers[0]
+        if c.op != 'bn' or not c.attrs['update'] or c.inputs[0] is not y or c not in self.g.nodes:
+            return None
+        return c
+
     def fwd_conv(self, n):
         x, y = n.inputs[0], n.outputs[0]
         gm = self.op_geom(n, _ffi.CONV_FWD)
         self.keep.append(gm)
+        bn = self._bn_consumer(n)
+        rows = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, None)) if bn is not None else 0
+        if rows > 0 and y.shape[-1] % (8 if self.g.dtype == 'bfloat16' else 4) == 0:
+            cand = []
+            keep = gm.tile
+            for t in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_FWD) + 1):     # room for any tile the autotuner may pin
+                gm.tile = t
+                cand.append(int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, None)))
+            gm.tile = keep
+            part = torch.zeros((max(cand), 3, y.shape[-1]), dtype=torch.float32, device=self.g.device)
+            bn.attrs['fused_stats'] = (part, gm)
+            self.fwd.add(lib.mcn_conv2d_fwd_bnstats, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')),
+                         y.buf.data_ptr(), part.data_ptr(), ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+            return
         self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
                      ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
 
@@ -312,6 +346,16 @@ class Lowering(object):
         if self.train and a['update']:
             st = a['saved']
             single = self.model.world_size == 1
+            if 'fused_stats' in a:
+                part, gm = a['fused_stats']
+                rpp = ctypes.c_int32(0)
+                rows = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, ctypes.byref(rpp)))
+                self.fwd.add(lib.mcn_bn_fwd_train_fused, x.buf.data_ptr(), part.data_ptr(), rows, rpp.value,
+                             self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
+                             y.buf.data_ptr(), st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
+                             a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
+                             float(a['momentum']), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+                return
             self.fwd.add(lib.mcn_bn_fwd_train, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
                          y.buf.data_ptr(), st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
                          a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,

@@ -452,3 +452,57 @@ def test_full_size_properties():
     assert np.abs(yb.mean(0)).max() < 1e-4
     v = y1.reshape(-1, c).astype(np.float64).var(0)
     np.testing.assert_allclose(yb.var(0), v / (v + 1e-3), rtol=1e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(4, 14, 14, 64, 64, 3, 1), (2, 28, 28, 32, 128, 1, 1), (3, 9, 11, 72, 136, 3, 1), (2, 16, 16, 16, 32, 3, 2), (8, 14, 14, 256, 64, 1, 1)])
+def test_conv_epilogue_bn_statistics(case, dtype):
+    """conv -> BN fusion: the conv writes per-(M tile, wave row) column sums / sums of squares of the values it stores;
+    mcn_bn_fwd_train_fused must give what mcn_bn_fwd_train gives on the same conv output (same tf.nn.fused_batch_norm
+    semantics), for every tile candidate, including ragged M / N tails."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k, s = case
+    x = (RNG.standard_normal((n, h, w_, cin)) + 3.0).astype(np.float32)       # offset input: |mean| >> std in the conv output
+    w = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin) + 0.05).astype(np.float32)
+    gamma = (0.5 + RNG.random(cout)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(cout)).astype(np.float32)
+    y_plain = u.conv_fwd(x, w, s, 'SAME', 1, dtype)
+    ref = u.bn_fwd_train(y_plain, gamma, beta, 1e-3, dtype, act=1, running=(np.zeros(cout, np.float32), np.ones(cout, np.float32)))
+    for tile in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_FWD) + 1):
+        g = u.geom(x.shape, w.shape, s, 'SAME')
+        g.tile = tile
+        rpp = ctypes.c_int32(0)
+        rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT[dtype], ctypes.byref(rpp))
+        assert rows > 0 and rows * rpp.value >= y_plain.size // cout
+        xd, wd = u.dev(x, dtype), u.dev(w)
+        y = torch.full(y_plain.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        part = torch.full((rows, 3, cout), float('nan'), dtype=torch.float32, device=u.DEV)
+        ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]))
+        _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
+                                              ws.data_ptr(), ws.numel() * 4, u.stream()))
+        np.testing.assert_array_equal(u.host(y), y_plain)                       # the stored output is unchanged
+        p = u.host(part).astype(np.float64)
+        yq = y_plain.astype(np.float64).reshape(-1, cout)
+        m = yq.shape[0]
+        for kk in range(rows):                                                   # every partial: shifted sums of its own rows
+            blk = yq[kk * rpp.value:(kk + 1) * rpp.value]
+            if len(blk) == 0:
+                continue
+            np.testing.assert_array_equal(p[kk, 2], blk[0])                     # the shift is the first stored row, exactly
+            d = blk - blk[0]
+            np.testing.assert_allclose(p[kk, 0], d.sum(0), rtol=1e-4, atol=1e-5 * np.abs(d).sum(0).max() + 1e-30)
+            np.testing.assert_allclose(p[kk, 1], (d ** 2).sum(0), rtol=1e-4, atol=1e-30)
+        out = torch.full(y_plain.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        gd, bd = u.dev(gamma), u.dev(beta)
+        sm, si, bm, bv = [torch.zeros(cout, dtype=torch.float32, device=u.DEV) for _ in range(4)]
+        rm, rv = torch.zeros(cout, dtype=torch.float32, device=u.DEV), torch.ones(cout, dtype=torch.float32, device=u.DEV)
+        bws = u.workspace(lib.mcn_bn_workspace_bytes(m, cout))
+        _ffi.check(lib.mcn_bn_fwd_train_fused(y.data_ptr(), part.data_ptr(), rows, rpp.value, gd.data_ptr(), bd.data_ptr(), 0, out.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                                              bm.data_ptr(), bv.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.99, m, cout, 1e-3, 1, u.MDT[dtype], bws.data_ptr(),
+                                              bws.numel() * 4, u.stream()))
+        check(u.host(out), ref['y'], dtype, 'fused bn y (tile {})'.format(tile), rel=1e-5 if dtype == 'float32' else 4e-3)
+        check(u.host(sm), ref['save_mean'], 'float32', 'save_mean', rel=1e-5, mx=1e-4)
+        check(u.host(si), ref['save_invstd'], 'float32', 'save_invstd', rel=1e-5)
+        check(u.host(rv), ref['running_var'], 'float32', 'running_var', rel=1e-5)
