@@ -253,6 +253,27 @@ int mcn_fc_bwd(const void* dy, const void* x, const float* w, void* dx, float* d
 int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce,
                              float* coef, float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing,
                              float loss_scale, void* stream);
+/* the same loss over many short rows — SegNet's per-pixel cross-entropy (segmentation/segnet.py:74-78 -> convnet.py:528-597
+ * with Y of shape [N,H,W,classes]): B = N*H*W rows, one thread per row; workspace >= 1024 floats for the mean. */
+int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce,
+                                  float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing,
+                                  float loss_scale, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- segmentation path -----------------------------------------------------
+ * tf.image.resize_bilinear (convnet.py:2396; align_corners=True at models/deeplabv3plus.py:64,74) and its gradient
+ * (gather form, deterministic); x/y NHWC in `dtype`, interpolation in fp32. */
+int mcn_resize_bilinear_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                            int32_t align_corners, mcn_dtype dtype, void* stream);
+int mcn_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                            int32_t align_corners, mcn_dtype dtype, void* stream);
+/* tf.concat along channels (models/deeplabv3plus.py:101,110) = one call per input; its gradient = one call per slice:
+ * dst[m][dst_offset + c] = src[m][src_offset + c] for c < C, m < M (strides in elements). */
+int mcn_copy_channels(const void* src, int32_t src_stride, int32_t src_offset, void* dst, int32_t dst_stride,
+                      int32_t dst_offset, int64_t M, int32_t C, mcn_dtype dtype, void* stream);
+/* SegNet label encoding (segmentation/segnet.py:31-50): NaN -> 0, class = round(label - 1), one-hot of depth C; label 0
+ * (class -1) and classes >= C give an all-zero row = ignored pixel.  labels fp32 [P], onehot fp32 [P][C]. */
+int mcn_one_hot_seg(const float* labels, float* onehot, int64_t P, int32_t C, void* stream);
+
 /* l2_factor * sum tf.nn.l2_loss(w) over a flat range (convnet.py:560-563): out[0] += factor*sum(w^2)/2 */
 int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* workspace, size_t workspace_bytes,
                 void* stream);

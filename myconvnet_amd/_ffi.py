@@ -85,6 +85,11 @@ SIGNATURES = {
     'mcn_softmax_xent_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_float, c_float, c_void_p]),
     'mcn_l2_loss': (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mcn_sgd_nesterov_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 6 + [c_void_p]),
+    'mcn_softmax_xent_rows_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    'mcn_resize_bilinear_fwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),
+    'mcn_resize_bilinear_bwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),
+    'mcn_copy_channels': (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int, c_void_p]),
+    'mcn_one_hot_seg': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'mcn_clip_by_global_norm': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mcn_ema_update': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     'mcn_bn_running_chain': (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_void_p]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libmcn_hip.so')
-SOURCES = ['conv.hip', 'bn.hip', 'eltwise.hip', 'pool.hip', 'loss_optim.hip', 'dwconv.hip']
+SOURCES = ['conv.hip', 'bn.hip', 'eltwise.hip', 'pool.hip', 'loss_optim.hip', 'dwconv.hip', 'seg.hip']
 HEADERS = ['common.h', 'conv_kernels.h', os.path.join('..', '..', 'include', 'mcn.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',

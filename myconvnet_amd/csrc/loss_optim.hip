@@ -66,6 +66,62 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
         coef[b] = cf;
     }
 }
+// few classes, many rows (per-pixel loss of the segmentation path, B = N*H*W): one thread per row, two passes over its C
+// logits; same arithmetic as the block-per-row kernel.
+__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                                const float* __restrict__ class_w, float* __restrict__ pred, float* __restrict__ ce,
+                                                                float* __restrict__ coef, float* __restrict__ dlogits, long B, int C, float ls,
+                                                                float loss_scale) {
+    for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
+        const float* z = logits + b * C;
+        const float* yv = labels + b * C;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float se = 0.f, sy = 0.f, bw = 0.f;
+        for (int c = 0; c < C; ++c) {
+            se += expf(z[c] - mx);
+            const float y = yv[c];
+            sy += y;
+            bw += y * (class_w ? class_w[c] : 1.f);
+        }
+        const float lse = logf(se);
+        const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
+        const float cf = bw * valid;
+        const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
+        const float gscale = cf * loss_scale / (float)B;
+        float cel = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float lsm = z[c] - mx - lse;
+            const float p = expf(lsm);
+            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+            cel -= lab * lsm;
+            if (pred) pred[b * C + c] = p;
+            if (dlogits) dlogits[b * C + c] = (p * lab_sum - lab) * gscale;
+        }
+        ce[b] = cel;
+        coef[b] = cf;
+    }
+}
+// two-stage mean for many rows: 1024 block partials (written over the first entries of `part`), then one block
+__global__ __launch_bounds__(256) void xent_partial_kernel(const float* __restrict__ ce, const float* __restrict__ coef, float* __restrict__ part, long B) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < B; i += (long)gridDim.x * 256) s += ce[i] * coef[i];
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void xent_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ loss, long B) {
+    __shared__ double shd[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)part[i];
+    shd[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(shd[0] / (double)B);
+}
 __global__ __launch_bounds__(256) void xent_mean_kernel(const float* __restrict__ ce, const float* __restrict__ coef, float* __restrict__ loss, int B) {
     __shared__ float sh[4];
     float s = 0.f;
@@ -83,6 +139,28 @@ extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels
     MCN_CHECK_LAUNCH();
     if (loss) {
         hipLaunchKernelGGL(xent_mean_kernel, dim3(1), dim3(256), 0, st, (const float*)ce, (const float*)coef, loss, B);
+        MCN_CHECK_LAUNCH();
+    }
+    return MCN_OK;
+}
+
+/* per-pixel variant (segmentation: rows = N*H*W pixels, few classes): one thread per row, two-stage mean through the
+ * caller's workspace (>= 1024 floats) */
+extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
+                                             float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void* ws,
+                                             size_t ws_bytes, void* stream) {
+    if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "softmax_xent_rows: bad argument");
+    if (loss && (!ws || ws_bytes < 1024 * sizeof(float))) MCN_FAIL(MCN_E_WORKSPACE, "softmax_xent_rows: workspace needs 4096 bytes");
+    hipStream_t st = (hipStream_t)stream;
+    long blocks = ((long)B + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, labels, class_w, pred, ce, coef, dlogits, (long)B, C,
+                       label_smoothing, loss_scale);
+    MCN_CHECK_LAUNCH();
+    if (loss) {
+        hipLaunchKernelGGL(xent_partial_kernel, dim3(1024), dim3(256), 0, st, (const float*)ce, (const float*)coef, (float*)ws, (long)B);
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, 1024, loss, (long)B);
         MCN_CHECK_LAUNCH();
     }
     return MCN_OK;

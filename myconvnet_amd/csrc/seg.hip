@@ -1,0 +1,192 @@
+// seg.hip — the extra ops of the DeepLabv3+ / SegNet path: bilinear resize with align_corners
+// (tf.image.resize_bilinear, reference convnet.py:2378-2406, called from models/deeplabv3plus.py:64,74), channel concat
+// (tf.concat, models/deeplabv3plus.py:101,110) and SegNet's label encoding (segmentation/segnet.py:31-50).  HBM-bound.
+#include "common.h"
+
+struct ResizeParams {
+    int N, H, W, C, OH, OW;
+    float sy, sx;          // source step per output index
+    int align;
+};
+
+// TF ResizeBilinear coordinates: align_corners: src = o * (in-1)/(out-1); else half-pixel centres clamped at 0
+__device__ __forceinline__ void rs_coord(int o, float scale, int align, int in, int& lo, int& hi, float& f) {
+    float src = align ? (float)o * scale : fmaxf(((float)o + 0.5f) * scale - 0.5f, 0.f);
+    int l = (int)floorf(src);
+    if (l > in - 1) l = in - 1;
+    lo = l;
+    hi = l + 1 < in ? l + 1 : in - 1;
+    f = src - (float)l;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const ResizeParams p) {
+    constexpr int CE = VecTraits<T>::CE;
+    const int cch = p.C / CE;
+    const long total = (long)p.N * p.OH * p.OW * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cch);
+        long q = i / cch;
+        const int ox = (int)(q % p.OW);
+        q /= p.OW;
+        const int oy = (int)(q % p.OH);
+        const long n = q / p.OH;
+        int ylo, yhi, xlo, xhi;
+        float fy, fx;
+        rs_coord(oy, p.sy, p.align, p.H, ylo, yhi, fy);
+        rs_coord(ox, p.sx, p.align, p.W, xlo, xhi, fx);
+        const T* base = x + n * p.H * p.W * p.C + (long)ch * CE;
+        const Chunk<T> a = load_chunk<T>(base + ((long)ylo * p.W + xlo) * p.C), b = load_chunk<T>(base + ((long)ylo * p.W + xhi) * p.C);
+        const Chunk<T> c = load_chunk<T>(base + ((long)yhi * p.W + xlo) * p.C), d = load_chunk<T>(base + ((long)yhi * p.W + xhi) * p.C);
+        Chunk<T> o;
+#pragma unroll
+        for (int k = 0; k < CE; ++k) {
+            const float top = a.get(k) * (1.f - fx) + b.get(k) * fx;
+            const float bot = c.get(k) * (1.f - fx) + d.get(k) * fx;
+            o.set(k, top * (1.f - fy) + bot * fy);
+        }
+        store_chunk<T>(y + i * CE, o);
+    }
+}
+
+// gather form of the gradient (deterministic): an input pixel collects dy from every output whose lower or upper
+// neighbour it is; candidates come from the inverse of the coordinate map, membership is re-checked with the forward's
+// own arithmetic so that rounding can not drop or duplicate a term.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, const ResizeParams p, float isy, float isx) {
+    constexpr int CE = VecTraits<T>::CE;
+    const int cch = p.C / CE;
+    const long total = (long)p.N * p.H * p.W * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cch);
+        long q = i / cch;
+        const int ix = (int)(q % p.W);
+        q /= p.W;
+        const int iy = (int)(q % p.H);
+        const long n = q / p.H;
+        // outputs with src in (i-1, i+1); one candidate of slack on both sides
+        int oy0 = (int)floorf(((float)iy - 1.f) * isy) - 1, oy1 = (int)ceilf(((float)iy + 1.f) * isy) + 1;
+        int ox0 = (int)floorf(((float)ix - 1.f) * isx) - 1, ox1 = (int)ceilf(((float)ix + 1.f) * isx) + 1;
+        if (!p.align) { oy0 -= 1; oy1 += 1; ox0 -= 1; ox1 += 1; }
+        if (oy0 < 0) oy0 = 0;
+        if (ox0 < 0) ox0 = 0;
+        if (oy1 > p.OH - 1) oy1 = p.OH - 1;
+        if (ox1 > p.OW - 1) ox1 = p.OW - 1;
+        float acc[CE];
+#pragma unroll
+        for (int k = 0; k < CE; ++k) acc[k] = 0.f;
+        const T* base = dy + n * p.OH * p.OW * p.C + (long)ch * CE;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            int lo, hi;
+            float f;
+            rs_coord(oy, p.sy, p.align, p.H, lo, hi, f);
+            const float wy = (lo == iy ? 1.f - f : 0.f) + (hi == iy ? f : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                rs_coord(ox, p.sx, p.align, p.W, lo, hi, f);
+                const float wx = (lo == ix ? 1.f - f : 0.f) + (hi == ix ? f : 0.f);
+                if (wx == 0.f) continue;
+                const Chunk<T> g = load_chunk<T>(base + ((long)oy * p.OW + ox) * p.C);
+                const float w = wy * wx;
+#pragma unroll
+                for (int k = 0; k < CE; ++k) acc[k] = fmaf(g.get(k), w, acc[k]);
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int k = 0; k < CE; ++k) o.set(k, acc[k]);
+        store_chunk<T>(dx + i * CE, o);
+    }
+}
+
+static int resize_setup(const void* a, const void* b, int N, int H, int W, int C, int OH, int OW, int align, mcn_dtype dt, ResizeParams* p, const char* nm) {
+    if (!a || !b || N < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) MCN_FAIL(MCN_E_BADARG, "%s: bad argument", nm);
+    if (dt != MCN_F32 && dt != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", nm, (int)dt);
+    if (C % (dt == MCN_F32 ? 4 : 8)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: C=%d must be a multiple of the 16-byte chunk", nm, C);
+    p->N = N; p->H = H; p->W = W; p->C = C; p->OH = OH; p->OW = OW; p->align = align ? 1 : 0;
+    if (align) {
+        p->sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+        p->sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    } else {
+        p->sy = (float)H / (float)OH;
+        p->sx = (float)W / (float)OW;
+    }
+    return MCN_OK;
+}
+static inline unsigned seg_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+extern "C" int mcn_resize_bilinear_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                                       int32_t align_corners, mcn_dtype dtype, void* stream) {
+    ResizeParams p;
+    if (int rc = resize_setup(x, y, N, H, W, C, OH, OW, align_corners, dtype, &p, "resize_bilinear_fwd")) return rc;
+    const long total = (long)N * OH * OW * (C / (dtype == MCN_F32 ? 4 : 8));
+    if (total == 0) return MCN_OK;
+    if (dtype == MCN_F32) hipLaunchKernelGGL((resize_fwd_kernel<float>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, p);
+    else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, p);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                                       int32_t align_corners, mcn_dtype dtype, void* stream) {
+    ResizeParams p;
+    if (int rc = resize_setup(dy, dx, N, H, W, C, OH, OW, align_corners, dtype, &p, "resize_bilinear_bwd")) return rc;
+    const long total = (long)N * H * W * (C / (dtype == MCN_F32 ? 4 : 8));
+    if (total == 0) return MCN_OK;
+    // inverse steps; a zero forward step (single output row / column) means every output maps to input 0
+    const float isy = p.sy > 0.f ? 1.f / p.sy : (float)OH, isx = p.sx > 0.f ? 1.f / p.sx : (float)OW;
+    if (dtype == MCN_F32) hipLaunchKernelGGL((resize_bwd_kernel<float>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, p, isy, isx);
+    else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, p, isy, isx);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// dst[m][dst_off + c] = src[m][src_off + c], c < C: tf.concat along channels (one call per input) and its gradient (slices)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict__ src, int ss, int so, T* __restrict__ dst, int ds, int dof, long M, int C) {
+    constexpr int CE = VecTraits<T>::CE;
+    const int cch = C / CE;
+    const long total = M * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / cch;
+        const int c = (int)(i - m * cch) * CE;
+        store_chunk<T>(dst + m * ds + dof + c, load_chunk<T>(src + m * ss + so + c));
+    }
+}
+extern "C" int mcn_copy_channels(const void* src, int32_t src_stride, int32_t src_offset, void* dst, int32_t dst_stride, int32_t dst_offset, int64_t M,
+                                 int32_t C, mcn_dtype dtype, void* stream) {
+    if (!src || !dst || M < 0 || C <= 0 || src_offset < 0 || dst_offset < 0 || src_offset + C > src_stride || dst_offset + C > dst_stride)
+        MCN_FAIL(MCN_E_BADARG, "copy_channels: bad argument");
+    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "copy_channels: dtype %d unsupported", (int)dtype);
+    const int ce = dtype == MCN_F32 ? 4 : 8;
+    if (C % ce || src_stride % ce || dst_stride % ce || src_offset % ce || dst_offset % ce)
+        MCN_FAIL(MCN_E_UNSUPPORTED, "copy_channels: channel counts / offsets must be multiples of the 16-byte chunk");
+    if (M == 0) return MCN_OK;
+    const long total = (long)M * (C / ce);
+    if (dtype == MCN_F32) hipLaunchKernelGGL((copy_channels_kernel<float>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, src_stride, src_offset, (float*)dst, dst_stride, dst_offset, (long)M, C);
+    else hipLaunchKernelGGL((copy_channels_kernel<bf16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_stride, src_offset, (bf16_t*)dst, dst_stride, dst_offset, (long)M, C);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// SegNet labels: NaN -> 0; class = round(label - 1) (half to even, tf.math.round); class -1 (label 0) or >= C -> all-zero row
+__global__ __launch_bounds__(256) void one_hot_seg_kernel(const float* __restrict__ labels, float* __restrict__ onehot, long P, int C) {
+    const long total = P * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long q = i / C;
+        const int c = (int)(i - q * C);
+        float l = labels[q];
+        if (l != l) l = 0.f;
+        const int cls = (int)rintf(l - 1.f);
+        onehot[i] = cls == c ? 1.f : 0.f;
+    }
+}
+extern "C" int mcn_one_hot_seg(const float* labels, float* onehot, int64_t P, int32_t C, void* stream) {
+    if (!labels || !onehot || P < 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "one_hot_seg: bad argument");
+    if (P == 0) return MCN_OK;
+    hipLaunchKernelGGL(one_hot_seg_kernel, dim3(seg_blocks((long)P * C)), dim3(256), 0, (hipStream_t)stream, labels, onehot, (long)P, C);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}

@@ -184,6 +184,74 @@ def depthwise_conv2d_wgrad(x, dy, w_shape, stride=1, padding='SAME', dilation=1)
 
 
 # --------------------------------------------------------------------------------------------
+# bilinear resize, channel concat  (DeepLabv3+ row, SURVEY §8f-3: tf.image.resize_bilinear at convnet.py:2396 with
+# align_corners=True as called from models/deeplabv3plus.py:64,74; tf.concat at :101,110)
+# --------------------------------------------------------------------------------------------
+def _resize_coords(in_size, out_size, align_corners=True):
+    """Source coordinate, lower index, upper index and upper weight per output index (TF ResizeBilinear:
+    align_corners -> scale = (in-1)/(out-1); otherwise half_pixel_centers -> (o+0.5)*in/out - 0.5 clamped at 0)."""
+    o = np.arange(out_size, dtype=np.float64)
+    if align_corners:
+        scale = (in_size - 1) / (out_size - 1) if out_size > 1 else 0.0
+        src = o * scale
+    else:
+        src = np.maximum((o + 0.5) * (in_size / out_size) - 0.5, 0.0)
+    lo = np.minimum(np.floor(src).astype(np.int64), in_size - 1)
+    hi = np.minimum(lo + 1, in_size - 1)
+    return lo, hi, src - lo
+
+
+def resize_bilinear_fwd(x, out_hw, align_corners=True):
+    n, h, w, c = x.shape
+    oh, ow = out_hw
+    ylo, yhi, fy = _resize_coords(h, oh, align_corners)
+    xlo, xhi, fx = _resize_coords(w, ow, align_corners)
+    fy = fy.reshape(1, oh, 1, 1).astype(x.dtype)
+    fx = fx.reshape(1, 1, ow, 1).astype(x.dtype)
+    top = x[:, ylo][:, :, xlo] * (1 - fx) + x[:, ylo][:, :, xhi] * fx
+    bot = x[:, yhi][:, :, xlo] * (1 - fx) + x[:, yhi][:, :, xhi] * fx
+    return top * (1 - fy) + bot * fy
+
+
+def resize_bilinear_bwd(dy, x_shape, align_corners=True):
+    n, h, w, c = x_shape
+    oh, ow = dy.shape[1:3]
+    ylo, yhi, fy = _resize_coords(h, oh, align_corners)
+    xlo, xhi, fx = _resize_coords(w, ow, align_corners)
+    dx = np.zeros(x_shape, dtype=dy.dtype)
+    fy = fy.reshape(1, oh, 1, 1)
+    fx = fx.reshape(1, 1, ow, 1)
+    for ys, wy in ((ylo, 1 - fy), (yhi, fy)):
+        for xs, wx in ((xlo, 1 - fx), (xhi, fx)):
+            contrib = (dy * (wy * wx)).astype(dy.dtype)
+            np.add.at(dx, (slice(None), ys[:, None], xs[None, :]), contrib)
+    return dx
+
+
+def concat_fwd(xs):
+    return np.concatenate(xs, axis=-1)
+
+
+def concat_bwd(dy, channels):
+    out, o = [], 0
+    for c in channels:
+        out.append(np.ascontiguousarray(dy[..., o:o + c]))
+        o += c
+    return out
+
+
+def seg_one_hot_labels(y, num_classes, dtype=np.float32):
+    """SegNet labels (segmentation/segnet.py:31-50): NaN -> 0, class = round(y - 1), -1 (label 0) and out-of-range
+    classes give an all-zero row = ignored pixel."""
+    y = np.where(np.isnan(y), 0.0, y)
+    idx = np.rint(y - 1.0).astype(np.int64)
+    oh = np.zeros(y.shape + (num_classes,), dtype=dtype)
+    valid = (idx >= 0) & (idx < num_classes)
+    np.put_along_axis(oh, np.clip(idx, 0, num_classes - 1)[..., None], valid[..., None].astype(dtype), axis=-1)
+    return oh
+
+
+# --------------------------------------------------------------------------------------------
 # batch norm  (tf.nn.fused_batch_norm, convnet.py:1883-1896; running stats convnet.py:1898-1914)
 # --------------------------------------------------------------------------------------------
 def bn_fwd_train(x, gamma, beta, eps=1e-3):
