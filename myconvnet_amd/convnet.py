@@ -291,13 +291,17 @@ class ConvNet(object):
         if kwargs.get('bias_norm_decay', False):
             raise NotImplementedError('bias_norm_decay is outside the built path')
         g = self.graph
-        B, C = self.logits.shape
-        self.Y = g.tensor((B, C), 'float32', 'Y_onehot')
-        g.node('labels', [], [self.Y])
-        self.pred = g.tensor((B, C), 'float32', 'pred')
+        shape = tuple(self.logits.shape)                    # [B, C] (classification) or [B, H, W, C] (SegNet: per-pixel loss)
+        seg = len(shape) == 4
+        if seg and float(kwargs.get('label_smoothing', 0.0)) > 0.0:
+            raise NotImplementedError('SegNet label smoothing (5x5 average of the labels, segnet.py:117-122) is not built')
+        self._label_shape = shape[:-1]
+        self.Y = g.tensor(shape, 'float32', 'Y_onehot')
+        g.node('labels', [], [self.Y], seg=seg)
+        self.pred = g.tensor(shape, 'float32', 'pred')
         self.d['pred'] = self.pred
         self._loss_node = g.node('loss', [self.logits, self.Y], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
-                                 label_smoothing=float(kwargs.get('label_smoothing', 0.0)))
+                                 label_smoothing=float(kwargs.get('label_smoothing', 0.0)), rows=int(np.prod(shape[:-1])), per_pixel=seg)
 
     # ---- compile: storage + launch lists -----------------------------------------------------------------------------------
     def compile(self, loss_scale=1.0):
@@ -312,7 +316,7 @@ class ConvNet(object):
         H, W, C = self._input_size
         dev = self.device
         self.X_in = torch.zeros((B, C, H, W) if self._channel_first else (B, H, W, C), dtype=torch.float32, device=dev)
-        self.Y_in = torch.zeros((B,), dtype=torch.float32, device=dev)
+        self.Y_in = torch.zeros(tuple(getattr(self, '_label_shape', (B,))), dtype=torch.float32, device=dev)
         # flat storage: [conv/fc weights | biases, gammas, betas] so the L2 term covers one contiguous range
         trainables = [v for v in self._var_order if v.kind in ('weight', 'bias', 'gamma', 'beta')]
         ordered = [v for v in trainables if v.kind == 'weight'] + [v for v in trainables if v.kind != 'weight']
@@ -338,8 +342,8 @@ class ConvNet(object):
             elif n.op == 'loss':
                 a = n.attrs
                 a['pred'] = self.pred
-                a['ce'] = torch.zeros(B, dtype=torch.float32, device=dev)
-                a['coef'] = torch.zeros(B, dtype=torch.float32, device=dev)
+                a['ce'] = torch.zeros(a['rows'], dtype=torch.float32, device=dev)
+                a['coef'] = torch.zeros(a['rows'], dtype=torch.float32, device=dev)
                 a['loss'] = torch.zeros(4, dtype=torch.float32, device=dev)
                 a['class_w'] = None if self._loss_weights is None else torch.tensor(np.asarray(self._loss_weights, dtype=np.float32), device=dev)
                 self.loss_buf = a['loss']
@@ -423,8 +427,8 @@ class ConvNet(object):
         pred_size = dataset.num_examples if max_examples is None else min(max_examples, dataset.num_examples)
         num_steps = int(np.ceil(pred_size / batch))
         _X = np.zeros([pred_size] + list(self._input_size), dtype=np.float32) if return_images else np.zeros([pred_size, 4, 4, 3], np.float32)
-        _Y_true = np.zeros([pred_size, self._num_classes], dtype=np.float32)
-        _Y_pred = np.zeros([pred_size, self._num_classes], dtype=np.float32)
+        _Y_true = np.zeros([pred_size] + list(self.Y.shape[1:]), dtype=np.float32)
+        _Y_pred = np.zeros([pred_size] + list(self.pred.shape[1:]), dtype=np.float32)
         _loss = np.zeros(num_steps, dtype=np.float32)
         dataset.initialize()
         for i in range(num_steps):
@@ -619,6 +623,31 @@ class ConvNet(object):
         y = self.graph.tensor((n, 1, 1, c) if keepdims else (n, c), x.dtype, self.scope_name('avgpool'))
         self.graph.node('gap', [x], [y], scope=self.scope_name())
         return y
+
+    def upsampling_2d_layer(self, x, scale=2, out_shape=None, align_corners=False, force_unaligned=False, upsampling_method='bilinear',
+                            name='upsampling'):
+        """reference convnet.py:2378-2406 -> tf.image.resize_bilinear (interpolation in fp32, result in the compute dtype)."""
+        if upsampling_method.lower() != 'bilinear':
+            raise NotImplementedError('upsampling method {} is outside the built path (supported: bilinear)'.format(upsampling_method))
+        if force_unaligned:
+            raise NotImplementedError('force_unaligned (legacy asymmetric resize) is outside the built path')
+        n, h, w, c = x.shape
+        oh, ow = (h * scale, w * scale) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
+        y = self.graph.tensor((n, oh, ow, c), x.dtype, self.scope_name(name), self._channel_first)
+        self.graph.node('resize', [x], [y], scope=self.scope_name(name), align=bool(align_corners))
+        return y
+
+    def concat(self, xs, name='concat'):
+        """Stand-in for tf.concat(xs, axis=channel axis) (models/deeplabv3plus.py:101,110)."""
+        xs = list(xs)
+        assert all(t.shape[:-1] == xs[0].shape[:-1] and t.dtype == xs[0].dtype for t in xs), 'concat: shapes differ'
+        y = self.graph.tensor(tuple(xs[0].shape[:-1]) + (sum(t.shape[-1] for t in xs),), xs[0].dtype, self.scope_name(name), self._channel_first)
+        self.graph.node('concat', xs, [y], scope=self.scope_name(name))
+        return y
+
+    def stop_gradient(self, x):
+        """Stand-in for tf.stop_gradient (models/deeplabv3plus.py:53); not on the built path (feature_gradients are True)."""
+        raise NotImplementedError('stop_gradient on a backbone feature is not built')
 
     def channel_scale(self, x, mask):
         """Stand-in for `x = x*se_mask` (models/efficientnet.py:161): mask [N,1,1,C] broadcast over H, W."""

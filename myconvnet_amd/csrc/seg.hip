@@ -19,9 +19,31 @@ __device__ __forceinline__ void rs_coord(int o, float scale, int align, int in, 
     f = src - (float)l;
 }
 
-template <typename T>
+template <typename T, int VEC>
+__device__ __forceinline__ void ldvec(const T* p, float (&v)[VEC]) {
+    if constexpr (VEC == 1) {
+        v[0] = to_f32(p[0]);
+    } else {
+        const Chunk<T> c = load_chunk<T>(p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = c.get(i);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void stvec(T* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 1) {
+        p[0] = from_f32<T>(v[0]);
+    } else {
+        Chunk<T> c;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) c.set(i, v[i]);
+        store_chunk<T>(p, c);
+    }
+}
+
+// CE = 16-byte chunk of channels, or 1 when C is not a chunk multiple (the class-logit maps: C = num_classes)
+template <typename T, int CE>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const ResizeParams p) {
-    constexpr int CE = VecTraits<T>::CE;
     const int cch = p.C / CE;
     const long total = (long)p.N * p.OH * p.OW * cch;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -36,25 +58,26 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x
         rs_coord(oy, p.sy, p.align, p.H, ylo, yhi, fy);
         rs_coord(ox, p.sx, p.align, p.W, xlo, xhi, fx);
         const T* base = x + n * p.H * p.W * p.C + (long)ch * CE;
-        const Chunk<T> a = load_chunk<T>(base + ((long)ylo * p.W + xlo) * p.C), b = load_chunk<T>(base + ((long)ylo * p.W + xhi) * p.C);
-        const Chunk<T> c = load_chunk<T>(base + ((long)yhi * p.W + xlo) * p.C), d = load_chunk<T>(base + ((long)yhi * p.W + xhi) * p.C);
-        Chunk<T> o;
+        float a[CE], b[CE], c[CE], d[CE], o[CE];
+        ldvec<T, CE>(base + ((long)ylo * p.W + xlo) * p.C, a);
+        ldvec<T, CE>(base + ((long)ylo * p.W + xhi) * p.C, b);
+        ldvec<T, CE>(base + ((long)yhi * p.W + xlo) * p.C, c);
+        ldvec<T, CE>(base + ((long)yhi * p.W + xhi) * p.C, d);
 #pragma unroll
         for (int k = 0; k < CE; ++k) {
-            const float top = a.get(k) * (1.f - fx) + b.get(k) * fx;
-            const float bot = c.get(k) * (1.f - fx) + d.get(k) * fx;
-            o.set(k, top * (1.f - fy) + bot * fy);
+            const float top = a[k] * (1.f - fx) + b[k] * fx;
+            const float bot = c[k] * (1.f - fx) + d[k] * fx;
+            o[k] = top * (1.f - fy) + bot * fy;
         }
-        store_chunk<T>(y + i * CE, o);
+        stvec<T, CE>(y + i * CE, o);
     }
 }
 
 // gather form of the gradient (deterministic): an input pixel collects dy from every output whose lower or upper
 // neighbour it is; candidates come from the inverse of the coordinate map, membership is re-checked with the forward's
 // own arithmetic so that rounding can not drop or duplicate a term.
-template <typename T>
+template <typename T, int CE>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, const ResizeParams p, float isy, float isx) {
-    constexpr int CE = VecTraits<T>::CE;
     const int cch = p.C / CE;
     const long total = (long)p.N * p.H * p.W * cch;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -86,23 +109,20 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
                 rs_coord(ox, p.sx, p.align, p.W, lo, hi, f);
                 const float wx = (lo == ix ? 1.f - f : 0.f) + (hi == ix ? f : 0.f);
                 if (wx == 0.f) continue;
-                const Chunk<T> g = load_chunk<T>(base + ((long)oy * p.OW + ox) * p.C);
+                float g[CE];
+                ldvec<T, CE>(base + ((long)oy * p.OW + ox) * p.C, g);
                 const float w = wy * wx;
 #pragma unroll
-                for (int k = 0; k < CE; ++k) acc[k] = fmaf(g.get(k), w, acc[k]);
+                for (int k = 0; k < CE; ++k) acc[k] = fmaf(g[k], w, acc[k]);
             }
         }
-        Chunk<T> o;
-#pragma unroll
-        for (int k = 0; k < CE; ++k) o.set(k, acc[k]);
-        store_chunk<T>(dx + i * CE, o);
+        stvec<T, CE>(dx + i * CE, acc);
     }
 }
 
 static int resize_setup(const void* a, const void* b, int N, int H, int W, int C, int OH, int OW, int align, mcn_dtype dt, ResizeParams* p, const char* nm) {
     if (!a || !b || N < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) MCN_FAIL(MCN_E_BADARG, "%s: bad argument", nm);
     if (dt != MCN_F32 && dt != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", nm, (int)dt);
-    if (C % (dt == MCN_F32 ? 4 : 8)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: C=%d must be a multiple of the 16-byte chunk", nm, C);
     p->N = N; p->H = H; p->W = W; p->C = C; p->OH = OH; p->OW = OW; p->align = align ? 1 : 0;
     if (align) {
         p->sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
@@ -122,10 +142,17 @@ extern "C" int mcn_resize_bilinear_fwd(const void* x, void* y, int32_t N, int32_
                                        int32_t align_corners, mcn_dtype dtype, void* stream) {
     ResizeParams p;
     if (int rc = resize_setup(x, y, N, H, W, C, OH, OW, align_corners, dtype, &p, "resize_bilinear_fwd")) return rc;
-    const long total = (long)N * OH * OW * (C / (dtype == MCN_F32 ? 4 : 8));
+    const int ce = C % (dtype == MCN_F32 ? 4 : 8) ? 1 : (dtype == MCN_F32 ? 4 : 8);
+    const long total = (long)N * OH * OW * (C / ce);
     if (total == 0) return MCN_OK;
-    if (dtype == MCN_F32) hipLaunchKernelGGL((resize_fwd_kernel<float>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, p);
-    else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) {
+        if (ce == 4) hipLaunchKernelGGL((resize_fwd_kernel<float, 4>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+        else hipLaunchKernelGGL((resize_fwd_kernel<float, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+    } else {
+        if (ce == 8) hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 8>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+        else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+    }
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -133,12 +160,19 @@ extern "C" int mcn_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
                                        int32_t align_corners, mcn_dtype dtype, void* stream) {
     ResizeParams p;
     if (int rc = resize_setup(dy, dx, N, H, W, C, OH, OW, align_corners, dtype, &p, "resize_bilinear_bwd")) return rc;
-    const long total = (long)N * H * W * (C / (dtype == MCN_F32 ? 4 : 8));
+    const int ce = C % (dtype == MCN_F32 ? 4 : 8) ? 1 : (dtype == MCN_F32 ? 4 : 8);
+    const long total = (long)N * H * W * (C / ce);
     if (total == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
     // inverse steps; a zero forward step (single output row / column) means every output maps to input 0
     const float isy = p.sy > 0.f ? 1.f / p.sy : (float)OH, isx = p.sx > 0.f ? 1.f / p.sx : (float)OW;
-    if (dtype == MCN_F32) hipLaunchKernelGGL((resize_bwd_kernel<float>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, p, isy, isx);
-    else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, p, isy, isx);
+    if (dtype == MCN_F32) {
+        if (ce == 4) hipLaunchKernelGGL((resize_bwd_kernel<float, 4>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, p, isy, isx);
+        else hipLaunchKernelGGL((resize_bwd_kernel<float, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, p, isy, isx);
+    } else {
+        if (ce == 8) hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 8>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p, isy, isx);
+        else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p, isy, isx);
+    }
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }

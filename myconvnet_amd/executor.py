@@ -209,7 +209,40 @@ class Lowering(object):
 
     def fwd_labels(self, n):
         y = n.outputs[0]
-        self.fwd.add(lib.mcn_one_hot, self.model.Y_in.data_ptr(), y.buf.data_ptr(), y.shape[0], y.shape[1])
+        if n.attrs.get('seg'):
+            self.fwd.add(lib.mcn_one_hot_seg, self.model.Y_in.data_ptr(), y.buf.data_ptr(), y.numel // y.shape[-1], y.shape[-1])
+        else:
+            self.fwd.add(lib.mcn_one_hot, self.model.Y_in.data_ptr(), y.buf.data_ptr(), y.shape[0], y.shape[1])
+
+    # ---- segmentation path: bilinear resize, channel concat (models/deeplabv3plus.py) -----------------------------------
+    def _resize_args(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        N, H, W, C = x.shape
+        return [N, H, W, C, y.shape[1], y.shape[2], 1 if n.attrs['align'] else 0, MCN_DT[x.dtype]]
+
+    def fwd_resize(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.fwd.add(lib.mcn_resize_bilinear_fwd, x.buf.data_ptr(), y.buf.data_ptr(), *self._resize_args(n))
+
+    def bwd_resize(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_resize_bilinear_bwd, y.grad.data_ptr(), dst, *self._resize_args(n)))
+
+    def fwd_concat(self, n):
+        y = n.outputs[0]
+        M, tot, off = y.numel // y.shape[-1], y.shape[-1], 0
+        for t in n.inputs:
+            self.fwd.add(lib.mcn_copy_channels, t.buf.data_ptr(), t.shape[-1], 0, y.buf.data_ptr(), tot, off, M, t.shape[-1], MCN_DT[y.dtype])
+            off += t.shape[-1]
+
+    def bwd_concat(self, n):
+        y = n.outputs[0]
+        M, tot, off = y.numel // y.shape[-1], y.shape[-1], 0
+        for t in n.inputs:
+            c = t.shape[-1]
+            self.contribute_via_scratch(t, lambda dst, o=off, cc=c: self.bwd.add(lib.mcn_copy_channels, y.grad.data_ptr(), tot, o, dst, cc, 0, M, cc,
+                                                                                MCN_DT[y.dtype]))
+            off += c
 
     # ---- conv -----------------------------------------------------------------------------------------------
     def _bn_consumer(self, n):
@@ -531,13 +564,18 @@ class Lowering(object):
     def fwd_loss(self, n):
         logits, onehot = n.inputs[0], n.inputs[1]
         a = n.attrs
-        B, C = logits.shape
+        B, C = a.get('rows', logits.shape[0]), logits.shape[-1]
         m = self.model
         dl = logits.grad.data_ptr() if (self.train and logits.needs_grad) else 0
         if dl:
             self.written.add(logits.id)
-        self.fwd.add(lib.mcn_softmax_xent_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
-                     a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale)
+        if a.get('per_pixel'):
+            self.fwd.add(lib.mcn_softmax_xent_rows_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
+                         a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale,
+                         self.ws_ptr, self.ws_bytes)
+        else:
+            self.fwd.add(lib.mcn_softmax_xent_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
+                         a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale)
         nw = m.n_l2_elems
         if a['l2_reg'] > 0.0 and nw > 0:
             # the regulariser always reads the master variables (collection 'weight_variables', convnet.py:535)

@@ -167,6 +167,20 @@ class Tape(object):
         self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g.reshape(n, c), x.a.shape)))
         return y
 
+    def resize(self, x, out_hw, align_corners=True):
+        y = V(ops.resize_bilinear_fwd(x.a, out_hw, align_corners), self.quant)
+        self.bw.append(lambda: x.acc(ops.resize_bilinear_bwd(y.g, x.a.shape, align_corners)))
+        return y
+
+    def concat(self, xs):
+        y = V(ops.concat_fwd([v.a for v in xs]), self.quant)
+
+        def bw():
+            for v, g in zip(xs, ops.concat_bwd(y.g, [v.a.shape[-1] for v in xs])):
+                v.acc(g)
+        self.bw.append(bw)
+        return y
+
     def max_pool(self, x, k, s, padding='SAME'):
         ya, arg = ops.maxpool_fwd(x.a, k, s, padding)
         y = V(ya, self.quant)
@@ -210,7 +224,7 @@ class Tape(object):
 class ResNetSpec(object):
     def __init__(self, channels=(64, 256, 512, 1024, 2048), kernels=(7, 3, 3, 3, 3), strides=(2, 1, 2, 2, 2),
                  res_units=(None, 3, 4, 6, 3), bottleneck=True, num_classes=1000, in_channels=3,
-                 backbone_only=False):
+                 backbone_only=False, dilations=None, multi_grid=(1, 2, 4)):
         self.channels = list(channels)
         self.kernels = list(kernels)
         self.strides = list(strides)
@@ -219,6 +233,13 @@ class ResNetSpec(object):
         self.num_classes = num_classes
         self.in_channels = in_channels
         self.backbone_only = backbone_only
+        self.dilations = list(dilations) if dilations is not None else None    # models/resnet_v1_5_dilated.py:11-12,63-67
+        self.multi_grid = list(multi_grid)
+
+    def unit_dilation(self, i, j):
+        if self.dilations is None or self.dilations[i] == 1:
+            return 1
+        return self.dilations[i] * self.multi_grid[j % len(self.multi_grid)]
 
     @staticmethod
     def resnet50(num_classes=1000, width_div=1):
@@ -298,7 +319,7 @@ class ResNetSpec(object):
                 if self.bottleneck:
                     y = t.conv(h, name + '/conv_0', 1)
                     y = t.relu(t.bn(y, name + '/conv_0/bn'))
-                    y = t.conv(y, name + '/conv_1', s)          # v1.5: stride on the 3x3
+                    y = t.conv(y, name + '/conv_1', s, 'SAME', self.unit_dilation(i, j))   # v1.5: stride on the 3x3; dilated variants
                     d[name + '/conv_1'] = y
                     y = t.relu(t.bn(y, name + '/conv_1/bn'))
                     y = t.conv(y, name + '/conv_2', 1)
@@ -439,6 +460,62 @@ class EfficientNetSpec(object):
 
 
 # ------------------------------------------------------------------------------------------------
+# DeepLabv3+ on a dilated ResNet  (models/deeplabv3plus.py, models/resnet_v1_5_dilated.py, segmentation/segnet.py) — §8f-3
+# ------------------------------------------------------------------------------------------------
+class DeepLabSpec(object):
+    segmentation = True
+
+    def __init__(self, num_classes=19, width_div=1, depth_div=1, strides=(2, 1, 2, 2, 2), res_units=(None, 3, 4, 6, 3),
+                 dilations=(None, 1, 1, 1, 2), aspp_dilations=(6, 12, 18)):
+        """Defaults = ResNet50OS16 (resnet_v1_5_dilated.py:7-12,145); ResNet101OS16: strides (2,1,2,2,1), units (None,3,4,23,3)."""
+        units = [None if u is None else max(1, u // depth_div) for u in res_units]
+        self.backbone = ResNetSpec(channels=[64 // width_div] + [c // width_div for c in (256, 512, 1024, 2048)], strides=strides,
+                                   res_units=units, bottleneck=True, num_classes=num_classes, backbone_only=True, dilations=dilations)
+        self.num_classes = num_classes
+        self.backbone_only = False
+        self.feature_channels = [max(8, 256 // width_div), max(8, 48 // width_div)] if width_div > 1 else [256, 48]
+        self.aspp_dilations = list(aspp_dilations)
+
+    def variables(self):
+        out = self.backbone.variables()
+
+        def conv_bn(scope, k, cin, cout):
+            out.append((scope + '/weights', (k, k, cin, cout), 'weight'))
+            for nm, kind in (('mu', 'mu'), ('sigma', 'sigma'), ('gamma', 'gamma'), ('beta', 'beta')):
+                out.append((scope + '/norm/' + nm, (cout,), kind))
+        c4, c1 = self.backbone.channels[4], self.backbone.channels[1]
+        fa, fd = self.feature_channels
+        conv_bn('block_5/aspp/conv_0', 1, c4, fa)
+        for i in range(len(self.aspp_dilations)):
+            conv_bn('block_5/aspp/conv_{}'.format(i + 1), 3, c4, fa)
+        conv_bn('block_5/aspp/conv_out', 1, fa * (1 + len(self.aspp_dilations)), fa)
+        conv_bn('block_6/features', 1, c1, fd)
+        conv_bn('block_6/decoder/conv_0', 3, fa + fd, fa)
+        out.append(('block_None/logits/weights', (1, 1, fa, self.num_classes), 'weight'))
+        out.append(('block_None/logits/biases', (self.num_classes,), 'bias'))
+        return out
+
+    def forward(self, t, x):
+        self.backbone.forward(t, x)
+        d = t.d
+        f4, f1 = d['block_4'], d['block_1']
+        ys = [t.bn(t.conv(f4, 'block_5/aspp/conv_0', 1), 'block_5/aspp/conv_0/norm')]
+        for i, dil in enumerate(self.aspp_dilations):
+            sc = 'block_5/aspp/conv_{}'.format(i + 1)
+            ys.append(t.bn(t.conv(f4, sc, 1, 'SAME', dil), sc + '/norm'))
+        h = t.bn(t.conv(t.concat(ys), 'block_5/aspp/conv_out', 1), 'block_5/aspp/conv_out/norm')
+        d['block_5'] = h
+        feat = t.bn(t.conv(f1, 'block_6/features', 1), 'block_6/features/norm')
+        h = t.resize(h, feat.a.shape[1:3], True)
+        h = t.bn(t.conv(t.concat([h, feat]), 'block_6/decoder/conv_0', 1), 'block_6/decoder/conv_0/norm')
+        d['block_6'] = h
+        h = t.conv(h, 'block_None/logits', 1, biased=True)
+        logits = t.resize(h, x.a.shape[1:3], True)
+        d['logits'] = logits
+        return logits
+
+
+# ------------------------------------------------------------------------------------------------
 # VGG  (models/vggnet.py)
 # ------------------------------------------------------------------------------------------------
 VGG_MEAN = np.array([123.68, 116.78, 103.94])
@@ -555,8 +632,15 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
         out = spec.forward(t, x)
     if spec.backbone_only:
         return t, out, None, None, None
-    onehot = ops.one_hot_labels(y_float, spec.num_classes, dtype=dt)
-    pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
+    if getattr(spec, 'segmentation', False):
+        # SegNet: labels [N,H,W], per-pixel CE averaged over all pixels, ignored pixels weigh 0 (segnet.py:31-50, convnet.py:528-597)
+        onehot = ops.seg_one_hot_labels(y_float, spec.num_classes, dtype=dt)
+        c = spec.num_classes
+        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a.reshape(-1, c).astype(dt), onehot.reshape(-1, c), None, 0.0)
+        pred, dlogits = pred.reshape(out.a.shape), dlogits.reshape(out.a.shape)
+    else:
+        onehot = ops.one_hot_labels(y_float, spec.num_classes, dtype=dt)
+        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
     weights = [v for k, v in params.items() if k.endswith('/weights')]
     loss = float(sm_loss) + ops.l2_reg_loss(weights, hp['l2_reg'])
     out.g = dlogits if quant is None else quant(dlogits)

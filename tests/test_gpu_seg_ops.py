@@ -21,7 +21,7 @@ def _u():
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(2, 5, 7, 8, 9, 13), (2, 9, 9, 16, 33, 33), (1, 33, 33, 24, 129, 129), (2, 3, 5, 8, 3, 5), (2, 1, 1, 8, 4, 6),
-                                  (1, 8, 8, 8, 4, 3), (2, 17, 17, 256, 33, 33)])
+                                  (1, 8, 8, 8, 4, 3), (2, 17, 17, 256, 33, 33), (2, 9, 9, 19, 33, 33), (1, 5, 6, 3, 10, 12)])   # last two: class maps, C not a chunk multiple
 def test_resize_bilinear_align_corners(case, dtype):
     from myconvnet_amd import _ffi
     u = _u()
