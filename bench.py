@@ -38,8 +38,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 256; 512 for --model efficientnet_b0)')
-    ap.add_argument('--model', default='resnet50', choices=['resnet50', 'efficientnet_b0'],
-                    help='resnet50 = the headline workload (BASELINE configs[1]/[2]); efficientnet_b0 = configs[3] (secondary, SURVEY 8f-2)')
+    ap.add_argument('--model', default='resnet50', choices=['resnet50', 'efficientnet_b0', 'deeplabv3plus'],
+                    help='resnet50 = the headline workload (BASELINE configs[1]/[2]); efficientnet_b0 = configs[3], deeplabv3plus = configs[4] on one GPU (secondary, SURVEY 8f-2 / 8f-3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
@@ -48,21 +48,25 @@ def parse():
     ap.add_argument('--layers', action='store_true', help='print a per-launch table (stderr) from the instrumented pass')
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 512 if args.model == 'efficientnet_b0' else 256
+        args.batch = {'efficientnet_b0': 512, 'deeplabv3plus': 16}.get(args.model, 256)
     return args
 
 
 def build_model(args, dtype, world):
     import myconvnet_amd as M
-    cls = M.EfficientNetB0 if args.model == 'efficientnet_b0' else M.ResNet50
-    model = cls([224, 224, 3], 1000, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
+    cls = {'efficientnet_b0': M.EfficientNetB0, 'deeplabv3plus': M.DeepLabV3PlusResNet50}.get(args.model, M.ResNet50)
+    size, classes = (513, 19) if args.model == 'deeplabv3plus' else (224, 1000)          # configs[4]: 513x513 synthetic Cityscapes
+    model = cls([size, size, 3], classes, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
                        seed=0, overlap_wgrad=not args.no_overlap, device='cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90,
                               update_ema=not args.no_ema)
     rank = int(os.environ.get('RANK', 0))
     rng = np.random.default_rng(1234 + rank)                               # SURVEY §8d synthetic inputs
-    x = rng.random((args.batch, 224, 224, 3), dtype=np.float32)
-    y = rng.integers(0, 1000, args.batch).astype(np.float32)
+    x = rng.random((args.batch, size, size, 3), dtype=np.float32)
+    if args.model == 'deeplabv3plus':
+        y = rng.integers(0, classes + 1, (args.batch, size, size)).astype(np.float32)   # 0 = ignored pixel
+    else:
+        y = rng.integers(0, classes, args.batch).astype(np.float32)
     model.feed(x, y)                                                       # resident in HBM before the timed region
     torch.cuda.synchronize()
     return model, opt
@@ -246,12 +250,13 @@ def main():
     dt = timed(opt, args.steps, args.warmup, world, args.autotune)
     ms = dt / args.steps * 1e3
     ips = args.batch * world * args.steps / dt
-    if args.model == 'efficientnet_b0':
-        # secondary workload: no MFMA roofline claim (depthwise / BN / SE are HBM-bound); per-call times from the instrumented pass
-        out = {'metric': 'images/sec EfficientNet-B0 224x224 synthetic training step', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
+    if args.model != 'resnet50':
+        # secondary workloads: no single-kernel roofline claim; per-call times from the instrumented pass
+        title = {'efficientnet_b0': ('EfficientNet-B0', 224, 'configs[3]'), 'deeplabv3plus': ('DeepLabv3+ (ResNet-50 OS16 backbone)', 513, 'configs[4]')}[args.model]
+        out = {'metric': 'images/sec {} {}x{} synthetic training step'.format(title[0], title[1], title[1]), 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
-               'config': {'workload': 'EfficientNet-B0 {} 224x224 synthetic ImageNet-1k training step (BASELINE configs[3]), batch={}/GPU'.format(args.dtype, args.batch),
+               'config': {'workload': '{} {} {}x{} synthetic training step (BASELINE {}), batch={}/GPU'.format(title[0], args.dtype, title[1], title[1], title[2], args.batch),
                           'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world), 'ema': not args.no_ema},
                'conv_macs_per_image': int(model.conv_macs), 'params': int(model.params)}
         if world == 1:

@@ -115,8 +115,21 @@ static size_t colsum_parts(long M) {
     if (parts < 1) parts = 1;
     return (size_t)parts;
 }
+// slices of the (image, output row) range for the fallback wgrad: enough blocks to fill the chip, at least 8 rows each
+static int naive_wgrad_slices(const Geo& g) {
+    const long total = (long)g.KH * g.KW * g.Cin * g.Cout, nrows = (long)g.N * g.OH;
+    const long wblocks = (total + 31) / 32;
+    long s = 2048 / (wblocks < 1 ? 1 : wblocks);
+    if (s > nrows / 8) s = nrows / 8;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+}
 static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     size_t b = 0;
+    if (!mfma_path_ok(g, dt)) {
+        const int sl = naive_wgrad_slices(g);
+        if (sl > 1) b += align_up((size_t)sl * g.KH * g.KW * g.Cin * g.Cout * 4, 256);
+    }
     if (mfma_path_ok(g, dt)) {
         const int splits = wgrad_splits(g, dt, nullptr, nullptr);
         const size_t rows = (size_t)g.KH * g.KW * round_up(g.Cin, ce_of(dt));
@@ -473,8 +486,16 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
     if (!mfma_path_ok(g, dt)) {
         NaiveConvParams p = naive_params(g);
         p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
-        hipLaunchKernelGGL((naive_conv_wgrad<T>), dim3(nblocks((long)g.KH * g.KW * g.Cin * g.Cout * 8)), dim3(256), 0, st, p);
+        const long total = (long)g.KH * g.KW * g.Cin * g.Cout;
+        const int sl = naive_wgrad_slices(g);
+        float* part = (float*)wsp;
+        if (sl > 1) wsp += align_up((size_t)sl * total * 4, 256);
+        hipLaunchKernelGGL((naive_conv_wgrad<T>), dim3(nblocks(total * 8), sl), dim3(256), 0, st, p, part);
         MCN_CHECK_LAUNCH();
+        if (sl > 1) {
+            hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, sl, scale);
+            MCN_CHECK_LAUNCH();
+        }
     } else {
         int nsteps, sps;
         const int splits = wgrad_splits(g, dt, &nsteps, &sps);

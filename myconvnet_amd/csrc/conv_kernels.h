@@ -891,15 +891,20 @@ __global__ void naive_conv_dgrad(const NaiveConvParams p) {
         dx[idx] = from_f32<T>(acc);
     }
 }
-// blockDim = (32 weight elements, 8 image slices): the reduction over the batch is split 8 ways and folded through LDS
-// (the squeeze-excite 1x1 convs of EfficientNet land here when their channel counts are not chunk multiples)
+// Fallback wgrad (channel counts that are not chunk multiples: the class-logit conv of the segmentation head, the
+// squeeze-excite convs).  blockDim = (32 weight elements, 8 lanes); the (image, output row) pairs are cut into gridDim.y
+// slices, the 8 lanes of a block stride over their slice and fold through LDS; slice partials go to `part` and are summed
+// in a fixed order by naive_wgrad_reduce (deterministic).  With one slice the result is written directly.
 template <typename T>
-__global__ __launch_bounds__(256) void naive_conv_wgrad(const NaiveConvParams p) {
+__global__ __launch_bounds__(256) void naive_conv_wgrad(const NaiveConvParams p, float* __restrict__ part) {
     __shared__ float red[8][32];
     const long total = (long)p.KH * p.KW * p.Cin * p.Cout;
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* dy = reinterpret_cast<const T*>(p.dy);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long nrows = (long)p.N * p.OH;
+    const long rps = (nrows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * rps, r1 = min(nrows, r0 + rps);
     for (long base = (long)blockIdx.x * 32; base < total; base += (long)gridDim.x * 32) {
         const long idx = base + tx;
         float acc = 0.f;
@@ -909,17 +914,17 @@ __global__ __launch_bounds__(256) void naive_conv_wgrad(const NaiveConvParams p)
             const int c = (int)(r % p.Cin);
             r /= p.Cin;
             const int ks = (int)(r % p.KW), kr = (int)(r / p.KW);
-            for (int n = ty; n < p.N; n += 8)
-                for (int oy = 0; oy < p.OH; ++oy) {
-                    const int iy = oy * p.SH + kr * p.DH - p.padT;
-                    if (iy < 0 || iy >= p.H) continue;
-                    for (int ox = 0; ox < p.OW; ++ox) {
-                        const int ix = ox * p.SW + ks * p.DW - p.padL;
-                        if (ix < 0 || ix >= p.W) continue;
-                        acc = fmaf(to_f32(x[(((long)n * p.H + iy) * p.W + ix) * p.x_cs + c]),
-                                   to_f32(dy[(((long)n * p.OH + oy) * p.OW + ox) * p.Cout + k]), acc);
-                    }
+            for (long row = r0 + ty; row < r1; row += 8) {
+                const int n = (int)(row / p.OH), oy = (int)(row - (long)n * p.OH);
+                const int iy = oy * p.SH + kr * p.DH - p.padT;
+                if (iy < 0 || iy >= p.H) continue;
+                for (int ox = 0; ox < p.OW; ++ox) {
+                    const int ix = ox * p.SW + ks * p.DW - p.padL;
+                    if (ix < 0 || ix >= p.W) continue;
+                    acc = fmaf(to_f32(x[(((long)n * p.H + iy) * p.W + ix) * p.x_cs + c]),
+                               to_f32(dy[(((long)n * p.OH + oy) * p.OW + ox) * p.Cout + k]), acc);
                 }
+            }
         }
         red[ty][tx] = acc;
         __syncthreads();
@@ -927,10 +932,18 @@ __global__ __launch_bounds__(256) void naive_conv_wgrad(const NaiveConvParams p)
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += red[j][tx];
-            p.dw[idx] = s * p.scale;
+            if (gridDim.y == 1) p.dw[idx] = s * p.scale;
+            else part[(long)blockIdx.y * total + idx] = s;
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void naive_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long total, int slices, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += part[(long)k * total + i];
+    dw[i] = s * scale;
 }
 
 // column sums of a [M][C] matrix -> fp32 [C] (bias gradient); two-stage, deterministic

@@ -66,40 +66,63 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
         coef[b] = cf;
     }
 }
-// few classes, many rows (per-pixel loss of the segmentation path, B = N*H*W): one thread per row, two passes over its C
-// logits; same arithmetic as the block-per-row kernel.
-__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
-                                                                const float* __restrict__ class_w, float* __restrict__ pred, float* __restrict__ ce,
-                                                                float* __restrict__ coef, float* __restrict__ dlogits, long B, int C, float ls,
-                                                                float loss_scale) {
-    for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
-        const float* z = logits + b * C;
-        const float* yv = labels + b * C;
-        float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
-        float se = 0.f, sy = 0.f, bw = 0.f;
-        for (int c = 0; c < C; ++c) {
-            se += expf(z[c] - mx);
-            const float y = yv[c];
-            sy += y;
-            bw += y * (class_w ? class_w[c] : 1.f);
+// few classes, many rows (per-pixel loss of the segmentation path, B = N*H*W): a block stages XR_ROWS rows of logits and
+// labels through LDS with coalesced loads (row pitch C|1, odd => conflict-free), one thread owns one row in LDS, results
+// (pred, dlogits) go back through the same LDS tiles and leave coalesced.  Same arithmetic as the block-per-row kernel.
+#define XR_ROWS 256
+__global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                                    const float* __restrict__ class_w, float* __restrict__ pred,
+                                                                    float* __restrict__ ce, float* __restrict__ coef, float* __restrict__ dlogits,
+                                                                    long B, int C, float ls, float loss_scale) {
+    extern __shared__ float xs[];
+    const int P = C | 1;
+    float* zt = xs;
+    float* yt = xs + XR_ROWS * P;
+    for (long b0 = (long)blockIdx.x * XR_ROWS; b0 < B; b0 += (long)gridDim.x * XR_ROWS) {
+        const int rows = (int)min((long)XR_ROWS, B - b0);
+        const long n = (long)rows * C;
+        for (long i = threadIdx.x; i < n; i += XR_ROWS) {
+            const int r = (int)(i / C), c = (int)(i - (long)r * C);
+            zt[r * P + c] = logits[b0 * C + i];
+            yt[r * P + c] = labels[b0 * C + i];
         }
-        const float lse = logf(se);
-        const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
-        const float cf = bw * valid;
-        const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
-        const float gscale = cf * loss_scale / (float)B;
-        float cel = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float lsm = z[c] - mx - lse;
-            const float p = expf(lsm);
-            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
-            cel -= lab * lsm;
-            if (pred) pred[b * C + c] = p;
-            if (dlogits) dlogits[b * C + c] = (p * lab_sum - lab) * gscale;
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            float* z = zt + threadIdx.x * P;
+            float* yv = yt + threadIdx.x * P;
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+            float se = 0.f, sy = 0.f, bw = 0.f;
+            for (int c = 0; c < C; ++c) {
+                se += expf(z[c] - mx);
+                const float y = yv[c];
+                sy += y;
+                bw += y * (class_w ? class_w[c] : 1.f);
+            }
+            const float lse = logf(se);
+            const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
+            const float cf = bw * valid;
+            const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
+            const float gscale = cf * loss_scale / (float)B;
+            float cel = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float lsm = z[c] - mx - lse;
+                const float pr = expf(lsm);
+                const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+                cel -= lab * lsm;
+                z[c] = pr;
+                yv[c] = (pr * lab_sum - lab) * gscale;
+            }
+            ce[b0 + threadIdx.x] = cel;
+            coef[b0 + threadIdx.x] = cf;
         }
-        ce[b] = cel;
-        coef[b] = cf;
+        __syncthreads();
+        for (long i = threadIdx.x; i < n; i += XR_ROWS) {
+            const int r = (int)(i / C), c = (int)(i - (long)r * C);
+            if (pred) pred[b0 * C + i] = zt[r * P + c];
+            if (dlogits) dlogits[b0 * C + i] = yt[r * P + c];
+        }
+        __syncthreads();
     }
 }
 // two-stage mean for many rows: 1024 block partials (written over the first entries of `part`), then one block
@@ -150,11 +173,15 @@ extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* l
                                              float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void* ws,
                                              size_t ws_bytes, void* stream) {
     if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "softmax_xent_rows: bad argument");
+    if (C > 64) MCN_FAIL(MCN_E_UNSUPPORTED, "softmax_xent_rows: C=%d > 64 classes: use mcn_softmax_xent_fwd_bwd", C);
     if (loss && (!ws || ws_bytes < 1024 * sizeof(float))) MCN_FAIL(MCN_E_WORKSPACE, "softmax_xent_rows: workspace needs 4096 bytes");
     hipStream_t st = (hipStream_t)stream;
-    long blocks = ((long)B + 255) / 256;
+    long blocks = ((long)B + XR_ROWS - 1) / XR_ROWS;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, labels, class_w, pred, ce, coef, dlogits, (long)B, C,
+    const size_t lds = (size_t)2 * XR_ROWS * (C | 1) * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XR_ROWS * 65 * 4), true);
+    (void)once;
+    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((unsigned)blocks), dim3(XR_ROWS), lds, st, logits, labels, class_w, pred, ce, coef, dlogits, (long)B, C,
                        label_smoothing, loss_scale);
     MCN_CHECK_LAUNCH();
     if (loss) {

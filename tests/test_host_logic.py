@@ -105,6 +105,24 @@ def test_efficientnet_b0_inventory_matches_reference_counts():
     assert len(rates) == 9 and rates[0] == pytest.approx(0.2 * 2 / 7) and rates[-1] == pytest.approx(0.2 * 6 / 7)
 
 
+def test_deeplab_inventory_and_graph():
+    """DeepLabv3+ / dilated ResNet / SegNet: variable names and shapes equal the oracle's independent
+    restatement; 39,170,995 parameters for the ResNet-50 variant with 19 classes; per-pixel labels and loss."""
+    from oracle import net as ON
+    m = M.DeepLabV3PlusResNet50([513, 513, 3], 19, batch_size=2, auto_compile=False, device='cpu')
+    spec = ON.DeepLabSpec(19)
+    assert sorted((n, tuple(s)) for n, s, _ in spec.variables()) == sorted((v.name, tuple(v.shape)) for v in m._var_order)
+    assert m.params == 39170995
+    assert m.logits.shape == (2, 513, 513, 19) and m.Y.shape == (2, 513, 513, 19) and m._label_shape == (2, 513, 513)
+    assert m.block_list == [None, 0, 1, 2, 3, 4, 5, 6]
+    dil = sorted({(n.attrs['geom'].DH, n.attrs['geom'].SH) for n in m.graph.nodes if n.op == 'conv' and n.attrs['geom'].KH == 3})
+    assert dil == [(1, 1), (1, 2), (2, 2), (4, 1), (6, 1), (8, 1), (12, 1), (18, 1)]      # multi-grid 2,4,8 in block 4 (stride 2 on the first), ASPP 6,12,18
+    r101 = M.DeepLabV3PlusResNet([65, 65, 3], 5, batch_size=2, auto_compile=False, device='cpu')
+    assert r101.res_units == [None, 3, 4, 23, 3] and r101.strides == [2, 1, 2, 2, 1]
+    with pytest.raises(NotImplementedError):
+        M.DeepLabV3PlusResNet50([65, 65, 3], 5, batch_size=2, label_smoothing=0.1, auto_compile=False, device='cpu')
+
+
 def test_lr_schedule_matches_reference_formulas():
     class Fake(M.Optimizer):
         def __init__(self, **kw):

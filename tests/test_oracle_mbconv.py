@@ -186,3 +186,96 @@ def test_efficientnet_two_step_golden(gm):
         np.testing.assert_array_equal(pred.argmax(-1), gm[p + 'argmax'])
         np.testing.assert_allclose([np.linalg.norm(grads[k]) for k in keys], gm[p + 'grad_norms'], rtol=1e-7, atol=1e-12)
         np.testing.assert_allclose([np.linalg.norm(state.params[k]) for k in keys], gm[p + 'param_norms'], rtol=1e-9)
+
+
+# ---- segmentation row: DeepLabv3+ oracle vs torch autograd ------------------------------------------------------
+def _torch_deeplab_forward(spec, P, x):
+    def bn(h, s):
+        mean = h.mean(dim=(0, 1, 2))
+        var = ((h - mean) ** 2).mean(dim=(0, 1, 2))
+        return (h - mean) / torch.sqrt(var + 1e-3) * P[s + '/gamma'] + P[s + '/beta']
+
+    def conv(h, s, stride=1, dil=1, bias=False):
+        w = P[s + '/weights']
+        n, hh, ww, c = h.shape
+        k = w.shape[0]
+        pt, pb, pl, pr = O.resolve_pads(hh, ww, k, k, stride, stride, 'SAME', dil, dil)
+        y = F.conv2d(F.pad(h.permute(0, 3, 1, 2), (pl, pr, pt, pb)), w.permute(3, 2, 0, 1), stride=stride, dilation=dil).permute(0, 2, 3, 1)
+        return y + P[s + '/biases'] if bias else y
+
+    def maxpool(h, k, s, padding):
+        n, hh, ww, c = h.shape
+        pt, pb, pl, pr = O.resolve_pads(hh, ww, k, k, s, s, padding)
+        return F.max_pool2d(F.pad(h.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float('-inf')), k, s).permute(0, 2, 3, 1)
+
+    def resize(h, hw):
+        return F.interpolate(h.permute(0, 3, 1, 2), size=tuple(hw), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+
+    bb = spec.backbone
+    ch = bb.channels
+    h = maxpool(F.relu(bn(conv(x, 'block_0/conv_0', bb.strides[0]), 'block_0/conv_0/bn')), 3, 2, 'SAME')
+    feats = {}
+    cin = ch[0]
+    for i in range(1, len(ch)):
+        for j in range(bb.res_units[i]):
+            s = bb.strides[i] if j == 0 else 1
+            nm = 'block_{}/res_{}'.format(i, j)
+            cout = ch[i]
+            if cin == cout:
+                skip = maxpool(h, s, s, 'VALID') if s > 1 else h
+            else:
+                skip = bn(conv(h, nm + '/conv_skip', s), nm + '/conv_skip/bn')
+            y = F.relu(bn(conv(h, nm + '/conv_0'), nm + '/conv_0/bn'))
+            y = F.relu(bn(conv(y, nm + '/conv_1', s, bb.unit_dilation(i, j)), nm + '/conv_1/bn'))
+            y = bn(conv(y, nm + '/conv_2'), nm + '/conv_2/bn')
+            h = F.relu(y + skip)
+            cin = cout
+        feats[i] = h
+    f4, f1 = feats[4], feats[1]
+    ys = [bn(conv(f4, 'block_5/aspp/conv_0'), 'block_5/aspp/conv_0/norm')]
+    for i, dil in enumerate(spec.aspp_dilations):
+        sc = 'block_5/aspp/conv_{}'.format(i + 1)
+        ys.append(bn(conv(f4, sc, 1, dil), sc + '/norm'))
+    h = bn(conv(torch.cat(ys, -1), 'block_5/aspp/conv_out'), 'block_5/aspp/conv_out/norm')
+    feat = bn(conv(f1, 'block_6/features'), 'block_6/features/norm')
+    h = resize(h, feat.shape[1:3])
+    h = bn(conv(torch.cat([h, feat], -1), 'block_6/decoder/conv_0'), 'block_6/decoder/conv_0/norm')
+    return resize(conv(h, 'block_None/logits', bias=True), x.shape[1:3])
+
+
+def test_deeplab_step_vs_torch_autograd():
+    spec = ON.DeepLabSpec(5, width_div=8, depth_div=3, aspp_dilations=(1, 2, 3))
+    params, stats = ON.init_variables(spec.variables(), seed=7, dtype=np.float64)
+    for k in params:
+        if k.endswith('gamma'):
+            params[k] = 0.5 + RNG.random(params[k].shape)
+        if k.endswith('beta') or k.endswith('biases'):
+            params[k] = 0.1 * RNG.standard_normal(params[k].shape)
+    state = ON.TrainState(params, stats)
+    x = RNG.random((2, 65, 65, 3))
+    y = RNG.integers(0, 6, (2, 65, 65)).astype(np.float64)
+    y[0, 0, :4] = np.nan
+    tape, out, pred, loss, onehot = ON.forward_loss(spec, state, x, y)
+    grads = tape.backward()
+    P = {k: t(v, True) for k, v in params.items()}
+    logits = _torch_deeplab_forward(spec, P, t(O.input_prep(x)))
+    valid = t(onehot.sum(-1))
+    ce = (-(t(onehot) * F.log_softmax(logits, -1)).sum(-1) * valid).mean()     # mean over ALL pixels, ignored ones weigh 0
+    ce.backward()
+    np.testing.assert_allclose(out.a, logits.detach().numpy(), rtol=1e-8, atol=1e-9)
+    l2 = sum((p ** 2).sum() / 2 for k, p in P.items() if k.endswith('/weights')) * 1e-4
+    np.testing.assert_allclose(loss, (ce + l2).item(), rtol=1e-10)
+    assert set(grads) == set(P)
+    for k in P:
+        np.testing.assert_allclose(grads[k], P[k].grad.numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
+
+
+def test_deeplab_known_answers():
+    """DeepLabv3+ on ResNet-50 (BASELINE configs[4]): 25.6M backbone - fc head + ASPP / decoder head; per-class logits."""
+    spec = ON.DeepLabSpec(19)
+    names = [n for n, _, _ in spec.variables()]
+    assert 'block_5/aspp/conv_3/weights' in names and 'block_6/decoder/conv_0/norm/gamma' in names and 'block_None/logits/biases' in names
+    n = sum(int(np.prod(s)) for _, s, k in spec.variables() if k not in ('mu', 'sigma'))
+    backbone = 25557032 - (2048 * 1000 + 1000)
+    head = 2048 * 256 + 3 * 9 * 2048 * 256 + 1024 * 256 + 256 * 48 + 9 * 304 * 256 + 256 * 19 + 19 + 2 * (5 * 256 + 48 + 256)
+    assert n == backbone + head == 39170995
