@@ -57,7 +57,7 @@ def build_model(args, dtype, world):
     cls = {'efficientnet_b0': M.EfficientNetB0, 'deeplabv3plus': M.DeepLabV3PlusResNet50}.get(args.model, M.ResNet50)
     size, classes = (513, 19) if args.model == 'deeplabv3plus' else (224, 1000)          # configs[4]: 513x513 synthetic Cityscapes
     model = cls([size, size, 3], classes, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
-                       seed=0, overlap_wgrad=not args.no_overlap, device='cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
+                       seed=0, overlap_wgrad=not args.no_overlap, device='cuda:{}'.format(local_device()))
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90,
                               update_ema=not args.no_ema)
     rank = int(os.environ.get('RANK', 0))
@@ -234,6 +234,12 @@ def cpu_baseline():
                        'the reference TF-1.x CPU path cannot run in this image')
 
 
+def local_device():
+    """GPU index of this rank: LOCAL_RANK (one process per GPU); MCN_BENCH_DEVICE overrides it (rehearsing several ranks on a
+    one-GPU box with MCN_DIST_BACKEND=gloo)."""
+    return int(os.environ.get('MCN_BENCH_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -241,10 +247,10 @@ def main():
     assert world == args.gpus, '--gpus {} but WORLD_SIZE={} (launch with torch.distributed.run for N>1)'.format(args.gpus, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(local_device())
     if world > 1:
         from myconvnet_amd.dist import init_process_group
-        init_process_group('cuda:{}'.format(int(os.environ.get('LOCAL_RANK', 0))))
+        init_process_group('cuda:{}'.format(local_device()))
 
     model, opt = build_model(args, args.dtype, world)
     dt = timed(opt, args.steps, args.warmup, world, args.autotune)

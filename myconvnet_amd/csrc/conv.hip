@@ -139,7 +139,7 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     return b;
 }
 
-extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 3; }
+extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return 4; }    /* NT: 128x128, 128x64, 64x64, 256x128 (bf16); TN: 4 shapes */
 
 extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
@@ -169,7 +169,10 @@ static void allow_lds(K kernel, int bytes) {
 // (A body/tail split — big tiles for whole rounds, small tiles for the remainder in a second launch — was measured
 // and lost 4 %: the kernel boundary costs more than the shorter tail saves.)
 #define MCN_NUM_CU 256
-struct NtTile { int bm, bn; };
+struct NtTile { int bm, bn, nw; };
+// candidate 3 (256x128, 8 waves) is bf16 only: fp32 is MFMA-bound and prefers the smallest tile
+static const NtTile kNtCand[4] = {{128, 128, 4}, {128, 64, 4}, {64, 64, 4}, {256, 128, 8}};
+#define MCN_NT_CANDS 4
 static inline double nt_tile_work(int c, size_t es) {
     static const double w[3] = {128.0 * 128, 128.0 * 64, 64.0 * 64};
     static const double f32[3] = {1.08, 1.03, 1.00}, bf16[3] = {1.00, 1.08, 1.35};
@@ -178,8 +181,9 @@ static inline double nt_tile_work(int c, size_t es) {
 template <typename T>
 static int pick_nt_tile(int M, int Nn, int hint = 0) {
     if (hint >= 1 && hint <= 3) return hint - 1;
+    if (hint == 4 && sizeof(T) == 2 && Nn > 64) return 3;      // 256x128 / 8 waves: bf16 only; otherwise the heuristic below
     static const int forced = [] { const char* e = getenv("MCN_NT_TILE"); return e ? atoi(e) : -1; }();
-    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const NtTile* cand = kNtCand;
     int best = Nn <= 64 ? 1 : 0;
     double best_cost = -1;
     for (int c = 0; c < 3; ++c) {
@@ -194,14 +198,14 @@ static int pick_nt_tile(int M, int Nn, int hint = 0) {
 
 template <typename T>
 static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, bool taps, hipStream_t st) {
-    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const NtTile* cand = kNtCand;
     const NtTile t = cand[tile];
     p.m_begin = m_begin;
     p.m_end = m_end;
     const int ntm = (m_end - m_begin + t.bm - 1) / t.bm, ntn = (p.Nn + t.bn - 1) / t.bn;
     if (ntm <= 0 || ntn <= 0) return MCN_OK;
     const int lds = 2 * (t.bm + t.bn) * 128;
-    const dim3 grid(ntm * ntn), block(256);
+    const dim3 grid(ntm * ntn), block(t.nw * 64);
     const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
 #define MCN_LAUNCH_NT(BMV, BNV, MODEV)                                               \
     do {                                                                             \
@@ -215,7 +219,22 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
         else if (mode == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NT_UNIFORM); \
         else MCN_LAUNCH_NT(BMV, BNV, NT_GENERIC);                       \
     } while (0)
-    if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_NT_MODE(128, 128);
+    if (t.bm == 256) {
+        if constexpr (sizeof(T) == 2) {
+#define MCN_LAUNCH_NT8(MODEV)                                                                        \
+    do {                                                                                             \
+        static bool once = (allow_lds(conv_gemm_nt<T, 256, 128, MODEV, 8>, 2 * (256 + 128) * 128), true); \
+        (void)once;                                                                                  \
+        hipLaunchKernelGGL((conv_gemm_nt<T, 256, 128, MODEV, 8>), grid, block, lds, st, p);          \
+    } while (0)
+            if (mode == NT_LINEAR) MCN_LAUNCH_NT8(NT_LINEAR);
+            else if (mode == NT_UNIFORM) MCN_LAUNCH_NT8(NT_UNIFORM);
+            else MCN_LAUNCH_NT8(NT_GENERIC);
+#undef MCN_LAUNCH_NT8
+        } else {
+            MCN_FAIL(MCN_E_UNSUPPORTED, "conv: 256x128 tile is bf16 only");
+        }
+    } else if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_NT_MODE(128, 128);
     else if (t.bm == 128) MCN_LAUNCH_NT_MODE(128, 64);
     else MCN_LAUNCH_NT_MODE(64, 64);
 #undef MCN_LAUNCH_NT_MODE
@@ -351,10 +370,11 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     if ((dtype != MCN_F32 && dtype != MCN_BF16) || !mfma_path_ok(g, dtype)) return 0;
     const long M = (long)g.N * g.OH * g.OW;
     if (M <= 0) return 0;
-    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const NtTile* cand = kNtCand;
     const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
-    if (rows_per_partial) *rows_per_partial = cand[t].bm / 2;
-    return (int32_t)(2 * ((M + cand[t].bm - 1) / cand[t].bm));
+    const int wrows = cand[t].nw / 2;
+    if (rows_per_partial) *rows_per_partial = cand[t].bm / wrows;
+    return (int32_t)(wrows * ((M + cand[t].bm - 1) / cand[t].bm));
 }
 extern "C" int mcn_conv2d_fwd_bnstats(const void* x, const float* w, const void* w_packed, const float* bias, void* y, float* stats_partials,
                                       const mcn_conv_geom* gg, mcn_dtype dtype, mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
@@ -632,14 +652,15 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!buf || buflen < 64) MCN_FAIL(MCN_E_BADARG, "kernel_name: buffer too small");
     const char* tn = dtype == MCN_F32 ? "float" : "bf16";
     const int ce = ce_of(dtype);
-    const NtTile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const NtTile* cand = kNtCand;
     if (op == MCN_CONV_FWD) {
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
         const long M = (long)g.N * g.OH * g.OW;
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
+        if (cand[t].nw == 8) snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, 8>", tn, cand[t].bm, cand[t].bn, mode);
+        else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
         return 1;
     }
     if (op == MCN_CONV_DGRAD) {
@@ -659,7 +680,8 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
+        if (cand[t].nw == 8) snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, 8>", tn, cand[t].bm, cand[t].bn, mode);
+        else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, mode);
         return ncls;
     }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }

@@ -152,13 +152,18 @@ struct LaneFold<C, 0> {
 // MODE 2 (NT_GENERIC): a K-step may straddle taps (stem: 1-2 chunks per tap); per-thread tap decode from an LDS table.
 enum { NT_LINEAR = 0, NT_UNIFORM = 1, NT_GENERIC = 2 };
 
-template <typename T, int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
+// NW waves per workgroup: 4 = 2x2 waves, 8 = 4x2 waves (BM = 256: the B tile is shared by four wave rows — 25 % fewer
+// operand bytes per FLOP out of L2 than 128x128 at the same waves, registers and LDS per CU as two 4-wave workgroups).
+template <typename T, int BM, int BN, int MODE, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
     constexpr bool TAPS = MODE != NT_LINEAR;
-    constexpr int AR = BM / 32, BR = BN / 32;          // staged chunks per thread
-    constexpr int WTM = BM / 2, WTN = BN / 2;          // wave tile (2x2 waves)
+    constexpr int NT = NW * 64;                        // threads
+    constexpr int RPP = NT / 8;                        // tile rows covered by one staging pass (8 chunks per row)
+    constexpr int WROWS = NW / 2;                      // wave rows (x 2 wave columns)
+    constexpr int AR = BM / RPP, BR = BN / RPP;        // staged chunks per thread
+    constexpr int WTM = BM / WROWS, WTN = BN / 2;      // wave tile
     constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
     constexpr int TILE_BYTES = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     int a_y[AR], a_x[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + crow + 32 * i;
+        const int m = m0 + crow + RPP * i;
         const bool mv = m < p.m_end;
         if (TAPS) {
             const int mm = mv ? m : 0;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
     unsigned b_off[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        const int n = n0 + crow + 32 * i;
+        const int n = n0 + crow + RPP * i;
         b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u + (unsigned)cid * 16u : MCN_OOB;
     }
     const int wr_off = crow * 128 + ((cid ^ ((crow >> 1) & 7)) << 4);
@@ -259,9 +264,9 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
         char* a = smem + buf * TILE_BYTES;
         char* b = a + BM * 128;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<i32x4*>(a + wr_off + i * 32 * 128) = ra[S][i];
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<i32x4*>(a + wr_off + i * RPP * 128) = ra[S][i];
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<i32x4*>(b + wr_off + i * 32 * 128) = rb[S][i];
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<i32x4*>(b + wr_off + i * RPP * 128) = rb[S][i];
     };
 
     typename MM::Acc acc[TN][TM];
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(const GemmNTParams p) {
         int base = 0;
         bool writer = true;
         LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
-        const int prow = ((m0 - p.m_begin) / BM) * 2 + wm;
+        const int prow = ((m0 - p.m_begin) / BM) * WROWS + wm;
         const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
         const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
         const int n = n0 + wn * WTN + j * MM::MT + nl + e;

@@ -506,3 +506,38 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         check(u.host(sm), ref['save_mean'], 'float32', 'save_mean', rel=1e-5, mx=1e-4)
         check(u.host(si), ref['save_invstd'], 'float32', 'save_invstd', rel=1e-5)
         check(u.host(rv), ref['running_var'], 'float32', 'running_var', rel=1e-5)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 14, 14, 128, 256, 1, 1), (3, 9, 11, 72, 136, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 28, 28, 64, 64, 3, 1)])
+def test_conv_tile_candidates_agree(case, dtype):
+    """mcn_conv_geom.tile (the autotuning hook): every tile candidate of forward and dgrad — incl. the 8-wave 256x128
+    bf16 tile — computes the same convolution (same products, same K order per output: bit-identical results)."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k, s = case
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    w = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    y0 = u.conv_fwd(x, w, s, 'SAME', 1, dtype)
+    dy = RNG.standard_normal(y0.shape).astype(np.float32)
+    dx0 = u.conv_dgrad(dy, w, x.shape, s, 'SAME', 1, dtype)
+    check(y0, O.conv2d_fwd(q(x, dtype), q(w, dtype), s, 'SAME'), dtype, 'fwd')
+    names = set()
+    for tile in range(1, lib.mcn_conv2d_tile_candidates(_ffi.CONV_FWD) + 1):
+        g = u.geom(x.shape, w.shape, s, 'SAME')
+        g.tile = tile
+        buf = ctypes.create_string_buffer(128)
+        lib.mcn_conv2d_kernel_name(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype], buf, 128)
+        names.add(buf.value.decode())
+        xd, wd, dyd = u.dev(x, dtype), u.dev(w), u.dev(dy, dtype)
+        y = torch.full(y0.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        dx = torch.full(x.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        ws = u.workspace(max(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]),
+                             lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype])))
+        _ffi.check(lib.mcn_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+        np.testing.assert_array_equal(u.host(y), y0, err_msg='fwd tile {}'.format(tile))
+        _ffi.check(lib.mcn_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+        np.testing.assert_array_equal(u.host(dx), dx0, err_msg='dgrad tile {}'.format(tile))
+    if dtype == 'bfloat16' and cout > 64:
+        assert any(nm.endswith(', 8>') for nm in names), names               # the 8-wave tile was exercised
