@@ -154,7 +154,10 @@ enum { NT_LINEAR = 0, NT_UNIFORM = 1, NT_GENERIC = 2 };
 
 // NW waves per workgroup: 4 = 2x2 waves, 8 = 4x2 waves (BM = 256: the B tile is shared by four wave rows — 25 % fewer
 // operand bytes per FLOP out of L2 than 128x128 at the same waves, registers and LDS per CU as two 4-wave workgroups).
-template <typename T, int BM, int BN, int MODE, int NW = 4>
+// GLDS: stage the tiles with LDS-DMA loads (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass).  A
+// wave-instruction writes 1 KiB of LDS linearly (8 rows x 128 B in lane order), so the XOR swizzle of the LDS image is
+// applied on the SOURCE side: the lane at slot s of row r fetches chunk s ^ key(r).  Two LDS buffers, one barrier per K-step.
+template <typename T, int BM, int BN, int MODE, int NW = 4, bool GLDS = false>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
@@ -190,7 +193,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
 
-    const int crow = tid >> 3, cid = tid & 7;
+    const int crow = tid >> 3;
+    const int cid = GLDS ? ((tid & 7) ^ ((crow >> 1) & 7)) : (tid & 7);   // K chunk this thread fetches (GLDS: pre-swizzled source)
     // per-thread A rows: byte offset of the row's pixel at tap offset (0,0) + its grid coordinates for the bounds test
     unsigned a_off[AR];
     int a_y[AR], a_x[AR];
@@ -218,15 +222,29 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
         const int n = n0 + crow + RPP * i;
         b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u + (unsigned)cid * 16u : MCN_OOB;
     }
-    const int wr_off = crow * 128 + ((cid ^ ((crow >> 1) & 7)) << 4);
+    const int wr_off = crow * 128 + (((tid & 7) ^ (GLDS ? 0 : ((crow >> 1) & 7))) << 4);   // GLDS: lane-linear (= tid * 16)
     const int pix_bytes = p.Cs * (int)sizeof(T);
     const int kpt = p.cpt >> 3;                          // K-steps per tap (NT_UNIFORM)
 
     // two staging register sets: the global loads of K-step ks+2 are issued while step ks is computed and step ks+1
     // is still in flight (prefetch distance 2: twice the bytes in flight per CU against L2 / HBM latency)
-    i32x4 ra[2][AR], rb[2][BR];
+    i32x4 ra[GLDS ? 1 : 2][GLDS ? 1 : AR], rb[GLDS ? 1 : 2][GLDS ? 1 : BR];
+    // LDS-DMA destination of this wave for staging pass i: wave-uniform base (M0), the hardware adds lane * 16
+    auto dma = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int lds_byte) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + __builtin_amdgcn_readfirstlane(lds_byte)), 16, (int)off, 0, 0, 0);
+    };
+    // setc: staging register set (register path) or LDS buffer index (GLDS)
     auto issue = [&](int ks, auto setc) {
         constexpr int S = decltype(setc)::value;
+        const int ldsA = S * TILE_BYTES + wave * 1024, ldsB = ldsA + BM * 128;
+        auto ldA = [&](int i, unsigned off) {
+            if constexpr (GLDS) dma(rsA, off, ldsA + i * RPP * 128);
+            else ra[S][i] = buf_load16(rsA, off);
+        };
+        auto ldB = [&](int i, unsigned off) {
+            if constexpr (GLDS) dma(rsB, off, ldsB + i * RPP * 128);
+            else rb[S][i] = buf_load16(rsB, off);
+        };
         if (MODE == NT_UNIFORM) {
             const int tap = ks / kpt;                    // wave-uniform (scalar ALU)
             const int cb = ks - tap * kpt;
@@ -235,13 +253,13 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ra[S][i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
+                ldA(i, ok ? a_off[i] + toff : MCN_OOB);
             }
         } else if (MODE == NT_LINEAR) {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) ra[S][i] = buf_load16(rsA, kv ? a_off[i] + (unsigned)ks * 128u : MCN_OOB);
+            for (int i = 0; i < AR; ++i) ldA(i, kv ? a_off[i] + (unsigned)ks * 128u : MCN_OOB);
         } else {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
@@ -252,12 +270,12 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = kv && (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ra[S][i] = buf_load16(rsA, ok ? a_off[i] + toff : MCN_OOB);
+                ldA(i, ok ? a_off[i] + toff : MCN_OOB);
             }
         }
         const bool kvb = MODE == NT_UNIFORM || (ks * 8 + cid) < p.nchunks;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[S][i] = buf_load16(rsB, kvb ? b_off[i] + (unsigned)ks * 128u : MCN_OOB);   // OOB + small stays OOB
+        for (int i = 0; i < BR; ++i) ldB(i, kvb ? b_off[i] + (unsigned)ks * 128u : MCN_OOB);   // OOB + small stays OOB
     };
     auto commit = [&](int buf, auto setc) {
         constexpr int S = decltype(setc)::value;
@@ -315,47 +333,70 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
 #endif
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
-    issue(0, S0{});
-    if (nk > 1) issue(1, S1{});
-    commit(0, S0{});
-    __syncthreads();
-#ifdef MCN_ABL_STAMP
-    st_t1 = __builtin_amdgcn_s_memtime();
-#endif
-    load_frags(0, 0, smem);
-    // one K-step: LDS buffer `buf` holds step ks, register set CS holds step ks+1 (in flight), set IS is free
-    auto kstep = [&](int ks, int buf, auto cs, auto is) {
-        const char* base = smem + buf * TILE_BYTES;
-#if !defined(MCN_ABL_NOLOAD) && !defined(MCN_ABL_NOISSUE)
-        if (ks + 2 < nk) issue(ks + 2, is);
-#endif
+    if constexpr (GLDS) {
+        // LDS-DMA pipeline: buffer `cur` holds step ks (its DMA was issued one step ago), the DMA of step ks+1 into the
+        // other buffer is issued right after the barrier that retires that buffer's readers and flies under this
+        // step's MFMAs.  vmcnt(0) + barrier per step: own DMA landed, then everybody's.
+        auto gstep = [&](int ks, auto cur, auto nxt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ks + 1 < nk) issue(ks + 1, nxt);
+            const char* base = smem + decltype(cur)::value * TILE_BYTES;
+            load_frags(0, 0, base);
 #pragma unroll
-        for (int s = 0; s + 1 < MM::SLABS; ++s) {
-            load_frags((s + 1) & 1, s + 1, base);
-            mma_set(s & 1);
+            for (int s = 0; s < MM::SLABS; ++s) {
+                if (s + 1 < MM::SLABS) load_frags((s + 1) & 1, s + 1, base);
+                mma_set(s & 1);
+            }
+        };
+        issue(0, S0{});
+        for (int ks = 0; ks < nk; ks += 2) {
+            gstep(ks, S0{}, S1{});
+            if (ks + 1 < nk) gstep(ks + 1, S1{}, S0{});
         }
-#if defined(MCN_ABL_NOCOMMIT)
-        if (ks + 1 < nk) {                                   // ablation: keep the global loads alive without the LDS writes
-            constexpr int S = decltype(cs)::value;
-#pragma unroll
-            for (int i = 0; i < AR; ++i) abl_sink ^= ra[S][i][0] ^ ra[S][i][3];
-#pragma unroll
-            for (int i = 0; i < BR; ++i) abl_sink ^= rb[S][i][0] ^ rb[S][i][3];
-        }
-#elif !defined(MCN_ABL_NOLOAD)
-        if (ks + 1 < nk) commit(buf ^ 1, cs);
-#endif
-#ifndef MCN_ABL_NOBARRIER
+    } else {
+        issue(0, S0{});
+        if (nk > 1) issue(1, S1{});
+        commit(0, S0{});
         __syncthreads();
-#endif
-        if (ks + 1 < nk) load_frags(0, 0, smem + (buf ^ 1) * TILE_BYTES);
-        mma_set(1);
-    };
-    for (int ks = 0; ks < nk; ks += 2) {
-        kstep(ks, 0, S1{}, S0{});
-        if (ks + 1 < nk) kstep(ks + 1, 1, S0{}, S1{});
-    }
+    #ifdef MCN_ABL_STAMP
+        st_t1 = __builtin_amdgcn_s_memtime();
+    #endif
+        load_frags(0, 0, smem);
+        // one K-step: LDS buffer `buf` holds step ks, register set CS holds step ks+1 (in flight), set IS is free
+        auto kstep = [&](int ks, int buf, auto cs, auto is) {
+            const char* base = smem + buf * TILE_BYTES;
+    #if !defined(MCN_ABL_NOLOAD) && !defined(MCN_ABL_NOISSUE)
+            if (ks + 2 < nk) issue(ks + 2, is);
+    #endif
+    #pragma unroll
+            for (int s = 0; s + 1 < MM::SLABS; ++s) {
+                load_frags((s + 1) & 1, s + 1, base);
+                mma_set(s & 1);
+            }
+    #if defined(MCN_ABL_NOCOMMIT)
+            if (ks + 1 < nk) {                                   // ablation: keep the global loads alive without the LDS writes
+                constexpr int S = decltype(cs)::value;
+    #pragma unroll
+                for (int i = 0; i < AR; ++i) abl_sink ^= ra[S][i][0] ^ ra[S][i][3];
+    #pragma unroll
+                for (int i = 0; i < BR; ++i) abl_sink ^= rb[S][i][0] ^ rb[S][i][3];
+            }
+    #elif !defined(MCN_ABL_NOLOAD)
+            if (ks + 1 < nk) commit(buf ^ 1, cs);
+    #endif
+    #ifndef MCN_ABL_NOBARRIER
+            __syncthreads();
+    #endif
+            if (ks + 1 < nk) load_frags(0, 0, smem + (buf ^ 1) * TILE_BYTES);
+            mma_set(1);
+        };
+        for (int ks = 0; ks < nk; ks += 2) {
+            kstep(ks, 0, S1{}, S0{});
+            if (ks + 1 < nk) kstep(ks + 1, 1, S0{}, S1{});
+        }
 
+    }
 #ifdef MCN_ABL_NOCOMMIT
     if (abl_sink == 0x12345678) acc[0][0][0] += 1.f;
 #endif
