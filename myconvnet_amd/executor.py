@@ -25,7 +25,9 @@ class Lowering(object):
         self.prepack = Program()       # one launch: cast / re-pack every conv weight from its fp32 master (or EMA shadow)
         self.ws = None
         self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
-        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', True))   # BN statistics in the conv epilogue
+        # BN statistics in the conv epilogue: on for bf16 (+2-3 % end to end); fp32's 1x1 convs are output-bound and the
+        # epilogue costs them what the skipped statistics pass saves, so fp32 keeps the separate pass unless asked
+        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', graph.dtype == 'bfloat16'))
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.scratch = {}
 

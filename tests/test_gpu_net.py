@@ -25,11 +25,11 @@ BATCH = 8
 LABELS = np.array([1, 7, 3, 9, 0, 4, 4, 2], dtype=np.float32)
 
 
-def make_resnet(kind, dtype, fuse, batch=BATCH, size=64, classes=10):
+def make_resnet(kind, dtype, fuse, batch=BATCH, size=64, classes=10, **kw):
     import myconvnet_amd as M
     cls = M.ResNet50 if kind == 50 else M.ResNet18
     spec = ON.ResNetSpec.resnet50(classes, 8) if kind == 50 else ON.ResNetSpec.resnet18(classes, 8)
-    model = cls([size, size, 3], classes, batch_size=batch, width_div=8, fuse=fuse, half_precision=(dtype == 'bfloat16'), num_gpus=1)
+    model = cls([size, size, 3], classes, batch_size=batch, width_div=8, fuse=fuse, half_precision=(dtype == 'bfloat16'), num_gpus=1, **kw)
     params, stats = ON.init_variables(spec.variables(), seed=3, dtype=np.float32)
     rng = np.random.default_rng(9)
     # Non-trivial BN parameters (zero-init gammas would hide the residual branches) chosen so that the tiny test network
@@ -71,6 +71,29 @@ def test_resnet_two_steps_fp32(kind, fuse):
         ema = model.get_variables('ema')
         worst = max((rel_l2(ema[k], v), k) for k, v in list(state.ema.items()) + list(state.ema_stats.items()))
         assert worst[0] <= 1e-4, 'step {}: worst EMA {}'.format(step, worst)
+
+
+def test_resnet_fp32_bn_statistics_from_conv_epilogue():
+    """fuse_bn_stats (default on for bf16 only): the fp32 network with the BN statistics taken in the conv epilogues."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(61)
+    model, spec, params, stats = make_resnet(50, 'float32', True, fuse_bn_stats=True)
+    assert any(getattr(fn, '__name__', '') == 'mcn_bn_fwd_train_fused' for fn, _ in model._train_low.fwd.calls)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    for step in range(2):
+        x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+        model.feed(x, LABELS)
+        loss, _, y_pred = opt._step(None)
+        rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), batch_total=BATCH)
+        assert abs(loss - rloss) <= 1e-4 * abs(rloss)
+        assert rel_l2(y_pred, rpred) <= 1e-4
+        grads = model.get_variables('grad')
+        worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
+        assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+        got = model.get_variables('data')
+        worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
+        assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
 
 
 def cosine(a, b):
