@@ -182,6 +182,8 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout
                 nl = lib.mcn_conv2d_kernel_name(ops[name], ctypes.byref(gm), mdt, buf, 128)
                 key = buf.value.decode()
+                if name == 'mcn_conv2d_fwd_bnstats':                       # the instantiation with the BN-statistics epilogue
+                    key = key.replace(', false>', ', true>')
                 es = 4 if dtype == 'fp32' else 2
                 # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)
                 xe = gm.N * gm.H * gm.W * gm.Cin if (gm.KH > 1 or gm.SH == 1) else gm.N * oh * ow * gm.Cin

@@ -104,7 +104,8 @@ int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njobs, mcn_dty
 int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, void* stream);
 
 /* profiling aid: writes the name of the GEMM kernel a conv call launches (as rocprofv3 prints it) into buf
- * (>= 64 bytes) and returns how many launches of it the call makes (stride-2 dgrad: one per parity class). */
+ * (>= 64 bytes) and returns how many launches of it the call makes (stride-2 dgrad: one per parity class).  For
+ * mcn_conv2d_fwd_bnstats the last template argument of the printed name is `true` instead of `false`. */
 int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype, char* buf, size_t buflen);
 
 /* replaces Conv2DBackpropFilter.  dw:[KH][KW][Cin][Cout] fp32 (overwritten; deterministic

@@ -207,12 +207,16 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
     const int lds = 2 * (t.bm + t.bn) * 128;
     const dim3 grid(ntm * ntn), block(t.nw * 64);
     const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
-    constexpr bool GL = sizeof(T) == 2;      // bf16 stages its tiles with LDS-DMA loads (measured 5-13 % faster per layer); fp32: registers
+    constexpr int GL = sizeof(T) == 2 ? 2 : 0;     // bf16 stages its tiles with LDS-DMA loads (measured 5-13 % faster per layer); fp32: registers
+#define MCN_LAUNCH_NT_S(BMV, BNV, MODEV, STV)                                        \
+    do {                                                                             \
+        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, 4, GL, STV>, 2 * (BMV + BNV) * 128), true); \
+        (void)once;                                                                  \
+        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, 4, GL, STV>), grid, block, lds, st, p); \
+    } while (0)
 #define MCN_LAUNCH_NT(BMV, BNV, MODEV)                                               \
     do {                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, 4, GL>, 2 * (BMV + BNV) * 128), true); \
-        (void)once;                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, 4, GL>), grid, block, lds, st, p); \
+        if (p.stats) MCN_LAUNCH_NT_S(BMV, BNV, MODEV, true); else MCN_LAUNCH_NT_S(BMV, BNV, MODEV, false); \
     } while (0)
 #define MCN_LAUNCH_NT_MODE(BMV, BNV)                                    \
     do {                                                                \
@@ -222,16 +226,21 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
     } while (0)
     if (t.bm == 256) {
         if constexpr (sizeof(T) == 2) {
+#define MCN_LAUNCH_NT8_S(MODEV, STV)                                                                 \
+    do {                                                                                             \
+        static bool once = (allow_lds(conv_gemm_nt<T, 256, 128, MODEV, 8, 2, STV>, 2 * (256 + 128) * 128), true); \
+        (void)once;                                                                                  \
+        hipLaunchKernelGGL((conv_gemm_nt<T, 256, 128, MODEV, 8, 2, STV>), grid, block, lds, st, p);  \
+    } while (0)
 #define MCN_LAUNCH_NT8(MODEV)                                                                        \
     do {                                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, 256, 128, MODEV, 8, true>, 2 * (256 + 128) * 128), true); \
-        (void)once;                                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, 256, 128, MODEV, 8, true>), grid, block, lds, st, p);    \
+        if (p.stats) MCN_LAUNCH_NT8_S(MODEV, true); else MCN_LAUNCH_NT8_S(MODEV, false);             \
     } while (0)
             if (mode == NT_LINEAR) MCN_LAUNCH_NT8(NT_LINEAR);
             else if (mode == NT_UNIFORM) MCN_LAUNCH_NT8(NT_UNIFORM);
             else MCN_LAUNCH_NT8(NT_GENERIC);
 #undef MCN_LAUNCH_NT8
+#undef MCN_LAUNCH_NT8_S
         } else {
             MCN_FAIL(MCN_E_UNSUPPORTED, "conv: 256x128 tile is bf16 only");
         }
@@ -240,6 +249,7 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
     else MCN_LAUNCH_NT_MODE(64, 64);
 #undef MCN_LAUNCH_NT_MODE
 #undef MCN_LAUNCH_NT
+#undef MCN_LAUNCH_NT_S
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -330,8 +340,7 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
         for (int s = 0; s < g.KW; ++s) {
             const int t = r * g.KW + s;
             pk.tr[t] = (signed char)r; pk.ts[t] = (signed char)s;
-            p.tdy[t] = (signed char)(r * g.DH - g.pT);
-            p.tdx[t] = (signed char)(s * g.DW - g.pL);
+            p.tap[t] = ((r * g.DH - g.pT) & 0xffff) | ((s * g.DW - g.pL) << 16);
         }
     if (!w_packed) {                                     // per-use cast / re-pack of the fp32 master (convnet.py:1421-1422)
         int rc = launch_pack<T>(pk, st);
@@ -447,7 +456,7 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         bool zero_off = true;
         for (int t = 0; t < c.nt; ++t) {
             pk.tr[t] = c.r[t]; pk.ts[t] = c.s[t];
-            p.tdy[t] = c.dy[t]; p.tdx[t] = c.dx[t];
+            p.tap[t] = ((int)c.dy[t] & 0xffff) | ((int)c.dx[t] << 16);
             if (c.dy[t] || c.dx[t]) zero_off = false;
         }
         int rc = MCN_OK;
@@ -660,7 +669,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, %s>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw, dtype == MCN_BF16 ? "true" : "false");
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw, dtype == MCN_BF16 ? 2 : 0);
         return 1;
     }
     if (op == MCN_CONV_DGRAD) {
@@ -680,7 +689,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, %s>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw, dtype == MCN_BF16 ? "true" : "false");
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw, dtype == MCN_BF16 ? 2 : 0);
         return ncls;
     }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }

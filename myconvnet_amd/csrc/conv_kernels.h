@@ -47,8 +47,8 @@ struct GemmNTParams {
     int osy, osx, oy0, ox0; // scatter of the sub-grid into the full output grid
     int accumulate;
     unsigned in_bytes, wt_bytes;
-    signed char tdy[MCN_MAX_TAPS];
-    signed char tdx[MCN_MAX_TAPS];
+    int tap[MCN_MAX_TAPS];  // (dy & 0xffff) | (dx << 16) per filter tap: 32-bit so that a wave-uniform tap index is a scalar load
+                            // (byte tables are fetched with vector loads whose waits drain the LDS-DMA queue)
 };
 
 struct GemmTNParams {
@@ -156,8 +156,17 @@ enum { NT_LINEAR = 0, NT_UNIFORM = 1, NT_GENERIC = 2 };
 // operand bytes per FLOP out of L2 than 128x128 at the same waves, registers and LDS per CU as two 4-wave workgroups).
 // GLDS: stage the tiles with LDS-DMA loads (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass).  A
 // wave-instruction writes 1 KiB of LDS linearly (8 rows x 128 B in lane order), so the XOR swizzle of the LDS image is
-// applied on the SOURCE side: the lane at slot s of row r fetches chunk s ^ key(r).  Two LDS buffers, one barrier per K-step.
-template <typename T, int BM, int BN, int MODE, int NW = 4, bool GLDS = false>
+// applied on the SOURCE side: the lane at slot s of row r fetches chunk s ^ key(r).  GLDS = 2: two LDS buffers, the DMA of
+// step ks+1 is issued after the barrier of step ks and flies under that step's MFMAs (vmcnt(0) + one barrier per K-step).
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <typename T, int BM, int BN, int MODE, int NW = 4, int GLDS = 0, bool STATS = false>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
@@ -184,8 +193,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
 
     if (MODE == NT_GENERIC) {
         if (tid < MCN_MAX_TAPS) {
-            s_tdy[tid] = p.tdy[tid];
-            s_tdx[tid] = p.tdx[tid];
+            s_tdy[tid] = (signed char)(short)(p.tap[tid] & 0xffff);
+            s_tdx[tid] = (signed char)(p.tap[tid] >> 16);
         }
         __syncthreads();
     }
@@ -230,36 +239,41 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     // is still in flight (prefetch distance 2: twice the bytes in flight per CU against L2 / HBM latency)
     i32x4 ra[GLDS ? 1 : 2][GLDS ? 1 : AR], rb[GLDS ? 1 : 2][GLDS ? 1 : BR];
     // LDS-DMA destination of this wave for staging pass i: wave-uniform base (M0), the hardware adds lane * 16
-    auto dma = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int lds_byte) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + __builtin_amdgcn_readfirstlane(lds_byte)), 16, (int)off, 0, 0, 0);
+    // (wave base + compile-time constant: distinct constants let the compiler see that the DMAs of different buffers do
+    // not overlap — with an opaque address it orders every new DMA behind all outstanding ones with vmcnt waits)
+    __attribute__((address_space(3))) char* const wbase =
+        (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto dma = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, auto ldsc) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(wbase + decltype(ldsc)::value), 16, (int)off, 0, 0, 0);
     };
     // setc: staging register set (register path) or LDS buffer index (GLDS)
     auto issue = [&](int ks, auto setc) {
         constexpr int S = decltype(setc)::value;
-        const int ldsA = S * TILE_BYTES + wave * 1024, ldsB = ldsA + BM * 128;
-        auto ldA = [&](int i, unsigned off) {
-            if constexpr (GLDS) dma(rsA, off, ldsA + i * RPP * 128);
+        auto ldA = [&](auto ic, unsigned off) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (GLDS) dma(rsA, off, std::integral_constant<int, S * TILE_BYTES + i * RPP * 128>{});
             else ra[S][i] = buf_load16(rsA, off);
         };
-        auto ldB = [&](int i, unsigned off) {
-            if constexpr (GLDS) dma(rsB, off, ldsB + i * RPP * 128);
+        auto ldB = [&](auto ic, unsigned off) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (GLDS) dma(rsB, off, std::integral_constant<int, S * TILE_BYTES + BM * 128 + i * RPP * 128>{});
             else rb[S][i] = buf_load16(rsB, off);
         };
         if (MODE == NT_UNIFORM) {
             const int tap = ks / kpt;                    // wave-uniform (scalar ALU)
             const int cb = ks - tap * kpt;
-            const int dy = p.tdy[tap], dx = p.tdx[tap];
+            const int tw = p.tap[tap];
+            const int dy = (short)(tw & 0xffff), dx = tw >> 16;
             const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + cb * 128);
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
+            static_for<AR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ldA(i, ok ? a_off[i] + toff : MCN_OOB);
-            }
+                ldA(ic, ok ? a_off[i] + toff : MCN_OOB);
+            });
         } else if (MODE == NT_LINEAR) {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
-#pragma unroll
-            for (int i = 0; i < AR; ++i) ldA(i, kv ? a_off[i] + (unsigned)ks * 128u : MCN_OOB);
+            static_for<AR>([&](auto ic) { ldA(ic, kv ? a_off[decltype(ic)::value] + (unsigned)ks * 128u : MCN_OOB); });
         } else {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
@@ -267,15 +281,14 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
             const int cc = j - tap * p.cpt;
             const int dy = s_tdy[tap], dx = s_tdx[tap];
             const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + (cc - cid) * 16);
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
+            static_for<AR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 const bool ok = kv && (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ldA(i, ok ? a_off[i] + toff : MCN_OOB);
-            }
+                ldA(ic, ok ? a_off[i] + toff : MCN_OOB);
+            });
         }
         const bool kvb = MODE == NT_UNIFORM || (ks * 8 + cid) < p.nchunks;
-#pragma unroll
-        for (int i = 0; i < BR; ++i) ldB(i, kvb ? b_off[i] + (unsigned)ks * 128u : MCN_OOB);   // OOB + small stays OOB
+        static_for<BR>([&](auto ic) { ldB(ic, kvb ? b_off[decltype(ic)::value] + (unsigned)ks * 128u : MCN_OOB); });   // OOB + small stays OOB
     };
     auto commit = [&](int buf, auto setc) {
         constexpr int S = decltype(setc)::value;
@@ -337,17 +350,22 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
         // LDS-DMA pipeline: buffer `cur` holds step ks (its DMA was issued one step ago), the DMA of step ks+1 into the
         // other buffer is issued right after the barrier that retires that buffer's readers and flies under this
         // step's MFMAs.  vmcnt(0) + barrier per step: own DMA landed, then everybody's.
-        auto gstep = [&](int ks, auto cur, auto nxt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (ks + 1 < nk) issue(ks + 1, nxt);
-            const char* base = smem + decltype(cur)::value * TILE_BYTES;
+        auto compute = [&](const char* base) {
             load_frags(0, 0, base);
 #pragma unroll
             for (int s = 0; s < MM::SLABS; ++s) {
                 if (s + 1 < MM::SLABS) load_frags((s + 1) & 1, s + 1, base);
                 mma_set(s & 1);
             }
+        };
+        // (A three-buffer variant that keeps the DMA of step ks+2 in flight across the barrier — counted vmcnt, raw
+        // s_barrier — was measured and is not faster at these tile sizes: with two workgroups per CU the other
+        // workgroup already covers the wait.  It needs every other load out of the loop: see GemmNTParams::tap.)
+        auto gstep = [&](int ks, auto cur, auto nxt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ks + 1 < nk) issue(ks + 1, nxt);
+            compute(smem + decltype(cur)::value * TILE_BYTES);
         };
         issue(0, S0{});
         for (int ks = 0; ks < nk; ks += 2) {
@@ -409,8 +427,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     // written as one partial row per (M tile, wave row): the separate read of y by the BN statistics pass disappears.
     T* out = reinterpret_cast<T*>(p.out);
     constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
-    float s1[TN][NG][4], s2[TN][NG][4], piv[TN][NG][4];
-    const bool do_stats = p.stats != nullptr;
+    float s1[STATS ? TN : 1][NG][4], s2[STATS ? TN : 1][NG][4], piv[STATS ? TN : 1][NG][4];
+    constexpr bool do_stats = STATS;             // compile-time: the plain instantiation carries no statistics code
     if (do_stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
