@@ -207,12 +207,11 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
     const int lds = 2 * (t.bm + t.bn) * 128;
     const dim3 grid(ntm * ntn), block(t.nw * 64);
     const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
-    constexpr int GL = sizeof(T) == 2 ? 2 : 0;     // bf16 stages its tiles with LDS-DMA loads (measured 5-13 % faster per layer); fp32: registers
 #define MCN_LAUNCH_NT_S(BMV, BNV, MODEV, STV)                                        \
     do {                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, 4, GL, STV>, 2 * (BMV + BNV) * 128), true); \
+        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, 4, STV>, 2 * (BMV + BNV) * 128), true); \
         (void)once;                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, 4, GL, STV>), grid, block, lds, st, p); \
+        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, 4, STV>), grid, block, lds, st, p); \
     } while (0)
 #define MCN_LAUNCH_NT(BMV, BNV, MODEV)                                               \
     do {                                                                             \
@@ -228,9 +227,9 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
         if constexpr (sizeof(T) == 2) {
 #define MCN_LAUNCH_NT8_S(MODEV, STV)                                                                 \
     do {                                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, 256, 128, MODEV, 8, 2, STV>, 2 * (256 + 128) * 128), true); \
+        static bool once = (allow_lds(conv_gemm_nt<T, 256, 128, MODEV, 8, STV>, 2 * (256 + 128) * 128), true); \
         (void)once;                                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, 256, 128, MODEV, 8, 2, STV>), grid, block, lds, st, p);  \
+        hipLaunchKernelGGL((conv_gemm_nt<T, 256, 128, MODEV, 8, STV>), grid, block, lds, st, p);  \
     } while (0)
 #define MCN_LAUNCH_NT8(MODEV)                                                                        \
     do {                                                                                             \
@@ -669,7 +668,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw, dtype == MCN_BF16 ? 2 : 0);
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return 1;
     }
     if (op == MCN_CONV_DGRAD) {
@@ -689,7 +688,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw, dtype == MCN_BF16 ? 2 : 0);
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return ncls;
     }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
