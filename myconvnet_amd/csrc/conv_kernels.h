@@ -522,8 +522,11 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 
-    // ---- X staging: fixed column (tap, c) per thread, XN pixel rows -------------------------
-    const int xcc = tid % XCPR, xpr = tid / XCPR;
+    // ---- X staging (LDS-DMA): the thread at linear LDS slot (pixel row xpr, slot tid % XCPR) fetches the chunk that the
+    // swizzled image keeps there (bf16: 32-byte granule g of row p sits at granule g ^ key(p); XPR is a multiple of 16,
+    // so the key is the same for all of a thread's rows); fixed column (tap, c) per thread, XN pixel rows ----
+    const int xpr = tid / XCPR, xsl = tid % XCPR;
+    const int xcc = sizeof(T) == 2 ? ((((xsl >> 1) ^ (tn_key(xpr) & XGM)) << 1) | (xsl & 1)) : xsl;
     const int gcol = r0 + xcc * CE;
     const bool xcol_ok = gcol < p.rows;
     int xt = 0, xc = gcol;
@@ -550,14 +553,18 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
         }
     }
     // ---- D staging ---------------------------------------------------------------------------
-    const int dcc = tid % DCPR, dpr = tid / DCPR;
+    const int dpr = tid / DCPR, dsl = tid % DCPR;
+    const int dcc = sizeof(T) == 2 ? ((((dsl >> 1) ^ (tn_key(dpr) & DGM)) << 1) | (dsl & 1)) : dsl;
     const int dn = n0 + dcc * CE;
     const bool dcol_ok = dn < p.Nn;
 
-    i32x4 rx[XN], rd[DN];
-    auto issue = [&](int ks) {
-#pragma unroll
-        for (int i = 0; i < XN; ++i) {
+    static_assert(XPR * XRS == 4096 && DPR * DRS == 4096, "one staging pass of the workgroup = 4 KiB of LDS");
+    __attribute__((address_space(3))) char* const wbase =
+        (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto issue = [&](int ks, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        static_for<XN>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const int m = ks * KP + xpr + XPR * i;
             unsigned off = MCN_OOB;
             if (LINEAR) {
@@ -573,37 +580,16 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
                 if (py[i] >= p.OH) { py[i] -= p.OH; pimg[i] += 1; }
                 pimg[i] += dKi;
             }
-            rx[i] = buf_load16(rsX, off);
-        }
-#pragma unroll
-        for (int i = 0; i < DN; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * 4096)), 16, (int)off, 0, 0, 0);
+        });
+        static_for<DN>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const int m = ks * KP + dpr + DPR * i;
             unsigned off = MCN_OOB;
             if (dcol_ok && m < p.M) off = ((unsigned)m * (unsigned)p.ldy + (unsigned)dn) * (unsigned)sizeof(T);
-            rd[i] = buf_load16(rsD, off);
-        }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + XBYTES + i * 4096)), 16, (int)off, 0, 0, 0);
+        });
     };
-    auto commit = [&](int buf) {
-        char* xs = smem + buf * TILE_BYTES;
-        char* ds = xs + XBYTES;
-#pragma unroll
-        for (int i = 0; i < XN; ++i) {
-            const int pr = xpr + XPR * i;
-            int off;
-            if (sizeof(T) == 2) off = pr * XRS + ((((xcc >> 1) ^ (tn_key(pr) & XGM))) << 5) + ((xcc & 1) << 4);
-            else off = pr * XRS + xcc * 16;
-            *reinterpret_cast<i32x4*>(xs + off) = rx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < DN; ++i) {
-            const int pr = dpr + DPR * i;
-            int off;
-            if (sizeof(T) == 2) off = pr * DRS + ((((dcc >> 1) ^ (tn_key(pr) & DGM))) << 5) + ((dcc & 1) << 4);
-            else off = pr * DRS + dcc * 16;
-            *reinterpret_cast<i32x4*>(ds + off) = rd[i];
-        }
-    };
-
     constexpr int ACCN = CF::MT == 16 ? 4 : 16;
     float acc[TR][TNn][ACCN];
 #pragma unroll
@@ -613,15 +599,15 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) acc[i][j][e] = 0.f;
 
-    if (ks0 < ks1) {
-        issue(ks0);
-        commit(0);
-    }
-    __syncthreads();
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const int buf = (ks - ks0) & 1;
-        if (ks + 1 < ks1) issue(ks + 1);
-        const char* xs = smem + buf * TILE_BYTES;
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
+    // one K-step (KP pixels) from LDS buffer `buf`; the DMA of the next step goes to the other buffer right after the
+    // barrier that retires its readers and flies under this step's MFMAs
+    auto kstep = [&](int ks, auto cur, auto nxt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < ks1) issue(ks + 1, nxt);
+        const char* xs = smem + decltype(cur)::value * TILE_BYTES;
         const char* ds = xs + XBYTES;
         if constexpr (sizeof(T) == 2) {
             // bf16: 16x16x32; operand rows come from transposing reads of the pixel-major tiles
@@ -682,8 +668,11 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
                     }
             }
         }
-        if (ks + 1 < ks1) commit(buf ^ 1);
-        __syncthreads();
+    };
+    if (ks0 < ks1) issue(ks0, B0{});
+    for (int ks = ks0; ks < ks1; ks += 2) {
+        kstep(ks, B0{}, B1{});
+        if (ks + 1 < ks1) kstep(ks + 1, B1{}, B0{});
     }
 
     // ---- store the partial tile to this split's slab (row-major [rows][Nn]) --------------------
