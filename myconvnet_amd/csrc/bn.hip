@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // ---- host ------------------------------------------------------------------------------------------
-#define BN_TARGET_BLOCKS 2048
+#define BN_TARGET_BLOCKS 1024
 static size_t bn_parts_bytes(long M, int C) {
     // worst case over vector widths: gy <= BN_TARGET_BLOCKS
     return align_up((size_t)BN_TARGET_BLOCKS * 2 * C * sizeof(float), 256);

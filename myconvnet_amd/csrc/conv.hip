@@ -548,9 +548,14 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         }
         const long total = (long)ntaps * g.Cin * g.Cout;
         const int nsp = M > 0 ? splits : 0;
-        if (Cp == g.Cin && total % 4 == 0 && (((uintptr_t)dw) & 15) == 0)
-            hipLaunchKernelGGL(wgrad_reduce_linear_kernel, dim3(nblocks(total / 4, 2048)), dim3(256), 0, st, (const float*)wsp, dw, nsp, total / 4, scale);
-        else
+        if (Cp == g.Cin && total % 4 == 0 && (((uintptr_t)dw) & 15) == 0) {
+            // lanes per output vector: enough workgroups to cover the chip even for the smallest filters
+            const long t4 = total / 4;
+            const float* sl = (const float*)wsp;
+            if (t4 >= 256 * 256 || nsp < 8) hipLaunchKernelGGL((wgrad_reduce_linear_kernel<1>), dim3(nblocks(t4, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
+            else if (t4 >= 64 * 256 || nsp < 32) hipLaunchKernelGGL((wgrad_reduce_linear_kernel<4>), dim3(nblocks(t4 * 4, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
+            else hipLaunchKernelGGL((wgrad_reduce_linear_kernel<16>), dim3(nblocks(t4 * 16, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
+        } else
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks(total, 2048)), dim3(256), 0, st, (const float*)wsp, dw, nsp, ntaps, Cp, g.Cin, g.Cout, scale);
         MCN_CHECK_LAUNCH();
         wsp += align_up((size_t)splits * p.rows * g.Cout * 4, 256);

@@ -713,21 +713,42 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 // Cp == Cin (every conv but the stem): the slab rows are the HWIO rows, so the reduction is a plain strided sum of
-// `splits` arrays — 16-byte lanes, 4 independent slab loads in flight per thread
+// `splits` arrays — 16-byte lanes.  SL lanes share one output vector and take the splits s = l, l+SL, ... (small filters
+// have few output vectors and up to 512 splits: one thread per output was a serial chain of ~500 dependent-issue loads in
+// a handful of workgroups); the SL partial sums are folded through LDS in a fixed order (deterministic).
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_linear_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
                                                                   long total4, float scale) {
+    constexpr int VPB = 256 / SL;                                 // output vectors per block
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
     const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
     f32x4* d4 = reinterpret_cast<f32x4*>(dw);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-        int k = 0;
-        for (; k + 3 < splits; k += 4) {
-            const f32x4 v0 = s4[(long)k * total4 + i], v1 = s4[(long)(k + 1) * total4 + i];
-            const f32x4 v2 = s4[(long)(k + 2) * total4 + i], v3 = s4[(long)(k + 3) * total4 + i];
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    const int v = threadIdx.x % VPB, l = threadIdx.x / VPB;
+    for (long i0 = (long)blockIdx.x * VPB; i0 < total4; i0 += (long)gridDim.x * VPB) {
+        const long i = i0 + v;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        if (i < total4) {
+            int k = l;
+            for (; k + SL < splits; k += 2 * SL) {
+                const f32x4 v0 = s4[(long)k * total4 + i], v1 = s4[(long)(k + SL) * total4 + i];
+                a0 += v0; a1 += v1;
+            }
+            if (k < splits) a0 += s4[(long)k * total4 + i];
         }
-        for (; k < splits; ++k) a0 += s4[(long)k * total4 + i];
-        d4[i] = ((a0 + a1) + (a2 + a3)) * scale;
+        a0 += a1;
+        if (SL == 1) {
+            if (i < total4) d4[i] = a0 * scale;
+        } else {
+            red[l * VPB + v] = a0;
+            __syncthreads();
+            if (l == 0 && i < total4) {
+                f32x4 t = red[v];
+#pragma unroll
+                for (int j = 1; j < SL; ++j) t += red[j * VPB + v];
+                d4[i] = t * scale;
+            }
+            __syncthreads();
+        }
     }
 }
 
