@@ -14,6 +14,9 @@ At N=1 the line also carries:
   cpu_baseline — the NumPy oracle ("port"; the reference's TF-CPU path cannot run here) timed on the host cores on a
                  bounded sample (same network, B=8)
   bf16         — a secondary measurement of the same step in bf16 (the north-star arithmetic), unless --dtype bf16.
+roofline.traffic = HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh; null if absent).
+--model efficientnet_b0 | deeplabv3plus: BASELINE configs[3] / configs[4] on one GPU (secondary workloads, no roofline object).
+--no-overlap: wgrad on the main stream (profiling: per-kernel averages are then not stretched by co-running kernels).
 """
 import argparse
 import json

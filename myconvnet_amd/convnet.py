@@ -395,12 +395,7 @@ class ConvNet(object):
     def autotune(self):
         """Pin the fastest measured tile shape for every conv launch (call after a few steps, buffers hold real data);
         the eval lowering inherits the forward choices."""
-        chosen = self._train_low.autotune()
-        from . import _ffi as F
-        for n in self.graph.nodes:
-            if n.op == 'conv' and 'geom_op' in n.attrs and F.CONV_FWD in n.attrs['geom_op']:
-                pass                                    # both lowerings share the per-op geometry objects of the node
-        return chosen
+        return self._train_low.autotune()     # both lowerings share the per-op geometry objects of each conv node
 
     def forward(self, train=True):
         low = self._train_low if train else self._eval_low
