@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from .graph import FlatStore, Graph, Tensor, Variable, out_size, same_pads
+from .graph import FlatStore, Graph, Variable, out_size, same_pads
 
 
 # ---- initializers (reference passes tf.initializers.* objects) -----------------------------------------

@@ -1,7 +1,6 @@
 """Lowering of graph Nodes to C-ABI launch lists (forward, backward) — the only place that calls
 libmcn_hip.  Every emit_* function cites the reference op it stands for in include/mcn.h."""
 import ctypes
-import os
 
 import torch
 
@@ -109,7 +108,7 @@ class Lowering(object):
         self.overlap_wgrad = self.train and bool(self.model._parameters.get('overlap_wgrad', True)) and self.g.device.type == 'cuda'
         if self.overlap_wgrad:
             self.ws2 = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=self.g.device)
-            self.bwd.side_stream = torch.cuda.Stream(device=self.g.device, priority=int(os.environ.get('MCN_SIDE_PRIO', '0')))
+            self.bwd.side_stream = torch.cuda.Stream(device=self.g.device)      # (stream priorities were measured: no effect)
         self.plan_packed_weights()
         for n in self.g.nodes:
             getattr(self, 'fwd_' + n.op)(n)

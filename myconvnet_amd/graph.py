@@ -12,7 +12,6 @@ import numpy as np
 import torch
 
 from . import _ffi
-from ._ffi import lib
 
 TORCH_DT = {'float32': torch.float32, 'bfloat16': torch.bfloat16}
 MCN_DT = {'float32': _ffi.F32, 'bfloat16': _ffi.BF16}

@@ -12,7 +12,6 @@ import time
 import numpy as np
 import torch
 
-from . import _ffi
 from ._ffi import lib
 from .graph import Program
 
