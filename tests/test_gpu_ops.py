@@ -455,7 +455,8 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('case', [(4, 14, 14, 64, 64, 3, 1), (2, 28, 28, 32, 128, 1, 1), (3, 9, 11, 72, 136, 3, 1), (2, 16, 16, 16, 32, 3, 2), (8, 14, 14, 256, 64, 1, 1)])
+@pytest.mark.parametrize('case', [(4, 14, 14, 64, 64, 3, 1), (2, 28, 28, 32, 128, 1, 1), (3, 9, 11, 72, 136, 3, 1), (2, 16, 16, 16, 32, 3, 2), (8, 14, 14, 256, 64, 1, 1),
+                                  (16, 56, 56, 16, 32, 1, 1)])      # last: > 512 partial rows -> the folded (two-stage) merge
 def test_conv_epilogue_bn_statistics(case, dtype):
     """conv -> BN fusion: the conv writes per-(M tile, wave row) column sums / sums of squares of the values it stores;
     mcn_bn_fwd_train_fused must give what mcn_bn_fwd_train gives on the same conv output (same tf.nn.fused_batch_norm

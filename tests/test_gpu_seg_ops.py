@@ -99,3 +99,57 @@ def test_seg_labels_and_per_pixel_loss():
                                                  dl2.data_ptr(), loss2.data_ptr(), B, c, 0.0, 1.0, u.stream()))
     check(u.host(pred2), u.host(pred), 'float32', 'pred (two entry points)', rel=1e-6)
     check(u.host(dl2), u.host(dl), 'float32', 'dlogits (two entry points)', rel=1e-6)
+
+
+def test_full_size_properties_seg_and_mbconv():
+    """Size-independent properties at the full layer sizes of BASELINE configs[3] / configs[4] (reduced batch):
+    adjointness <dy, op(x)> == <op^T(dy), x> of the depthwise conv (and == <wgrad, w>) and of the bilinear resize,
+    and the row properties of the per-pixel loss on a 513x513 class map."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    rng = np.random.default_rng(77)
+    # EfficientNet-B0 block_2 depthwise 3x3/2 on 112x112x96 and block_6 5x5/1 on 14x14x672
+    for (n, h, c, k, s) in [(4, 112, 96, 3, 2), (8, 14, 672, 5, 1)]:
+        x = rng.standard_normal((n, h, h, c)).astype(np.float32)
+        w = (rng.standard_normal((k, k, c, 1)) / k).astype(np.float32)
+        y = u.dwconv_fwd(x, w, s, 'SAME')
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        lhs = float((dy.astype(np.float64) * y).sum())
+        dx = u.dwconv_dgrad(dy, w, x.shape, s, 'SAME')
+        dw = u.dwconv_wgrad(x, dy, k, s, 'SAME')
+        assert abs(lhs - float((dx.astype(np.float64) * x).sum())) <= 1e-4 * abs(lhs) + 1e-2
+        assert abs(lhs - float((dw.astype(np.float64) * w).sum())) <= 1e-4 * abs(lhs) + 1e-2
+    # DeepLab: ASPP output 33x33x256 -> 129x129, class map 129x129x19 -> 513x513
+    for (n, h, c, oh) in [(2, 33, 256, 129), (2, 129, 19, 513)]:
+        x = rng.standard_normal((n, h, h, c)).astype(np.float32)
+        dy = rng.standard_normal((n, oh, oh, c)).astype(np.float32)
+        xd, dyd = u.dev(x), u.dev(dy)
+        y = torch.zeros((n, oh, oh, c), dtype=torch.float32, device=u.DEV)
+        dx = torch.zeros((n, h, h, c), dtype=torch.float32, device=u.DEV)
+        _ffi.check(_ffi.lib.mcn_resize_bilinear_fwd(xd.data_ptr(), y.data_ptr(), n, h, h, c, oh, oh, 1, _ffi.F32, u.stream()))
+        _ffi.check(_ffi.lib.mcn_resize_bilinear_bwd(dyd.data_ptr(), dx.data_ptr(), n, h, h, c, oh, oh, 1, _ffi.F32, u.stream()))
+        lhs = float((dy.astype(np.float64) * u.host(y)).sum())
+        rhs = float((u.host(dx).astype(np.float64) * x).sum())
+        assert abs(lhs - rhs) <= 1e-5 * abs(lhs) + 1e-2
+        assert abs(u.host(dx).sum(dtype=np.float64) - dy.sum(dtype=np.float64)) <= 1e-4 * np.abs(dy).sum()   # interpolation weights sum to 1
+    # per-pixel loss at 513x513, 19 classes
+    n, hw, c = 2, 513, 19
+    labels = rng.integers(0, c + 1, (n, hw, hw)).astype(np.float32)
+    logits = rng.standard_normal((n, hw, hw, c)).astype(np.float32)
+    B = n * hw * hw
+    ld, zd = u.dev(labels), u.dev(logits)
+    oh_ = torch.zeros((B, c), dtype=torch.float32, device=u.DEV)
+    pred, dl = torch.zeros((B, c), dtype=torch.float32, device=u.DEV), torch.zeros((B, c), dtype=torch.float32, device=u.DEV)
+    ce, coef = torch.zeros(B, dtype=torch.float32, device=u.DEV), torch.zeros(B, dtype=torch.float32, device=u.DEV)
+    loss = torch.zeros(4, dtype=torch.float32, device=u.DEV)
+    ws = u.workspace(4096)
+    _ffi.check(_ffi.lib.mcn_one_hot_seg(ld.data_ptr(), oh_.data_ptr(), B, c, u.stream()))
+    _ffi.check(_ffi.lib.mcn_softmax_xent_rows_fwd_bwd(zd.data_ptr(), oh_.data_ptr(), 0, pred.data_ptr(), ce.data_ptr(), coef.data_ptr(), dl.data_ptr(),
+                                                      loss.data_ptr(), B, c, 0.0, 1.0, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    p, g, cf, cel = u.host(pred), u.host(dl), u.host(coef), u.host(ce)
+    valid = labels.reshape(-1) > 0
+    np.testing.assert_array_equal(cf, valid.astype(np.float32))
+    np.testing.assert_allclose(p.sum(-1), 1.0, rtol=1e-5)
+    assert np.abs(g.sum(-1)).max() <= 1e-9                                      # each row of dlogits sums to 0
+    assert np.abs(g[~valid]).max() == 0.0                                       # ignored pixels carry no gradient
+    assert abs(float(loss[0].item()) - float((cel.astype(np.float64) * cf).sum() / B)) <= 1e-5
