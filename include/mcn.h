@@ -124,10 +124,14 @@ int mcn_conv2d_wgrad(const void* x, const void* dy, float* dw_hwio, float* dbias
  * save_mean / save_invstd (fp32 [C]) are kept for the backward pass.  `skip` (same shape as y,
  * may be NULL) is the residual branch of stochastic_depth(drop_rate=0) (convnet.py:2511) and
  * `act` the following tf.nn.relu (convnet.py:2537), both fused.
+ * relu_mask (may be NULL; mcn_bn_relu_mask_bytes(M, C, dtype) bytes, needs C % chunk == 0): with act == RELU the apply
+ * pass also writes [y > 0] as one byte per 16-byte chunk; mcn_bn_bwd reads it instead of y (1/16 of the bytes) — meant
+ * for the BNs with a fused residual, whose mask cannot be recomputed from x alone.
  * workspace: mcn_bn_workspace_bytes(M, C). */
 size_t mcn_bn_workspace_bytes(int64_t M, int32_t C);
+size_t mcn_bn_relu_mask_bytes(int64_t M, int32_t C, mcn_dtype dtype);
 int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* skip, void* y,
-                     float* save_mean, float* save_invstd, float* batch_mean, float* batch_var,
+                     uint8_t* relu_mask, float* save_mean, float* save_invstd, float* batch_mean, float* batch_var,
                      float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
                      mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -141,8 +145,8 @@ int mcn_conv2d_fwd_bnstats(const void* x, const float* w_hwio, const void* w_pac
                            float* stats_partials, const mcn_conv_geom* geom, mcn_dtype dtype, mcn_layout layout,
                            void* workspace, size_t workspace_bytes, void* stream);
 int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma,
-                           const float* beta, const void* skip, void* y, float* save_mean, float* save_invstd,
-                           float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum,
+                           const float* beta, const void* skip, void* y, uint8_t* relu_mask, float* save_mean,
+                           float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum,
                            int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* workspace,
                            size_t workspace_bytes, void* stream);
 
@@ -153,6 +157,7 @@ int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const
 
 /* replaces FusedBatchNormGrad [+ ReluGrad + the add's gradient fan-out].
  * dy: gradient w.r.t. the (activated) output y.  If act == RELU the mask [y > 0] is applied first:
+ *   relu_mask != NULL : mask from the byte mask mcn_bn_fwd_train wrote (y is ignored);
  *   y != NULL : mask from the stored forward output (required when the forward fused a residual `skip`);
  *   y == NULL : mask recomputed from x as [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0], the expression the
  *               forward apply pass evaluated (saves one read of y per pass; forward without `skip` only).
@@ -160,7 +165,7 @@ int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const
  *   dz = dy * (s + z*s*(1-s)), s = sigmoid(z); no fused residual (dskip must be NULL), y is ignored.
  * dskip (may be NULL): receives the masked dy, i.e. the gradient of the residual branch.
  * dgamma/dbeta fp32 [C], multiplied by grad_scale. */
-int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
+int mcn_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask, const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta,
                float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
                size_t workspace_bytes, void* stream);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_kernel(
 template <typename T, int VEC, bool SKIP, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, long M, int C,
-                                                       int TX, int TY, long rpb) {
+                                                       int TX, int TY, long rpb, unsigned char* __restrict__ mask = nullptr) {
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int col = blockIdx.x * TX + tx;
     if (ty >= TY || col * VEC >= C) return;
@@ -208,15 +208,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         ldv<T, VEC>(x + off, v);
         float s[VEC];
         if (SKIP) ldv<T, VEC>(skip + off, s);
+        unsigned bits = 0;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float o = fmaf(v[i], sc[i], sh[i]);
             if (SKIP) o += s[i];
-            if (ACT == 1) o = fmaxf(o, 0.f);
+            if (ACT == 1) {
+                bits |= (o > 0.f ? 1u : 0u) << i;
+                o = fmaxf(o, 0.f);
+            }
             if (ACT == 2) o = o / (1.f + expf(-o));          // swish = z*sigmoid(z) (convnet.py:2553)
             v[i] = o;
         }
         stv<T, VEC>(y + off, v);
+        // ReLU mask, one byte per 16-byte chunk: the backward of a BN with a fused residual reads it instead of y
+        if (ACT == 1 && VEC > 1 && mask) mask[r * (C / VEC) + col] = (unsigned char)bits;
     }
 }
 
@@ -230,6 +236,8 @@ __device__ __forceinline__ float swish_grad(float z) {
 // [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0] — the same fp32 expression the forward apply pass evaluated, so
 // the mask is the forward's; saves one full read of y in each backward pass (only valid without a fused residual).
 // RELU == 3: swish, dz = dy * (s + z*s*(1-s)), s = sigmoid(z), z recomputed from x the same way (no residual).
+// RELU == 4: mask from the bit mask the forward apply pass wrote (one byte per 16-byte chunk; `y` then points to it):
+//            1/16 of the bytes of reading y itself — used for the BNs with a fused residual.
 template <typename T, int VEC, int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -260,10 +268,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             ldv<T, VEC>(dy + off, g);
             ldv<T, VEC>(x + off, v);
             if (RELU == 1) ldv<T, VEC>(y + off, o);
+            unsigned bits = 0;
+            if (RELU == 4) bits = reinterpret_cast<const unsigned char*>(y)[r * (C / VEC) + col];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float gg = g[i];
                 if (RELU == 1) gg = o[i] > 0.f ? gg : 0.f;
+                if (RELU == 4) gg = (bits >> i) & 1u ? gg : 0.f;
                 if (RELU == 2) gg = fmaf(v[i], sc[i], sh[i]) > 0.f ? gg : 0.f;
                 if (RELU == 3) gg *= swish_grad(fmaf(v[i], sc[i], sh[i]));
                 s1[i] += gg;
@@ -342,9 +353,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         ldv<T, VEC>(dy + off, g);
         ldv<T, VEC>(x + off, v);
         if (RELU == 1) ldv<T, VEC>(y + off, o);
+        unsigned bits = 0;
+        if (RELU == 4) bits = reinterpret_cast<const unsigned char*>(y)[r * (C / VEC) + col];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             if (RELU == 1) g[i] = o[i] > 0.f ? g[i] : 0.f;
+            if (RELU == 4) g[i] = (bits >> i) & 1u ? g[i] : 0.f;
             if (RELU == 2) g[i] = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
             if (RELU == 3) g[i] *= swish_grad(fmaf(v[i], sc[i], sh[i]));
             const float xh = (v[i] - mu[i]) * is[i];
@@ -367,7 +381,7 @@ extern "C" size_t mcn_bn_workspace_bytes(int64_t M, int32_t C) {
 }
 
 template <typename T, int VEC>
-static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* skip, void* y, float* save_mean,
+static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* skip, void* y, unsigned char* relu_mask, float* save_mean,
                           float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
                           float momentum, long M, int C, float eps, mcn_act act, void* ws, hipStream_t st) {
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
@@ -383,7 +397,7 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     const int a = (int)act;
 #define BN_APPLY(SK, RL)                                                                                                   \
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, (const float*)scale, \
-                       (const float*)shift, M, C, L.TX, L.TY, L.rpb)
+                       (const float*)shift, M, C, L.TX, L.TY, L.rpb, relu_mask)
     if (skip) { if (a == 1) BN_APPLY(true, 1); else if (a == 2) BN_APPLY(true, 2); else BN_APPLY(true, 0); }
     else { if (a == 1) BN_APPLY(false, 1); else if (a == 2) BN_APPLY(false, 2); else BN_APPLY(false, 0); }
     MCN_CHECK_LAUNCH();
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kern
 
 template <typename T, int VEC>
 static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp, const float* gamma, const float* beta, const void* skip, void* y,
-                          float* save_mean, float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
+                          unsigned char* relu_mask, float* save_mean, float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
                           float momentum, long M, int C, float eps, mcn_act act, void* ws, hipStream_t st) {
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     double* fold = (double*)ws;                                  // BN_FOLD_ROWS*2*C doubles fit the partial area of the workspace
@@ -492,7 +506,7 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
     const int a = (int)act;
 #define BN_APPLY_F(SK, RL)                                                                                                   \
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC, SK, RL>), grid, block, 0, st, (const T*)x, (const T*)skip, (T*)y, (const float*)scale, \
-                       (const float*)shift, M, C, L.TX, L.TY, L.rpb)
+                       (const float*)shift, M, C, L.TX, L.TY, L.rpb, relu_mask)
     if (skip) { if (a == 1) BN_APPLY_F(true, 1); else if (a == 2) BN_APPLY_F(true, 2); else BN_APPLY_F(true, 0); }
     else { if (a == 1) BN_APPLY_F(false, 1); else if (a == 2) BN_APPLY_F(false, 2); else BN_APPLY_F(false, 0); }
 #undef BN_APPLY_F
@@ -500,22 +514,27 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
     return MCN_OK;
 }
 extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta,
-                                      const void* skip, void* y, float* save_mean, float* save_invstd, float* batch_mean, float* batch_var,
-                                      float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps, mcn_act act,
-                                      mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+                                      const void* skip, void* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, float* batch_mean,
+                                      float* batch_var, float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
+                                      mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     if (rows_per_partial <= 0 || (int64_t)nparts * rows_per_partial < M) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: partials do not cover M rows");
     if (!x || !y || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 4) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MCN_F32) return bn_fwd_fused_t<float, 4>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+    if (dtype == MCN_F32) return bn_fwd_fused_t<float, 4>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
     if (dtype == MCN_BF16) {
-        if (C % 8 == 0) return bn_fwd_fused_t<bf16_t, 8>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        if (C % 8 == 0) return bn_fwd_fused_t<bf16_t, 8>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
         MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: bf16 needs C %% 8 == 0");
     }
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: dtype %d unsupported", (int)dtype);
 }
 
-extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* skip, void* y, float* save_mean,
+extern "C" size_t mcn_bn_relu_mask_bytes(int64_t M, int32_t C, mcn_dtype dtype) {
+    const int vec = dtype == MCN_F32 ? 4 : 8;
+    if (M <= 0 || C <= 0 || C % vec) return 0;
+    return (size_t)M * (C / vec);
+}
+extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* skip, void* y, uint8_t* relu_mask, float* save_mean,
                                 float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
                                 float momentum, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes,
                                 void* stream) {
@@ -523,12 +542,12 @@ extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* 
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) {
-        if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
-        return bn_fwd_train_t<float, 1>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        return bn_fwd_train_t<float, 1>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
     }
     if (dtype == MCN_BF16) {
-        if (C % 8 == 0) return bn_fwd_train_t<bf16_t, 8>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
-        return bn_fwd_train_t<bf16_t, 1>(x, gamma, beta, skip, y, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        if (C % 8 == 0) return bn_fwd_train_t<bf16_t, 8>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        return bn_fwd_train_t<bf16_t, 1>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
     }
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train: dtype %d unsupported", (int)dtype);
 }
@@ -539,6 +558,7 @@ static int channel_affine_t(const void* x, const float* scale, const float* shif
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     const dim3 grid(L.gx, L.gy), block(256);
     const void* skip = nullptr;
+    unsigned char* relu_mask = nullptr;
     BN_APPLY(false, 0);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -615,18 +635,20 @@ extern "C" int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* 
 }
 
 template <typename T, int VEC>
-static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
+static int bn_bwd_t(const void* dy, const void* x, const void* y_in, const unsigned char* relu_mask, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, long M, int C, mcn_act act,
                     void* ws, hipStream_t st) {
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
     const dim3 grid(L.gx, L.gy), block(256);
-    const int relu = act == MCN_ACT_SWISH ? 3 : (act != MCN_ACT_RELU ? 0 : (y ? 1 : 2));
+    const bool use_mask = act == MCN_ACT_RELU && relu_mask && VEC > 1;
+    const void* y = use_mask ? (const void*)relu_mask : y_in;
+    const int relu = act == MCN_ACT_SWISH ? 3 : (act != MCN_ACT_RELU ? 0 : (use_mask ? 4 : (y ? 1 : 2)));
 #define BN_BWD_REDUCE(RL)                                                                                                          \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, RL>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)x, \
                        (const T*)y, save_mean, save_invstd, gamma, beta, part, M, C, L.TX, L.TY, L.rpb)
-    if (relu == 0) BN_BWD_REDUCE(0); else if (relu == 1) BN_BWD_REDUCE(1); else if (relu == 2) BN_BWD_REDUCE(2); else BN_BWD_REDUCE(3);
+    if (relu == 0) BN_BWD_REDUCE(0); else if (relu == 1) BN_BWD_REDUCE(1); else if (relu == 2) BN_BWD_REDUCE(2); else if (relu == 3) BN_BWD_REDUCE(3); else BN_BWD_REDUCE(4);
 #undef BN_BWD_REDUCE
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
@@ -638,21 +660,22 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
     if (relu == 1) { if (dskip) BN_BWD_APPLY(1, true); else BN_BWD_APPLY(1, false); }
     else if (relu == 2) { if (dskip) BN_BWD_APPLY(2, true); else BN_BWD_APPLY(2, false); }
     else if (relu == 3) BN_BWD_APPLY(3, false);
+    else if (relu == 4) { if (dskip) BN_BWD_APPLY(4, true); else BN_BWD_APPLY(4, false); }
     else { if (dskip) BN_BWD_APPLY(0, true); else BN_BWD_APPLY(0, false); }
 #undef BN_BWD_APPLY
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
-extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
+extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask, const float* gamma, const float* beta, const float* save_mean,
                           const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, int64_t M,
                           int32_t C, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !dx || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd: workspace too small");
     if (act == MCN_ACT_SWISH && dskip) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: swish with a fused residual is not built");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
-                                            : bn_bwd_t<float, 1>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
-    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
-                                             : bn_bwd_t<bf16_t, 1>(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                            : bn_bwd_t<float, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                             : bn_bwd_t<bf16_t, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
 }

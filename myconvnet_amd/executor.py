@@ -391,18 +391,26 @@ class Lowering(object):
         if self.train and a['update']:
             st = a['saved']
             single = self.model.world_size == 1
+            # a BN with a fused residual cannot recompute its ReLU mask from x: keep [y > 0] as one byte per 16-byte chunk
+            # (the backward then reads 1/16 of the bytes of y, twice)
+            mask_ptr = 0
+            if skip is not None and a.get('act', 0) == _ffi.ACT_RELU and x.needs_grad:
+                nb = int(lib.mcn_bn_relu_mask_bytes(M, C, MCN_DT[x.dtype]))
+                if nb:
+                    a['relu_mask'] = torch.zeros(nb, dtype=torch.uint8, device=self.g.device)
+                    mask_ptr = a['relu_mask'].data_ptr()
             if 'fused_stats' in a:
                 part, gm = a['fused_stats']
                 rpp = ctypes.c_int32(0)
                 rows = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, ctypes.byref(rpp)))
                 self.fwd.add(lib.mcn_bn_fwd_train_fused, x.buf.data_ptr(), part.data_ptr(), rows, rpp.value,
                              self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
-                             y.buf.data_ptr(), st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
+                             y.buf.data_ptr(), mask_ptr, st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
                              a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
                              float(a['momentum']), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
                 return
             self.fwd.add(lib.mcn_bn_fwd_train, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
-                         y.buf.data_ptr(), st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
+                         y.buf.data_ptr(), mask_ptr, st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
                          a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
                          float(a['momentum']), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
         else:
@@ -433,11 +441,13 @@ class Lowering(object):
                 post = (skip.grad.data_ptr(), s.data_ptr(), skip.grad.numel(), MCN_DT[skip.dtype])
         g, b = a['gamma'], a['beta']
 
-        # ReLU without a fused residual: the mask is recomputed from x inside the kernel (y pointer = 0)
+        # ReLU without a fused residual: the mask is recomputed from x inside the kernel (y pointer = 0);
+        # with a fused residual: from the byte mask of the forward pass
         yptr = y.buf.data_ptr() if (skip is not None or not a.get('act', 0)) else 0
+        mptr = a['relu_mask'].data_ptr() if 'relu_mask' in a else 0
 
         def emit(dst):
-            self.bwd.add(lib.mcn_bn_bwd, y.grad.data_ptr(), x.buf.data_ptr(), yptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
+            self.bwd.add(lib.mcn_bn_bwd, y.grad.data_ptr(), x.buf.data_ptr(), yptr, mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
                          st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
                          b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, a.get('act', 0), MCN_DT[x.dtype],
                          self.ws_ptr, self.ws_bytes)

@@ -102,7 +102,7 @@ def conv_wgrad(x, dy, w_shape, stride, padding, dilation=1, dtype='float32', wit
     return (host(dw), host(db)) if with_bias else host(dw)
 
 
-def bn_fwd_train(x, gamma, beta, eps=1e-3, dtype='float32', skip=None, act=0, running=None, momentum=0.99):
+def bn_fwd_train(x, gamma, beta, eps=1e-3, dtype='float32', skip=None, act=0, running=None, momentum=0.99, want_mask=False):
     c = x.shape[-1]
     m = x.size // c
     xd = dev(x, dtype)
@@ -113,17 +113,21 @@ def bn_fwd_train(x, gamma, beta, eps=1e-3, dtype='float32', skip=None, act=0, ru
     rm = dev(running[0]) if running is not None else None
     rv = dev(running[1]) if running is not None else None
     ws = workspace(lib.mcn_bn_workspace_bytes(m, c))
+    mask = torch.full((max(int(lib.mcn_bn_relu_mask_bytes(m, c, MDT[dtype])), 1),), 0xAA, dtype=torch.uint8, device=DEV) if want_mask else None
     _ffi.check(lib.mcn_bn_fwd_train(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sd.data_ptr() if sd is not None else 0, y.data_ptr(),
-                                    sm.data_ptr(), si.data_ptr(), bm.data_ptr(), bv.data_ptr(), rm.data_ptr() if rm is not None else 0,
+                                    mask.data_ptr() if mask is not None else 0, sm.data_ptr(), si.data_ptr(), bm.data_ptr(), bv.data_ptr(), rm.data_ptr() if rm is not None else 0,
                                     rv.data_ptr() if rv is not None else 0, momentum, m, c, eps, act, MDT[dtype], ws.data_ptr(),
                                     ws.numel() * 4, stream()))
     out = dict(y=host(y), save_mean=host(sm), save_invstd=host(si), batch_mean=host(bm), batch_var=host(bv))
     if running is not None:
         out['running_mean'], out['running_var'] = host(rm), host(rv)
+    if mask is not None:
+        torch.cuda.synchronize()
+        out['relu_mask'] = mask.cpu().numpy()
     return out
 
 
-def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want_dskip=False, scale=1.0, beta=None):
+def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want_dskip=False, scale=1.0, beta=None, relu_mask=None):
     c = x.shape[-1]
     m = x.size // c
     dyd, xd = dev(dy, dtype), dev(x, dtype)
@@ -134,7 +138,8 @@ def bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dtype='float32', act=0, want
     dsk = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV) if want_dskip else None
     dg, db = torch.zeros(c, dtype=torch.float32, device=DEV), torch.zeros(c, dtype=torch.float32, device=DEV)
     ws = workspace(lib.mcn_bn_workspace_bytes(m, c))
-    _ffi.check(lib.mcn_bn_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr() if yd is not None else 0, gd.data_ptr(), bd.data_ptr() if bd is not None else 0, smd.data_ptr(), sid.data_ptr(),
+    mk = torch.as_tensor(relu_mask).to(DEV) if relu_mask is not None else None
+    _ffi.check(lib.mcn_bn_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr() if yd is not None else 0, mk.data_ptr() if mk is not None else 0, gd.data_ptr(), bd.data_ptr() if bd is not None else 0, smd.data_ptr(), sid.data_ptr(),
                               dx.data_ptr(), dsk.data_ptr() if dsk is not None else 0, dg.data_ptr(), db.data_ptr(), float(scale), m, c, act,
                               MDT[dtype], ws.data_ptr(), ws.numel() * 4, stream()))
     return host(dx), host(dg), host(db), (host(dsk) if dsk is not None else None)

@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu():
     assert lib.mcn_conv2d_kernel_name(_ffi.CONV_DGRAD, ctypes.byref(g2), _ffi.F32, buf, 96) == 4        # one launch per stride-parity class
     assert lib.mcn_conv2d_kernel_name(_ffi.CONV_WGRAD, ctypes.byref(g2), _ffi.F32, buf, 96) == 1 and buf.value.startswith(b'conv_gemm_tn<float')
     assert lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) >= 16 * 9 * 16 * 4
-    assert lib.mcn_bn_fwd_train(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.9, 10, 4, 1e-3, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
+    assert lib.mcn_bn_fwd_train(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.9, 10, 4, 1e-3, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
     assert lib.mcn_bn_workspace_bytes(1000, 64) > 0
     assert lib.mcn_relu_fwd(0, 0, 10, _ffi.F32, 0) == _ffi.E_BADARG
     assert lib.mcn_sgd_nesterov_fused(0, 0, 0, 0, 10, 0.1, 0.9, 0.0, 0.0, 0.99, 1.0, 0) == _ffi.E_BADARG

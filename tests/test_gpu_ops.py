@@ -175,6 +175,16 @@ def test_bn_fused_add_relu(dtype):
     check(gds, dmask, dtype, 'fused dskip', rel=1e-6 if dtype == 'float32' else 1e-6)
     check(gdg, dg, 'float32', 'fused dgamma', rel=1e-4)
     check(gdb, db, 'float32', 'fused dbeta', rel=1e-4)
+    # the byte mask written by the forward ([y > 0], one byte per 16-byte chunk) replaces y in the backward, bit for bit
+    outm = u.bn_fwd_train(x, g, b, 1e-3, dtype, skip=skip, act=1, want_mask=True)
+    np.testing.assert_array_equal(outm['y'], ydev)
+    vec = 4 if dtype == 'float32' else 8
+    bits = (ydev.reshape(-1, vec) > 0).astype(np.uint32)
+    ref_mask = (bits << np.arange(vec, dtype=np.uint32)).sum(-1).astype(np.uint8)
+    np.testing.assert_array_equal(outm['relu_mask'][:ref_mask.size], ref_mask)
+    mdx, mdg, mdb, mds = u.bn_bwd(dy, x, None, g, sm, si, dtype, act=1, want_dskip=True, relu_mask=outm['relu_mask'])
+    for a_, b_ in ((mdx, gdx), (mdg, gdg), (mdb, gdb), (mds, gds)):
+        np.testing.assert_array_equal(a_, b_)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -500,7 +510,7 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         sm, si, bm, bv = [torch.zeros(cout, dtype=torch.float32, device=u.DEV) for _ in range(4)]
         rm, rv = torch.zeros(cout, dtype=torch.float32, device=u.DEV), torch.ones(cout, dtype=torch.float32, device=u.DEV)
         bws = u.workspace(lib.mcn_bn_workspace_bytes(m, cout))
-        _ffi.check(lib.mcn_bn_fwd_train_fused(y.data_ptr(), part.data_ptr(), rows, rpp.value, gd.data_ptr(), bd.data_ptr(), 0, out.data_ptr(), sm.data_ptr(), si.data_ptr(),
+        _ffi.check(lib.mcn_bn_fwd_train_fused(y.data_ptr(), part.data_ptr(), rows, rpp.value, gd.data_ptr(), bd.data_ptr(), 0, out.data_ptr(), 0, sm.data_ptr(), si.data_ptr(),
                                               bm.data_ptr(), bv.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.99, m, cout, 1e-3, 1, u.MDT[dtype], bws.data_ptr(),
                                               bws.numel() * 4, u.stream()))
         check(u.host(out), ref['y'], dtype, 'fused bn y (tile {})'.format(tile), rel=1e-5 if dtype == 'float32' else 4e-3)
