@@ -134,7 +134,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     from myconvnet_amd._ffi import lib, check
     low = model._train_low
     sp = model.stream_ptr()
-    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
     mdt = _ffi.F32 if dtype == 'fp32' else _ffi.BF16
     buf = ctypes.create_string_buffer(128)
     table, rows = {}, {}
@@ -191,8 +191,8 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)
                 xe = gm.N * gm.H * gm.W * gm.Cin if (gm.KH > 1 or gm.SH == 1) else gm.N * oh * ow * gm.Cin
                 byt = es * (xe + gm.N * oh * ow * gm.Cout) + (4 if name == 'mcn_conv2d_wgrad' else es) * gm.KH * gm.KW * gm.Cin * gm.Cout
-                if name == 'mcn_conv2d_dgrad' and a[5]:
-                    byt += es * xe                                         # accumulate: dx is read as well as written
+                if (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
+                    byt += es * xe                                         # accumulate / fused residual fan-in: one more read of a dx-sized tensor
                 if layers:
                     r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
                     r[0] += 1

@@ -108,6 +108,16 @@ int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, v
  * mcn_conv2d_fwd_bnstats the last template argument of the printed name is `true` instead of `false`. */
 int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype, char* buf, size_t buflen);
 
+/* dgrad fused with the gradient fan-in of an identity shortcut (models/resnet_v1_5.py:66-70: x + skip, relu): the input
+ * of a residual block receives dgrad(conv_0) + [y_block > 0] * dy_block.  add_src = dy_block (same shape and dtype as dx),
+ * add_mask = the ReLU byte mask the block's last BN wrote (mcn_bn_fwd_train, relu_mask): the masked tensor is never
+ * materialised (one write + one read of a block-output-sized tensor less per identity block).  Stride-1 geometries only:
+ * mcn_conv2d_dgrad_addmasked_ok() != 0. */
+int32_t mcn_conv2d_dgrad_addmasked_ok(const mcn_conv_geom* geom, mcn_dtype dtype);
+int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w_hwio, const void* w_packed, void* dx, const void* add_src,
+                               const uint8_t* add_mask, const mcn_conv_geom* geom, mcn_dtype dtype, mcn_layout layout,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* replaces Conv2DBackpropFilter.  dw:[KH][KW][Cin][Cout] fp32 (overwritten; deterministic
  * split-K through workspace slabs).  dbias (optional, fp32 [Cout]) = column sums of dy
  * (BiasAddGrad). grad_scale multiplies both (loss un-scaling, optimizers.py:109-111). */

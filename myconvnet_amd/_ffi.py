@@ -43,6 +43,8 @@ SIGNATURES = {
     'mcn_conv2d_workspace_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
     'mcn_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_dgrad_addmasked_ok': (c_int32, [ctypes.POINTER(ConvGeom), c_int]),
+    'mcn_conv2d_dgrad_addmasked': (c_int, [c_void_p] * 6 + [ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_packed_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
     'mcn_conv2d_pack_table_bytes': (c_size_t, [ctypes.POINTER(PackJob), c_int32]),
     'mcn_conv2d_pack_table_build': (c_int, [ctypes.POINTER(PackJob), c_int32, c_int, c_void_p, c_size_t, ctypes.POINTER(c_int32)]),

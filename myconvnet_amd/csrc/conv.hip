@@ -403,7 +403,7 @@ static inline int pos_mod(int a, int m) { return ((a % m) + m) % m; }
 
 template <typename T>
 static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, void* dx, const Geo& g, int accumulate, mcn_dtype dt,
-                        void* ws, size_t ws_bytes, hipStream_t st) {
+                        void* ws, size_t ws_bytes, hipStream_t st, const void* add_src = nullptr, const unsigned char* add_mask = nullptr) {
     const long Min = (long)g.N * g.H * g.W;
     if (Min == 0) return MCN_OK;
     if (!mfma_dgrad_ok(g, dt)) {
@@ -466,7 +466,8 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         p.in = dy; p.wt = wsp; p.out = dx; p.bias = nullptr;
         p.M = g.N * OHs * OWs; p.OH = OHs; p.OW = OWs; p.IH = g.OH; p.IW = g.OW; p.Cs = g.Cout;
         p.cpt = Cp / ce; p.ntaps = c.nt; p.nchunks = c.nt * p.cpt; p.sy = 1; p.sx = 1; p.Nn = g.Cin;
-        p.OHf = g.H; p.OWf = g.W; p.ldo = g.Cin; p.osy = g.SH; p.osx = g.SW; p.oy0 = c.py; p.ox0 = c.px; p.accumulate = accumulate;
+        p.OHf = g.H; p.OWf = g.W; p.ldo = g.Cin; p.osy = g.SH; p.osx = g.SW; p.oy0 = c.py; p.ox0 = c.px; p.accumulate = add_src ? 2 : accumulate;
+        p.add_src = add_src; p.add_mask = add_mask;
         p.in_bytes = (unsigned)((size_t)g.N * g.OH * g.OW * g.Cout * sizeof(T));
         p.wt_bytes = (unsigned)((size_t)g.Cin * c.nt * Cp * sizeof(T));
         const bool linear = c.nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
@@ -489,6 +490,28 @@ extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, const void* w_pa
     if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
     if (dtype == MCN_BF16) return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: dtype %d unsupported", (int)dtype);
+}
+
+// dgrad that also adds the masked gradient of a residual block's output: dx = dgrad(dy) + add_src * [add_mask bit].
+// Stride-1 geometries on the MFMA path only (one parity class, every dx element written exactly once, dx dense).
+extern "C" int32_t mcn_conv2d_dgrad_addmasked_ok(const mcn_conv_geom* gg, mcn_dtype dtype) {
+    Geo g;
+    if (!gg || geo_from(gg, &g)) return 0;
+    if (dtype != MCN_F32 && dtype != MCN_BF16) return 0;
+    return (g.SH == 1 && g.SW == 1 && g.xcs == g.Cin && mfma_dgrad_ok(g, dtype) && g.Cin % ce_of(dtype) == 0) ? 1 : 0;
+}
+extern "C" int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w, const void* w_packed, void* dx, const void* add_src,
+                                          const uint8_t* add_mask, const mcn_conv_geom* gg, mcn_dtype dtype, mcn_layout layout, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_addmasked: only NHWC activations");
+    if (!dy || !w || !dx || !add_src || !add_mask) MCN_FAIL(MCN_E_BADARG, "conv2d_dgrad_addmasked: null pointer");
+    if (!mcn_conv2d_dgrad_addmasked_ok(gg, dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_addmasked: geometry not eligible (see mcn_conv2d_dgrad_addmasked_ok)");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
+    return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
 }
 
 // ---- wgrad -----------------------------------------------------------------------------------------------

@@ -42,7 +42,10 @@ struct GemmNTParams {
     int Nn;                 // GEMM N
     int OWf, OHf, ldo;      // full output grid (pixels) and channel stride
     int osy, osx, oy0, ox0; // scatter of the sub-grid into the full output grid
-    int accumulate;
+    int accumulate;         // 0: store; 1: out += old value; 2: out += add_src * [bit of add_mask] (the masked gradient of a
+                            // residual block's output, see mcn_conv2d_dgrad_addmasked)
+    const void* add_src;
+    const unsigned char* add_mask;
     unsigned in_bytes, wt_bytes;
     int tap[MCN_MAX_TAPS];  // (dy & 0xffff) | (dx << 16) per filter tap: 32-bit so that a wave-uniform tap index is a scalar load
                             // (byte tables are fetched with vector loads whose waits drain the LDS-DMA queue)
@@ -399,9 +402,14 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
                 if (sizeof(T) == 4) {
                     f32x4* dst = reinterpret_cast<f32x4*>(orow + n);
                     f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (p.accumulate) {
+                    if (p.accumulate == 1) {
                         const f32x4 old = *dst;
                         o += old;
+                    } else if (p.accumulate == 2) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
+                        const unsigned mb = p.add_mask[pix * (p.ldo >> 2) + (n >> 2)];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += (mb >> e) & 1u ? sv[e] : 0.f;
                     }
                     *dst = o;
                     if (do_stats) {
@@ -414,10 +422,15 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
                     }
                 } else {
                     bf16x4* dst = reinterpret_cast<bf16x4*>(orow + n);
-                    if (p.accumulate) {
+                    if (p.accumulate == 1) {
                         const bf16x4 old = *dst;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+                    } else if (p.accumulate == 2) {
+                        const bf16x4 sv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
+                        const unsigned mb = (unsigned)p.add_mask[pix * (p.ldo >> 3) + (n >> 3)] >> (n & 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? (float)sv[e] : 0.f;
                     }
                     bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                     *dst = o;

@@ -27,6 +27,8 @@ class Lowering(object):
         # BN statistics in the conv epilogue: on for bf16 (+2-3 % end to end); fp32's 1x1 convs are output-bound and the
         # epilogue costs them what the skipped statistics pass saves, so fp32 keeps the separate pass unless asked
         self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', graph.dtype == 'bfloat16'))
+        self.defer_dskip = bool(model._parameters.get('defer_dskip', True))
+        self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.scratch = {}
 
@@ -117,6 +119,7 @@ class Lowering(object):
                 f = getattr(self, 'bwd_' + n.op, None)
                 if f is not None:
                     f(n)
+            assert not self.lazy_grad, 'deferred residual gradients were not consumed: {}'.format(list(self.lazy_grad))
         return self
 
     def plan_packed_weights(self):
@@ -162,7 +165,7 @@ class Lowering(object):
         """Measure, don't guess: time every tile candidate of every conv launch of this lowering on the GPU (HIP events
         on the launch stream, data already in the buffers) and pin the fastest through mcn_conv_geom.tile.  The result
         of a conv does not depend on the tile except for the fp32 summation order of the split wgrad."""
-        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
         sp = torch.cuda.current_stream(self.g.device).cuda_stream
         self.prepack.run(sp)
         chosen = {}
@@ -302,7 +305,14 @@ class Lowering(object):
         late = self.overlap_wgrad
         if not late:
             emit_wgrad()
-        if x.needs_grad:
+        lazy = self.lazy_grad.pop(x.id, None)
+        if lazy is not None:
+            # identity shortcut: dx = dgrad + [y_block > 0] * dy_block in the epilogue (first and only writer of x.grad so far)
+            assert x.needs_grad and x.id not in self.written
+            self.written.add(x.id)
+            self.bwd.add(lib.mcn_conv2d_dgrad_addmasked, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), lazy[0], lazy[1],
+                         ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+        elif x.needs_grad:
             self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), dst,
                                                              ctypes.byref(gm), acc, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes))
         if late:
@@ -420,6 +430,27 @@ class Lowering(object):
             self.fwd.add(lib.mcn_bn_fwd_infer, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), mp, sp,
                          ptr(skip.buf) if skip else 0, y.buf.data_ptr(), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype])
 
+    def _defer_dskip(self, n, skip, y):
+        """Residual BN (y = relu(bn(x) + skip)) with a ReLU byte mask: instead of materialising dskip = [y > 0] * dy, let
+        the skip branch's only other gradient consumer apply it — the dgrad of the block's first conv (identity shortcut:
+        mcn_conv2d_dgrad_addmasked) or the projection shortcut's BN backward.  Returns True when deferred."""
+        a = n.attrs
+        if 'relu_mask' not in a or not self.defer_dskip or skip.id in self.written or skip.id in self.lazy_grad:
+            return False
+        lazy = (y.grad.data_ptr(), a['relu_mask'].data_ptr())
+        others = [c for c in skip.consumers if c is not n]
+        prod = skip.producer
+        if not others and prod is not None and prod.op == 'bn' and prod.attrs.get('update') and not prod.attrs.get('act', 0) \
+                and prod.attrs.get('skip') is None and self.train:
+            self.lazy_grad[skip.id] = lazy                                  # projection shortcut: conv_skip -> bn -> (add)
+            return True
+        if len(others) == 1 and others[0].op == 'conv' and others[0].inputs[0] is skip and others[0] in self.g.nodes \
+                and self.g.nodes.index(others[0]) < self.g.nodes.index(n) \
+                and lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(self.op_geom(others[0], _ffi.CONV_DGRAD)), self.dt):
+            self.lazy_grad[skip.id] = lazy                                  # identity shortcut: the block's conv_0 reads it
+            return True
+        return False
+
     def bwd_bn(self, n):
         x, y = n.inputs[0], n.outputs[0]
         a = n.attrs
@@ -431,7 +462,9 @@ class Lowering(object):
         st = a['saved']
         gs = 1.0 / self.loss_scale
         dskip_ptr, post = 0, None
-        if skip is not None and skip.needs_grad:
+        if skip is not None and skip.needs_grad and self._defer_dskip(n, skip, y):
+            pass                                         # the skip branch's consumer applies [y > 0] * dy itself (no dskip tensor)
+        elif skip is not None and skip.needs_grad:
             if skip.id not in self.written:
                 self.written.add(skip.id)
                 dskip_ptr = skip.grad.data_ptr()
@@ -445,11 +478,18 @@ class Lowering(object):
         # with a fused residual: from the byte mask of the forward pass
         yptr = y.buf.data_ptr() if (skip is not None or not a.get('act', 0)) else 0
         mptr = a['relu_mask'].data_ptr() if 'relu_mask' in a else 0
+        dy_ptr, act = y.grad.data_ptr(), a.get('act', 0)
+        lazy = self.lazy_grad.pop(y.id, None)
+        if lazy is not None:
+            # this BN produced the skip branch of a residual block: its output gradient is [y_block > 0] * dy_block, read
+            # straight from the block's gradient and byte mask (mathematically a ReLU in front of this BN's output)
+            assert y.id not in self.written and not act and skip is None
+            dy_ptr, mptr, yptr, act = lazy[0], lazy[1], 0, _ffi.ACT_RELU
 
         def emit(dst):
-            self.bwd.add(lib.mcn_bn_bwd, y.grad.data_ptr(), x.buf.data_ptr(), yptr, mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
+            self.bwd.add(lib.mcn_bn_bwd, dy_ptr, x.buf.data_ptr(), yptr, mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
                          st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
-                         b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, a.get('act', 0), MCN_DT[x.dtype],
+                         b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, act, MCN_DT[x.dtype],
                          self.ws_ptr, self.ws_bytes)
         self.contribute_via_scratch(x, emit)
         if post:

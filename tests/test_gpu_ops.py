@@ -552,3 +552,33 @@ def test_conv_tile_candidates_agree(case, dtype):
         np.testing.assert_array_equal(u.host(dx), dx0, err_msg='dgrad tile {}'.format(tile))
     if dtype == 'bfloat16' and cout > 64:
         assert any(', 8, false>' in nm for nm in names), names             # the 8-wave tile was exercised
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(4, 14, 14, 64, 32, 1), (3, 9, 11, 72, 136, 3), (2, 28, 28, 256, 64, 1)])
+def test_conv_dgrad_with_masked_residual_add(case, dtype):
+    """dx = dgrad(dy) + add_src * [add_mask bit]: the fan-in of an identity shortcut fused into conv_0's dgrad epilogue must
+    equal (bit for bit) the two-step path it replaces: dskip = masked dy_block written first, dgrad accumulated on top."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k = case
+    wgt = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    dy = RNG.standard_normal((n, h, w_, cout)).astype(np.float32)
+    dyb = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)            # gradient of the block output
+    yb = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)             # block output (pre-ReLU sign decides the mask)
+    vec = 4 if dtype == 'float32' else 8
+    bits = (yb.reshape(-1, vec) > 0).astype(np.uint32)
+    mask = (bits << np.arange(vec, dtype=np.uint32)).sum(-1).astype(np.uint8)
+    masked = np.where(yb > 0, q(dyb, dtype), 0.0)
+    ref = u.conv_dgrad(dy, wgt, (n, h, w_, cin), 1, 'SAME', 1, dtype, accumulate_into=masked.astype(np.float32))
+    g = u.geom((n, h, w_, cin), wgt.shape, 1, 'SAME')
+    assert lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(g), u.MDT[dtype]) == 1
+    dyd, wd, src, md = u.dev(dy, dtype), u.dev(wgt), u.dev(dyb, dtype), torch.as_tensor(mask).to(u.DEV)
+    dx = torch.full((n, h, w_, cin), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype]))
+    _ffi.check(lib.mcn_conv2d_dgrad_addmasked(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), src.data_ptr(), md.data_ptr(), ctypes.byref(g), u.MDT[dtype],
+                                              _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    np.testing.assert_array_equal(u.host(dx), ref)
+    g2 = u.geom((n, 2 * h, 2 * w_, cin), wgt.shape, 2, 'SAME')
+    assert lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(g2), u.MDT[dtype]) == 0      # strided: not eligible
