@@ -59,9 +59,13 @@ typedef struct {
     int32_t KH, KW, SH, SW, DH, DW;
     int32_t padT, padB, padL, padR;
     int32_t x_cs; /* channel stride of x (0 => Cin).  Channels >= Cin must be finite (they meet zero weights) */
-    int32_t tile; /* 0 = library heuristic; k > 0 = force tile candidate k-1 of this op (1..mcn_conv2d_tile_candidates);
-                     results are identical up to fp32 summation order — used by callers that time the candidates */
+    int32_t tile; /* low byte: 0 = library heuristic; k > 0 = force tile candidate k-1 of this op
+                     (1..mcn_conv2d_tile_candidates); results are identical up to fp32 summation order — used by callers that
+                     time the candidates.  | MCN_TILE_NOSPLIT: fwd / dgrad run every tile's whole K loop in one workgroup
+                     (default: the tiles of the last, partially filled round of workgroups are cut along K when the workspace
+                     has room for the partial sums — deterministic, again identical up to fp32 summation order) */
 } mcn_conv_geom;
+#define MCN_TILE_NOSPLIT 0x100
 
 typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_conv_op;
 
@@ -69,6 +73,9 @@ typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_co
 int mcn_conv2d_tile_candidates(mcn_conv_op op);
 /* bytes of workspace the given op needs for this geometry/dtype (0 is a valid answer) */
 size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
+/* K-slices per tile of the last, partially filled round of workgroups of the op's (first) GEMM launch: 1 = unsplit
+ * (always for MCN_CONV_WGRAD, whose split over pixels is mcn_conv2d_workspace_bytes' business) */
+int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
 
 /* replaces tf.nn.conv2d (reference convnet.py:1659) [+ tf.nn.bias_add, convnet.py:1694, when
  * bias != NULL].  w_packed (may be NULL): the operand produced by mcn_conv2d_pack_* from the same

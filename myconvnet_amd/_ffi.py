@@ -41,6 +41,7 @@ SIGNATURES = {
     'mcn_last_error': (c_char_p, []),
     'mcn_conv2d_tile_candidates': (c_int, [c_int]),
     'mcn_conv2d_workspace_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
+    'mcn_conv2d_kslices': (c_int32, [c_int, ctypes.POINTER(ConvGeom), c_int]),
     'mcn_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_dgrad_addmasked_ok': (c_int32, [ctypes.POINTER(ConvGeom), c_int]),

@@ -27,6 +27,10 @@ static bool force_naive() {
 }
 
 // ---- geometry helpers ----------------------------------------------------------------------------
+#define MCN_NUM_CU 256
+// worst case of the stream-K partials (sk_plan): tail tiles x slices <= resident workgroup slots, largest tile
+#define MCN_SK_MAX_BYTES ((size_t)MCN_NUM_CU * 256 * 128 * sizeof(float))
+
 struct Geo {
     int N, H, W, Cin, Cout, KH, KW, SH, SW, DH, DW, pT, pB, pL, pR, xcs, OH, OW, tile;
 };
@@ -81,6 +85,7 @@ static size_t dgrad_pack_bytes(const Geo& g, mcn_dtype dt) {
 // 8-25 % because the per-K-step pixel bookkeeping is amortised over fewer MFMAs)
 static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int forced, int* br, int* bn) {
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    forced &= 0xff;
     if (forced >= 1 && forced <= 4) { *br = cand[forced - 1][0]; *bn = cand[forced - 1][1]; return; }
     if (dt == MCN_F32 && linear) { *br = 64; *bn = 64; return; }
     *br = rows <= 64 ? 64 : 128;
@@ -146,8 +151,9 @@ extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom
     if (geo_from(gg, &g) != MCN_OK) return 0;
     if (dtype != MCN_F32 && dtype != MCN_BF16) return 0;
     switch (op) {
-        case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) : 0;
-        case MCN_CONV_DGRAD: return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) : 0;
+        /* packed weights (unless the caller keeps them) + room for the stream-K partials */
+        case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : 0;
+        case MCN_CONV_DGRAD: return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : 0;
         case MCN_CONV_WGRAD: return wgrad_ws_bytes(g, dtype);
     }
     return 0;
@@ -168,7 +174,6 @@ static void allow_lds(K kernel, int bytes) {
 // (conv fwd+dgrad 38.4 ms vs 41.5 ms per step with 128x128); bf16 is LDS-bandwidth sensitive and keeps the big tiles.
 // (A body/tail split — big tiles for whole rounds, small tiles for the remainder in a second launch — was measured
 // and lost 4 %: the kernel boundary costs more than the shorter tail saves.)
-#define MCN_NUM_CU 256
 struct NtTile { int bm, bn, nw; };
 // candidate 3 (256x128, 8 waves) is bf16 only: fp32 is MFMA-bound and prefers the smallest tile
 static const NtTile kNtCand[4] = {{128, 128, 4}, {128, 64, 4}, {64, 64, 4}, {256, 128, 8}};
@@ -180,6 +185,7 @@ static inline double nt_tile_work(int c, size_t es) {
 }
 template <typename T>
 static int pick_nt_tile(int M, int Nn, int hint = 0) {
+    hint &= 0xff;
     if (hint >= 1 && hint <= 3) return hint - 1;
     if (hint == 4 && sizeof(T) == 2 && Nn > 64) return 3;      // 256x128 / 8 waves: bf16 only; otherwise the heuristic below
     static const int forced = [] { const char* e = getenv("MCN_NT_TILE"); return e ? atoi(e) : -1; }();
@@ -196,56 +202,72 @@ static int pick_nt_tile(int M, int Nn, int hint = 0) {
     return best;
 }
 
+// Stream-K tail (fp32).  The fp32 conv_gemm_nt is MFMA bound, so a CU's time is the tile work it receives: W tiles over S
+// resident workgroup slots cost ceil(W / S) rounds and the last round of the late ResNet stages is mostly empty (14x14 / 7x7
+// layers at B = 256: 2.45 / 1.2 rounds).  The whole rounds run as ordinary tiles; the tiles of the last, partial round are
+// cut along K into `slices` workgroups each so that they fill the slots once, in the SAME launch (no kernel boundary in
+// front of the tail); the slices park their fp32 accumulators in the workspace and a short second launch sums them in a
+// fixed order (deterministic, unlike an atomic tail) and runs the epilogue.  Measured per layer on MI355X (B = 256):
+// 7x7 3x3 512 -> 512 fwd 540 -> 479 us, 7x7 1x1 fwd / dgrad -8 %, 14x14 3x3 -3 %; layers with many rounds or a short K loop
+// lose (stem: 39 rounds, 7 K-steps, +4 %), hence the two guards below.  bf16 is off: its layers are LDS / L2 / HBM bound,
+// the tiles of a thin last round run faster than those of a full one, and the split cost 4 % of the step (per-layer +10-38 %).
+struct SkPlan { int body, tail, slices; size_t bytes; };
+// resident workgroups per CU: 160 KB of LDS / (2 buffers x (BM + BN) x 128 B); registers allow at least as many
+static const int kNtSlotsPerCU[MCN_NT_CANDS] = {2, 3, 5, 1};
+#define MCN_SK_MAX_ROUNDS 8          /* more whole rounds than this: the tail is too small a share of the layer to pay */
+#define MCN_SK_MIN_KSTEPS 4          /* K-steps per slice (below: prologue + partial traffic outweigh the MFMAs) */
+static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
+    // MCN_NT_STREAMK: 0 = off, 1 = default (fp32 only), 2 = every dtype (experiments)
+    static const int enabled = [] { const char* e = getenv("MCN_NT_STREAMK"); return e ? atoi(e) : 1; }();
+    SkPlan sp = {(int)W, 0, 1, 0};
+    if (!enabled || (es != 4 && enabled < 2)) return sp;
+    const long S = (long)kNtSlotsPerCU[tile] * MCN_NUM_CU;
+    const long tail = W % S;
+    if (W < S || W / S >= MCN_SK_MAX_ROUNDS || tail == 0 || 4 * tail >= 3 * S) return sp;   // last round already >= 75 % full
+    int slices = (int)(S / tail);
+    if (slices > nk / MCN_SK_MIN_KSTEPS) slices = nk / MCN_SK_MIN_KSTEPS;
+    if (slices > 32) slices = 32;
+    if (slices < 2) return sp;
+    sp.body = (int)(W - tail);
+    sp.tail = (int)tail;
+    sp.slices = slices;
+    sp.bytes = (size_t)tail * slices * kNtCand[tile].bm * kNtCand[tile].bn * sizeof(float);
+    return sp;
+}
+
 template <typename T>
-static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, bool taps, hipStream_t st) {
-    const NtTile* cand = kNtCand;
-    const NtTile t = cand[tile];
-    p.m_begin = m_begin;
-    p.m_end = m_end;
-    const int ntm = (m_end - m_begin + t.bm - 1) / t.bm, ntn = (p.Nn + t.bn - 1) / t.bn;
-    if (ntm <= 0 || ntn <= 0) return MCN_OK;
-    const int lds = 2 * (t.bm + t.bn) * 128;
-    const dim3 grid(ntm * ntn), block(t.nw * 64);
-    const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
-#define MCN_LAUNCH_NT_S(BMV, BNV, MODEV, STV)                                        \
+static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mode, bool reduce, hipStream_t st) {
+    const NtTile t = kNtCand[tile];
+    const int lds = reduce ? 0 : 2 * (t.bm + t.bn) * 128;
+    const dim3 grid(nblocks), block(t.nw * 64);
+#define MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, STV)                                    \
     do {                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, 4, STV>, 2 * (BMV + BNV) * 128), true); \
+        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, NWV, STV>, 2 * (BMV + BNV) * 128), true); \
         (void)once;                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, 4, STV>), grid, block, lds, st, p); \
+        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, NWV, STV>), grid, block, lds, st, p); \
     } while (0)
-#define MCN_LAUNCH_NT(BMV, BNV, MODEV)                                               \
+#define MCN_LAUNCH_NT(BMV, BNV, NWV, MODEV)                                           \
     do {                                                                             \
-        if (p.stats) MCN_LAUNCH_NT_S(BMV, BNV, MODEV, true); else MCN_LAUNCH_NT_S(BMV, BNV, MODEV, false); \
+        if (p.stats) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, true); else MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, false); \
     } while (0)
-#define MCN_LAUNCH_NT_MODE(BMV, BNV)                                    \
-    do {                                                                \
-        if (mode == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NT_LINEAR);      \
-        else if (mode == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NT_UNIFORM); \
-        else MCN_LAUNCH_NT(BMV, BNV, NT_GENERIC);                       \
+#define MCN_LAUNCH_NT_MODE(BMV, BNV, NWV)                                                 \
+    do {                                                                                  \
+        if (reduce) {                                                                     \
+            if (p.stats) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, true>), grid, block, 0, st, p);  \
+            else hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, false>), grid, block, 0, st, p);         \
+        } else if (mode == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_LINEAR);            \
+        else if (mode == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_UNIFORM);            \
+        else MCN_LAUNCH_NT(BMV, BNV, NWV, NT_GENERIC);                                    \
     } while (0)
     if (t.bm == 256) {
         if constexpr (sizeof(T) == 2) {
-#define MCN_LAUNCH_NT8_S(MODEV, STV)                                                                 \
-    do {                                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, 256, 128, MODEV, 8, STV>, 2 * (256 + 128) * 128), true); \
-        (void)once;                                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, 256, 128, MODEV, 8, STV>), grid, block, lds, st, p);  \
-    } while (0)
-#define MCN_LAUNCH_NT8(MODEV)                                                                        \
-    do {                                                                                             \
-        if (p.stats) MCN_LAUNCH_NT8_S(MODEV, true); else MCN_LAUNCH_NT8_S(MODEV, false);             \
-    } while (0)
-            if (mode == NT_LINEAR) MCN_LAUNCH_NT8(NT_LINEAR);
-            else if (mode == NT_UNIFORM) MCN_LAUNCH_NT8(NT_UNIFORM);
-            else MCN_LAUNCH_NT8(NT_GENERIC);
-#undef MCN_LAUNCH_NT8
-#undef MCN_LAUNCH_NT8_S
+            MCN_LAUNCH_NT_MODE(256, 128, 8);
         } else {
             MCN_FAIL(MCN_E_UNSUPPORTED, "conv: 256x128 tile is bf16 only");
         }
-    } else if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_NT_MODE(128, 128);
-    else if (t.bm == 128) MCN_LAUNCH_NT_MODE(128, 64);
-    else MCN_LAUNCH_NT_MODE(64, 64);
+    } else if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_NT_MODE(128, 128, 4);
+    else if (t.bm == 128) MCN_LAUNCH_NT_MODE(128, 64, 4);
+    else MCN_LAUNCH_NT_MODE(64, 64, 4);
 #undef MCN_LAUNCH_NT_MODE
 #undef MCN_LAUNCH_NT
 #undef MCN_LAUNCH_NT_S
@@ -253,10 +275,25 @@ static int launch_nt_range(GemmNTParams p, int tile, int m_begin, int m_end, boo
     return MCN_OK;
 }
 
+// sk_ws: scratch for the stream-K partials (may be null / too small: the conv then runs unsplit)
 template <typename T>
-static int launch_nt(const GemmNTParams& p, bool taps, int tile_hint, hipStream_t st) {
+static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
     if (p.M <= 0 || p.Nn <= 0) return MCN_OK;
-    return launch_nt_range<T>(p, pick_nt_tile<T>(p.M, p.Nn, tile_hint), 0, p.M, taps, st);
+    const int tile = pick_nt_tile<T>(p.M, p.Nn, tile_hint & 0xff);
+    const NtTile t = kNtCand[tile];
+    p.m_begin = 0;
+    p.m_end = p.M;
+    const long W = (long)((p.M + t.bm - 1) / t.bm) * ((p.Nn + t.bn - 1) / t.bn);
+    const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
+    const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
+    if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
+    p.sk_mode = 1;
+    p.sk_body = sp.body;
+    p.sk_slices = sp.slices;
+    p.partial = (float*)sk_ws;
+    int rc = launch_nt_tiles<T>(p, tile, sp.body + sp.tail * sp.slices, mode, false, st);
+    if (rc) return rc;
+    return launch_nt_tiles<T>(p, tile, sp.tail, mode, true, st);
 }
 
 template <typename T>
@@ -352,7 +389,9 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
     p.in_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(T));
     p.wt_bytes = (unsigned)((size_t)g.Cout * ntaps * Cp * sizeof(T));
     const bool linear = ntaps == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
-    return launch_nt<T>(p, !linear, g.tile, st);
+    // workspace: [packed weights unless the caller keeps them | stream-K partials]
+    const size_t used = w_packed ? 0 : need;
+    return launch_nt<T>(p, !linear, g.tile, st, ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0);
 }
 
 extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const mcn_conv_geom* gg,
@@ -471,7 +510,8 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         p.in_bytes = (unsigned)((size_t)g.N * g.OH * g.OW * g.Cout * sizeof(T));
         p.wt_bytes = (unsigned)((size_t)g.Cin * c.nt * Cp * sizeof(T));
         const bool linear = c.nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
-        rc = launch_nt<T>(p, !linear, g.tile, st);
+        const size_t used = w_packed ? 0 : need;
+        rc = launch_nt<T>(p, !linear, g.tile, st, ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0);
         if (rc) return rc;
         wsp += align_up((size_t)g.Cin * c.nt * Cp * sizeof(T), 256);
     }
@@ -724,6 +764,35 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
     snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s>", tn, br, bn, conv_is_linear(g) ? "true" : "false");
     return 1;
+}
+
+// K-slices per tail tile of the stream-K split the (first) GEMM launch of this conv uses when the workspace has room
+// (1 = every tile runs its whole K loop; tests and the bench use it to know which layers are split)
+extern "C" int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
+    Geo g;
+    if (!gg || geo_from(gg, &g) || (dtype != MCN_F32 && dtype != MCN_BF16) || (g.tile & MCN_TILE_NOSPLIT)) return 1;
+    const int ce = ce_of(dtype);
+    long M;
+    int Nn, nchunks;
+    if (op == MCN_CONV_FWD) {
+        if (!mfma_path_ok(g, dtype)) return 1;
+        M = (long)g.N * g.OH * g.OW; Nn = g.Cout; nchunks = g.KH * g.KW * (round_up(g.Cin, ce) / ce);
+    } else if (op == MCN_CONV_DGRAD) {
+        if (!mfma_dgrad_ok(g, dtype)) return 1;
+        int nt0 = 0;                                      // taps of the first non-empty stride-parity class
+        for (int py = 0; py < g.SH && py < g.H && !nt0; ++py)
+            for (int px = 0; px < g.SW && px < g.W && !nt0; ++px)
+                for (int r = 0; r < g.KH; ++r)
+                    for (int s = 0; s < g.KW; ++s)
+                        if (!pos_mod(py + g.pT - r * g.DH, g.SH) && !pos_mod(px + g.pL - s * g.DW, g.SW)) nt0++;
+        M = (long)g.N * ((g.H + g.SH - 1) / g.SH) * ((g.W + g.SW - 1) / g.SW); Nn = g.Cin; nchunks = nt0 * (round_up(g.Cout, ce) / ce);
+    } else {
+        return 1;
+    }
+    if (M <= 0) return 1;
+    const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, Nn, g.tile) : pick_nt_tile<bf16_t>((int)M, Nn, g.tile);
+    const long W = (long)((M + kNtCand[t].bm - 1) / kNtCand[t].bm) * ((Nn + kNtCand[t].bn - 1) / kNtCand[t].bn);
+    return sk_plan(t, W, (nchunks + 7) >> 3, mcn_dtype_size(dtype)).slices;
 }
 
 // ---- fully connected = 1x1 convolution on a [B][1][1][In] tensor ------------------------------------------

@@ -42,6 +42,10 @@ struct GemmNTParams {
     int Nn;                 // GEMM N
     int OWf, OHf, ldo;      // full output grid (pixels) and channel stride
     int osy, osx, oy0, ox0; // scatter of the sub-grid into the full output grid
+    // stream-K tail (see launch_nt): sk_mode 1 = workgroups >= sk_body compute one of sk_slices K-slices of a tail tile each
+    // and write their accumulators to `partial`; conv_nt_sk_reduce sums them and runs the epilogue
+    float* partial;
+    int sk_mode, sk_slices, sk_body;
     int accumulate;         // 0: store; 1: out += old value; 2: out += add_src * [bit of add_mask] (the masked gradient of a
                             // residual block's output, see mcn_conv2d_dgrad_addmasked)
     const void* add_src;
@@ -168,6 +172,159 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// Epilogue of conv_gemm_nt / conv_nt_sk_reduce: bias, store (or accumulate), optional BN-statistics partials.
+template <typename T, int BM, int BN, bool TAPS, int NW, bool STATS>
+__device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
+                                            typename MmaNT<T>::Acc (&acc)[BN / 2 / MmaNT<T>::MT][BM / (NW / 2) / MmaNT<T>::MT],
+                                            const int m0, const int n0, const int lane, const int wm, const int wn) {
+    typedef MmaNT<T> MM;
+    constexpr int WROWS = NW / 2;
+    constexpr int WTM = BM / WROWS, WTN = BN / 2;
+    constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
+    const int fr = MM::frag_row(lane);
+    // ---- epilogue: lane holds 4 consecutive output channels of one pixel per register group ----
+    // p.stats: the batch-norm statistics of the layer's output ride here — per-lane sums of the STORED (rounded) values
+    // and of their squares over the wave's pixel tiles, folded across the 16 / 32 lanes that share a channel group and
+    // written as one partial row per (M tile, wave row): the separate read of y by the BN statistics pass disappears.
+    T* out = reinterpret_cast<T*>(p.out);
+    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
+    float s1[STATS ? TN : 1][NG][4], s2[STATS ? TN : 1][NG][4], piv[STATS ? TN : 1][NG][4];
+    constexpr bool do_stats = STATS;             // compile-time: the plain instantiation carries no statistics code
+    if (do_stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                const int n = n0 + wn * WTN + j * MM::MT + nl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[j][0][g * 4 + e];
+                    if (p.bias && n < p.Nn) v += p.bias[n + e];
+                    v = to_f32(from_f32<T>(v));                                  // the value as stored
+                    piv[j][g][e] = __shfl(v, lane & ~(MM::MT - 1));            // pixel row 0 of the wave row
+                    s1[j][g][e] = s2[j][g][e] = 0.f;
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * MM::MT + fr;
+        if (m >= p.m_end) continue;
+        long pix;
+        if (TAPS || p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf) {
+            const int hw = p.OH * p.OW;
+            const int img = m / hw, rem = m - img * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            pix = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
+        } else {
+            pix = m;
+        }
+        T* orow = out + pix * p.ldo;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
+                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                const int n = n0 + wn * WTN + j * MM::MT + nl;
+                if (n >= p.Nn) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e];
+                if (p.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                if (sizeof(T) == 4) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(orow + n);
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate == 1) {
+                        const f32x4 old = *dst;
+                        o += old;
+                    } else if (p.accumulate == 2) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
+                        const unsigned mb = p.add_mask[pix * (p.ldo >> 2) + (n >> 2)];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += (mb >> e) & 1u ? sv[e] : 0.f;
+                    }
+                    *dst = o;
+                    if (do_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = o[e] - piv[j][g][e];
+                            s1[j][g][e] += d;
+                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
+                        }
+                    }
+                } else {
+                    bf16x4* dst = reinterpret_cast<bf16x4*>(orow + n);
+                    if (p.accumulate == 1) {
+                        const bf16x4 old = *dst;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+                    } else if (p.accumulate == 2) {
+                        const bf16x4 sv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
+                        const unsigned mb = (unsigned)p.add_mask[pix * (p.ldo >> 3) + (n >> 3)] >> (n & 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? (float)sv[e] : 0.f;
+                    }
+                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *dst = o;
+                    if (do_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = (float)o[e] - piv[j][g][e];
+                            s1[j][g][e] += d;
+                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (do_stats) {
+        // Fold over the MT lanes that hold different pixel rows of the same channels with a halving butterfly: at each
+        // step a lane keeps half of its values and receives the partner's copies of that half (V/2 + V/4 + ... shuffles
+        // instead of V per step); when one value is left the remaining steps are plain all-reduce steps.  At the end lane
+        // (lane & (MT-1)) owns the total of flat value index `base` (j, g, e order).
+        constexpr int V = TN * NG * 4;
+        float a[V], b[V];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[(j * NG + g) * 4 + e] = s1[j][g][e];
+                    b[(j * NG + g) * 4 + e] = s2[j][g][e];
+                }
+        int base = 0;
+        bool writer = true;
+        LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
+        const int prow = (m0 / BM) * WROWS + wm;                     // absolute: body and stream-K tail launches share the buffer
+        const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
+        const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+        const int n = n0 + wn * WTN + j * MM::MT + nl + e;
+        if (writer && n < p.Nn) {
+            p.stats[((long)prow * 3 + 0) * p.Nn + n] = a[0];
+            p.stats[((long)prow * 3 + 1) * p.Nn + n] = b[0];
+        }
+        if (fr == 0) {                                                          // the pivots: 4 consecutive channels per (j, g)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    const int nl2 = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * gg + 4 * (lane >> 5));
+                    const int n2 = n0 + wn * WTN + jj * MM::MT + nl2;
+                    if (n2 < p.Nn)
+                        *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 3 + 2) * p.Nn + n2) = f32x4{piv[jj][gg][0], piv[jj][gg][1], piv[jj][gg][2], piv[jj][gg][3]};
+                }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int MODE, int NW = 4, bool STATS = false>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
@@ -187,7 +344,11 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.Nn + BN - 1) / BN;
     const int ntm = (p.m_end - p.m_begin + BM - 1) / BM;
-    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    // Stream-K tail (sk_mode 1): the first sk_body workgroups compute whole tiles, the rest compute one K-slice each of the
+    // tiles behind them (sk_rel = tile * sk_slices + slice) and park their accumulators for conv_nt_sk_reduce.
+    const int sk_rel = (int)blockIdx.x - p.sk_body;
+    const bool sk_slice = p.sk_mode == 1 && sk_rel >= 0;
+    const int L = sk_slice ? p.sk_body + sk_rel / p.sk_slices : xcd_remap(blockIdx.x, p.sk_mode == 1 ? p.sk_body : ntm * ntn);
     const int m0 = p.m_begin + (L / ntn) * BM, n0 = (L % ntn) * BN;
 
     if (MODE == NT_GENERIC) {
@@ -314,10 +475,19 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
             for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[set][j], xa[set][i]);
     };
 
-    const int nk = (p.nchunks + 7) >> 3;
+    const int nk_all = (p.nchunks + 7) >> 3;
+    // K-step range of this workgroup: everything, or one slice of a stream-K tail tile (sk_mode 1), or nothing (sk_mode 2)
+    int ks0 = 0, nk = nk_all;
+    if (sk_slice) {
+        const int per = (nk_all + p.sk_slices - 1) / p.sk_slices, sl = sk_rel % p.sk_slices;
+        ks0 = sl * per;
+        nk = min(nk_all, ks0 + per);
+    }
+    constexpr int ACCSZ = (int)(sizeof(typename MM::Acc) / 4);
+    constexpr int NREG = TN * TM * ACCSZ;                       // accumulator registers per thread
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
-    {
+    if (ks0 < nk) {
         // LDS-DMA pipeline: buffer `cur` holds step ks (its DMA was issued one step ago), the DMA of step ks+1 into the
         // other buffer is issued right after the barrier that retires that buffer's readers and flies under this
         // step's MFMAs.  vmcnt(0) + barrier per step: own DMA landed, then everybody's.
@@ -338,153 +508,56 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
             if (ks + 1 < nk) issue(ks + 1, nxt);
             compute(smem + decltype(cur)::value * TILE_BYTES);
         };
-        issue(0, S0{});
-        for (int ks = 0; ks < nk; ks += 2) {
+        issue(ks0, S0{});
+        for (int ks = ks0; ks < nk; ks += 2) {
             gstep(ks, S0{}, S1{});
             if (ks + 1 < nk) gstep(ks + 1, S1{}, S0{});
         }
     }
-    // ---- epilogue: lane holds 4 consecutive output channels of one pixel per register group ----
-    // p.stats: the batch-norm statistics of the layer's output ride here — per-lane sums of the STORED (rounded) values
-    // and of their squares over the wave's pixel tiles, folded across the 16 / 32 lanes that share a channel group and
-    // written as one partial row per (M tile, wave row): the separate read of y by the BN statistics pass disappears.
-    T* out = reinterpret_cast<T*>(p.out);
-    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
-    float s1[STATS ? TN : 1][NG][4], s2[STATS ? TN : 1][NG][4], piv[STATS ? TN : 1][NG][4];
-    constexpr bool do_stats = STATS;             // compile-time: the plain instantiation carries no statistics code
-    if (do_stats) {
+    if (sk_slice) {
+        // stream-K slice: park the accumulators ([tile][slice][register][thread]: coalesced) — the reduce pass runs the epilogue
+        float* dst = p.partial + ((size_t)sk_rel * NREG) * NT + tid;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-                const int n = n0 + wn * WTN + j * MM::MT + nl;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[j][0][g * 4 + e];
-                    if (p.bias && n < p.Nn) v += p.bias[n + e];
-                    v = to_f32(from_f32<T>(v));                                  // the value as stored
-                    piv[j][g][e] = __shfl(v, lane & ~(MM::MT - 1));            // pixel row 0 of the wave row
-                    s1[j][g][e] = s2[j][g][e] = 0.f;
-                }
-            }
+                for (int e = 0; e < ACCSZ; ++e) dst[(size_t)((j * TM + i) * ACCSZ + e) * NT] = acc[j][i][e];
+        return;
     }
+    nt_epilogue<T, BM, BN, TAPS, NW, STATS>(p, acc, m0, n0, lane, wm, wn);
+}
+
+// Stream-K reduce: tail tile blockIdx.x = the sum of its K-slices in a fixed order (deterministic), then the ordinary epilogue.
+template <typename T, int BM, int BN, int NW, bool STATS>
+__global__ __launch_bounds__(NW * 64) void conv_nt_sk_reduce(const GemmNTParams p) {
+    typedef MmaNT<T> MM;
+    constexpr int NT = NW * 64;
+    constexpr int WROWS = NW / 2;
+    constexpr int TM = BM / WROWS / MM::MT, TN = BN / 2 / MM::MT;
+    constexpr int ACCSZ = (int)(sizeof(typename MM::Acc) / 4);
+    constexpr int NREG = TN * TM * ACCSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int L = p.sk_body + (int)blockIdx.x;
+    const int m0 = p.m_begin + (L / ntn) * BM, n0 = (L % ntn) * BN;
+    typename MM::Acc acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * MM::MT + fr;
-        if (m >= p.m_end) continue;
-        long pix;
-        if (TAPS || p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf) {
-            const int hw = p.OH * p.OW;
-            const int img = m / hw, rem = m - img * hw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            pix = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
-        } else {
-            pix = m;
-        }
-        T* orow = out + pix * p.ldo;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
-                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-                const int n = n0 + wn * WTN + j * MM::MT + nl;
-                if (n >= p.Nn) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e];
-                if (p.bias) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                }
-                if (sizeof(T) == 4) {
-                    f32x4* dst = reinterpret_cast<f32x4*>(orow + n);
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (p.accumulate == 1) {
-                        const f32x4 old = *dst;
-                        o += old;
-                    } else if (p.accumulate == 2) {
-                        const f32x4 sv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
-                        const unsigned mb = p.add_mask[pix * (p.ldo >> 2) + (n >> 2)];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += (mb >> e) & 1u ? sv[e] : 0.f;
-                    }
-                    *dst = o;
-                    if (do_stats) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = o[e] - piv[j][g][e];
-                            s1[j][g][e] += d;
-                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
-                        }
-                    }
-                } else {
-                    bf16x4* dst = reinterpret_cast<bf16x4*>(orow + n);
-                    if (p.accumulate == 1) {
-                        const bf16x4 old = *dst;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
-                    } else if (p.accumulate == 2) {
-                        const bf16x4 sv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
-                        const unsigned mb = (unsigned)p.add_mask[pix * (p.ldo >> 3) + (n >> 3)] >> (n & 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? (float)sv[e] : 0.f;
-                    }
-                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                    *dst = o;
-                    if (do_stats) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = (float)o[e] - piv[j][g][e];
-                            s1[j][g][e] += d;
-                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (do_stats) {
-        // Fold over the MT lanes that hold different pixel rows of the same channels with a halving butterfly: at each
-        // step a lane keeps half of its values and receives the partner's copies of that half (V/2 + V/4 + ... shuffles
-        // instead of V per step); when one value is left the remaining steps are plain all-reduce steps.  At the end lane
-        // (lane & (MT-1)) owns the total of flat value index `base` (j, g, e order).
-        constexpr int V = TN * NG * 4;
-        float a[V], b[V];
+            for (int e = 0; e < ACCSZ; ++e) acc[j][i][e] = 0.f;
+    for (int sl = 0; sl < p.sk_slices; ++sl) {
+        const float* src = p.partial + (((size_t)blockIdx.x * p.sk_slices + sl) * NREG) * NT + tid;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[(j * NG + g) * 4 + e] = s1[j][g][e];
-                    b[(j * NG + g) * 4 + e] = s2[j][g][e];
-                }
-        int base = 0;
-        bool writer = true;
-        LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
-        const int prow = ((m0 - p.m_begin) / BM) * WROWS + wm;
-        const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
-        const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-        const int n = n0 + wn * WTN + j * MM::MT + nl + e;
-        if (writer && n < p.Nn) {
-            p.stats[((long)prow * 3 + 0) * p.Nn + n] = a[0];
-            p.stats[((long)prow * 3 + 1) * p.Nn + n] = b[0];
-        }
-        if (fr == 0) {                                                          // the pivots: 4 consecutive channels per (j, g)
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-                for (int gg = 0; gg < NG; ++gg) {
-                    const int nl2 = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * gg + 4 * (lane >> 5));
-                    const int n2 = n0 + wn * WTN + jj * MM::MT + nl2;
-                    if (n2 < p.Nn)
-                        *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 3 + 2) * p.Nn + n2) = f32x4{piv[jj][gg][0], piv[jj][gg][1], piv[jj][gg][2], piv[jj][gg][3]};
-                }
-        }
+                for (int e = 0; e < ACCSZ; ++e) acc[j][i][e] += src[(size_t)((j * TM + i) * ACCSZ + e) * NT];
     }
+    nt_epilogue<T, BM, BN, true, NW, STATS>(p, acc, m0, n0, lane, wave >> 1, wave & 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -555,6 +555,102 @@ def test_conv_tile_candidates_agree(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(8, 28, 28, 256, 1024, 1, 1),      # fwd splits (64x64 / 128x64 tiles)
+                                  (64, 14, 14, 1024, 256, 1, 1),     # dgrad splits
+                                  (96, 7, 7, 512, 2048, 1, 1),       # 128x128 (and the 8-wave bf16 tile) split
+                                  (128, 14, 14, 256, 256, 3, 1),     # 3x3: taps inside the K-slices
+                                  (200, 15, 15, 512, 512, 3, 2)])    # stride 2: dgrad parity classes, ragged M tail
+def test_conv_streamk_tail(case, dtype):
+    """fp32 layers whose tile count leaves the last round of workgroups mostly empty run that round K-sliced (partials in the
+    workspace, fixed-order reduce): same convolution as the unsplit path up to fp32 summation order, deterministic, also
+    with the BN-statistics epilogue and the masked residual add; too small a workspace falls back to the unsplit path."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k, s = case
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    w = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    g0 = u.geom(x.shape, w.shape, s, 'SAME')
+    oh, ow = -(-h // s), -(-w_ // s)
+    dy = RNG.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    xd, wd, dyd = u.dev(x, dtype), u.dev(w), u.dev(dy, dtype)
+    tol = dict(rel=2e-6, mx=2e-5) if dtype == 'float32' else dict(rel=1.5e-3, mx=1e-2)   # bf16: rare one-ulp rounding flips
+    nsplit = 0
+
+    def run_fwd(g, ws, stats=None):
+        y = torch.full((n, oh, ow, cout), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        if stats is None:
+            _ffi.check(lib.mcn_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+        else:
+            _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), stats.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
+                                                  ws.data_ptr(), ws.numel() * 4, u.stream()))
+        return u.host(y)
+
+    def run_dgrad(g, ws):
+        dx = torch.full(x.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        _ffi.check(lib.mcn_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+        return u.host(dx)
+
+    for tile in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_FWD) + 1):
+        g = u.geom(x.shape, w.shape, s, 'SAME')
+        g.tile = tile
+        gn = u.geom(x.shape, w.shape, s, 'SAME')
+        gn.tile = tile | 0x100                                                   # MCN_TILE_NOSPLIT
+        assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gn), u.MDT[dtype]) == 1
+        ws = u.workspace(max(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]),
+                             lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype])))
+        if lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]) > 1:
+            nsplit += 1
+            y_ref = run_fwd(gn, ws)
+            y = run_fwd(g, ws)
+            check(y, y_ref, dtype, 'fwd split vs unsplit (tile {})'.format(tile), **tol)
+            assert not np.array_equal(y, y_ref) or dtype == 'bfloat16'            # the split path really ran
+            np.testing.assert_array_equal(run_fwd(g, ws), y)                       # deterministic
+            # workspace without room for the partials: the unsplit path, bit for bit
+            pack = lib.mcn_conv2d_packed_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype])
+            small = u.workspace(pack + 1024)
+            np.testing.assert_array_equal(run_fwd(g, small), y_ref)
+            # BN statistics ride the reduce pass: partial rows are indexed by absolute M tile
+            rpp = ctypes.c_int32(0)
+            rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT[dtype], ctypes.byref(rpp))
+            part = torch.full((rows, 3, cout), float('nan'), dtype=torch.float32, device=u.DEV)
+            ys = run_fwd(g, ws, part)
+            np.testing.assert_array_equal(ys, y)
+            pr = u.host(part).astype(np.float64)
+            yq = y.astype(np.float64).reshape(-1, cout)
+            assert np.isfinite(pr[:-(-yq.shape[0] // rpp.value)]).all()
+            for kk in (0, rows // 2, -(-yq.shape[0] // rpp.value) - 1):
+                blk = yq[kk * rpp.value:(kk + 1) * rpp.value]
+                np.testing.assert_array_equal(pr[kk, 2], blk[0])
+                np.testing.assert_allclose(pr[kk, 0], (blk - blk[0]).sum(0), rtol=1e-4, atol=1e-5 * np.abs(blk - blk[0]).sum(0).max() + 1e-30)
+        if lib.mcn_conv2d_kslices(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype]) > 1:
+            nsplit += 1
+            dx_ref = run_dgrad(gn, ws)
+            dx = run_dgrad(g, ws)
+            check(dx, dx_ref, dtype, 'dgrad split vs unsplit (tile {})'.format(tile), **tol)
+            np.testing.assert_array_equal(run_dgrad(g, ws), dx)
+            if lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(g), u.MDT[dtype]):
+                src = RNG.standard_normal(x.shape).astype(np.float32)
+                mb = lib.mcn_bn_relu_mask_bytes(n * h * w_, cin, u.MDT[dtype])
+                mask = torch.from_numpy(RNG.integers(0, 256, mb, dtype=np.uint8)).to(u.DEV)
+                sd = u.dev(src, dtype)
+                outs = []
+                for gg in (gn, g):
+                    dxa = torch.full(x.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+                    _ffi.check(lib.mcn_conv2d_dgrad_addmasked(dyd.data_ptr(), wd.data_ptr(), 0, dxa.data_ptr(), sd.data_ptr(), mask.data_ptr(), ctypes.byref(gg),
+                                                              u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+                    outs.append(u.host(dxa))
+                check(outs[1], outs[0], dtype, 'dgrad+masked add split vs unsplit (tile {})'.format(tile), **tol)
+    # fp32 only: the bf16 layers are not MFMA bound and the split cost 4 % of the ResNet-50 step (conv.hip, sk_plan)
+    assert nsplit > 0 if dtype == 'float32' else nsplit == 0, 'stream-K tail: {} split launches'.format(nsplit)
+    # the unsplit path against the oracle at this size (1x1 cases: the oracle is one matmul)
+    if k == 1:
+        g = u.geom(x.shape, w.shape, s, 'SAME')
+        ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]))
+        check(run_fwd(g, ws), O.conv2d_fwd(q(x, dtype), q(w, dtype), s, 'SAME'), dtype, 'fwd (default plan) vs oracle')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(4, 14, 14, 64, 32, 1), (3, 9, 11, 72, 136, 3), (2, 28, 28, 256, 64, 1)])
 def test_conv_dgrad_with_masked_residual_add(case, dtype):
     """dx = dgrad(dy) + add_src * [add_mask bit]: the fan-in of an identity shortcut fused into conv_0's dgrad epilogue must
