@@ -187,6 +187,14 @@ int mcn_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
                float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* gradient of fused_batch_norm(is_training=False) used INSIDE a training graph: the frozen-statistics BN of
+ * update_batch_norm=False / blocks_to_train (convnet.py:1781-1789, 1915-1923).  mean / var: the running statistics the
+ * forward pass (mcn_bn_fwd_infer) normalised with.  dx = dz*gamma*invstd, dgamma = sum(dz*xhat), dbeta = sum(dz), with
+ * dz = dy masked / scaled by the activation as in mcn_bn_bwd (ReLU: from the stored y, required; swish: recomputed). */
+int mcn_bn_bwd_frozen(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean,
+                      const float* var, float eps, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale,
+                      int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- depthwise convolution ---------------------------------------------------
  * replaces tf.nn.depthwise_conv2d (convnet.py:1645) with channel multiplier 1 (every EfficientNet call site,
  * models/efficientnet.py:145) and its two gradients.  geom: Cin == Cout == C (multiple of the 16-byte chunk);
@@ -312,6 +320,11 @@ int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* works
  * over n contiguous fp32 elements. */
 int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum,
                            float l2, float wd, float ema_decay, float grad_scale, void* stream);
+/* the reference's other decoupled decays, applied after apply_gradients (optimizers.py:163-170; the default
+ * w -= wd*w rides in mcn_sgd_nesterov_fused): mode 0: w -= wd*w; 1 (l1_weight_decay): w -= wd*sign(w);
+ * 2 (huber_decay_delta): w -= wd*w/sqrt(1 + (w/delta)^2).  n contiguous fp32 elements. */
+typedef enum { MCN_DECAY_L2 = 0, MCN_DECAY_L1 = 1, MCN_DECAY_HUBER = 2 } mcn_decay_mode;
+int mcn_decoupled_decay(float* w, int64_t n, float wd, int32_t mode, float delta, void* stream);
 /* replaces tf.clip_by_global_norm(grads, gradient_threshold) (optimizers.py:112-113) over the flat gradient buffer:
  * first g[i] += l2 * w[i] for i < n_l2 (the gradient of the L2 term, which the reference's loss contains and which
  * otherwise rides in mcn_sgd_nesterov_fused — pass l2 = 0 there when clipping), then g *= t / max(||g||_2, t).

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libmcn_hip.so')
 F32, BF16, F16 = 0, 1, 2
 NHWC, NCHW = 0, 1
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
+DECAY_L2, DECAY_L1, DECAY_HUBER = 0, 1, 2
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 OK, E_BADARG, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -60,6 +61,7 @@ SIGNATURES = {
     'mcn_bn_fwd_train_fused': (c_int, [c_void_p, c_void_p, c_int32, c_int32] + [c_void_p] * 11 + [c_float, c_int64, c_int32, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_bn_fwd_infer': (c_int, [c_void_p] * 7 + [c_int64, c_int32, c_float, c_int, c_int, c_void_p]),
     'mcn_bn_bwd': (c_int, [c_void_p] * 12 + [c_float, c_int64, c_int32, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_bn_bwd_frozen': (c_int, [c_void_p] * 7 + [c_float] + [c_void_p] * 4 + [c_float, c_int64, c_int32, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_channel_affine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     'mcn_dwconv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_void_p]),
     'mcn_dwconv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int32, c_int, c_void_p]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     'mcn_fc_bwd': (c_int, [c_void_p] * 6 + [c_float, c_int32, c_int32, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_softmax_xent_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_float, c_float, c_void_p]),
     'mcn_l2_loss': (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mcn_decoupled_decay': (c_int, [c_void_p, c_int64, c_float, c_int32, c_float, c_void_p]),
     'mcn_sgd_nesterov_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 6 + [c_void_p]),
     'mcn_softmax_xent_rows_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     'mcn_resize_bilinear_fwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),

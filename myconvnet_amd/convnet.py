@@ -288,8 +288,8 @@ class ConvNet(object):
         """reference convnet.py:528-597."""
         if kwargs.get('l1_reg', 0.0) > 0.0 or kwargs.get('focal_loss_factor', 0.0) > 0.0 or kwargs.get('sigmoid_focal_loss_factor', 0.0) > 0.0:
             raise NotImplementedError('l1 / focal losses are outside the built path')
-        if kwargs.get('bias_norm_decay', False):
-            raise NotImplementedError('bias_norm_decay is outside the built path')
+        # bias_norm_decay (convnet.py:536-537, optimizers.py:150-151): biases, gammas and betas join the regularised set
+        self.bias_norm_decay = bool(kwargs.get('bias_norm_decay', False))
         g = self.graph
         shape = tuple(self.logits.shape)                    # [B, C] (classification) or [B, H, W, C] (SegNet: per-pixel loss)
         seg = len(shape) == 4
@@ -323,6 +323,8 @@ class ConvNet(object):
         self.store = FlatStore(ordered, dev, with_grad=True)
         nw = [v for v in ordered if v.kind == 'weight']
         self.n_l2_elems = (nw[-1].offset + (nw[-1].size + 3) // 4 * 4) if nw else 0
+        if getattr(self, 'bias_norm_decay', False):
+            self.n_l2_elems = self.store.size            # L2 term and decoupled decay cover every trainable variable
         self.stats = FlatStore([v for v in self._var_order if v.kind in ('mu', 'sigma')], dev, with_grad=False)
         # per-step batch statistics in the same order as `stats` (for the cross-rank chain, convnet.py:1899-1909)
         self.batch_stats = torch.zeros(max(self.stats.size, 4), dtype=torch.float32, device=dev)

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, long M, int C,
                                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                             float grad_scale, float* __restrict__ coef) {
+                                                                             float grad_scale, float* __restrict__ coef, int frozen) {
     __shared__ double sh[FIN_CH * FIN_LANES * 2];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const int lane = threadIdx.x / FIN_CH;
@@ -320,8 +320,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_bwd_finalize_kernel(con
     if (dbeta) dbeta[c] = (float)a * grad_scale;
     if (dgamma) dgamma[c] = (float)b * grad_scale;
     coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
-    coef[C + c] = (float)(a / (double)M);
-    coef[2 * C + c] = (float)(b / (double)M);
+    // frozen statistics (is_training=False): mean / variance are constants, the two correction terms of dx vanish
+    coef[C + c] = frozen ? 0.f : (float)(a / (double)M);
+    coef[2 * C + c] = frozen ? 0.f : (float)(b / (double)M);
 }
 
 template <typename T, int VEC, int RELU, bool DSKIP>
@@ -377,7 +378,7 @@ static size_t bn_parts_bytes(long M, int C) {
 }
 extern "C" size_t mcn_bn_workspace_bytes(int64_t M, int32_t C) {
     if (M < 0 || C <= 0) return 0;
-    return bn_parts_bytes(M, C) + align_up((size_t)3 * C * sizeof(float), 256);
+    return bn_parts_bytes(M, C) + align_up((size_t)4 * C * sizeof(float), 256);   // partials + coef[3][C] + invstd[C] (frozen backward)
 }
 
 template <typename T, int VEC>
@@ -637,7 +638,7 @@ extern "C" int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* 
 template <typename T, int VEC>
 static int bn_bwd_t(const void* dy, const void* x, const void* y_in, const unsigned char* relu_mask, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, long M, int C, mcn_act act,
-                    void* ws, hipStream_t st) {
+                    void* ws, hipStream_t st, bool frozen = false) {
     const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
@@ -652,7 +653,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y_in, const unsig
 #undef BN_BWD_REDUCE
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
-                       dbeta, grad_scale, coef);
+                       dbeta, grad_scale, coef, frozen ? 1 : 0);
     MCN_CHECK_LAUNCH();
 #define BN_BWD_APPLY(RL, DS)                                                                                                    \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, RL, DS>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, \
@@ -678,4 +679,27 @@ extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const ui
     if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
                                              : bn_bwd_t<bf16_t, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
+}
+
+// ---- backward of the frozen-statistics BN (fused_batch_norm(is_training=False) inside a training graph) ----------------
+__global__ void bn_invstd_kernel(const float* __restrict__ var, float eps, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = 1.f / sqrtf(var[c] + eps);
+}
+extern "C" int mcn_bn_bwd_frozen(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean, const float* var,
+                                 float eps, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, int64_t M, int32_t C, mcn_act act,
+                                 mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !dx || !mean || !var || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd_frozen: bad argument");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd_frozen: workspace too small");
+    if (act == MCN_ACT_RELU && !y) MCN_FAIL(MCN_E_BADARG, "bn_bwd_frozen: the ReLU mask is taken from the stored output y");
+    if (act == MCN_ACT_SWISH && dskip) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_frozen: swish with a fused residual is not built");
+    hipStream_t st = (hipStream_t)stream;
+    float* invstd = (float*)((char*)ws + bn_parts_bytes(M, C)) + 3 * (size_t)C;
+    hipLaunchKernelGGL(bn_invstd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, var, eps, invstd, C);
+    MCN_CHECK_LAUNCH();
+    if (dtype == MCN_F32) return C % 4 == 0 ? bn_bwd_t<float, 4>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true)
+                                            : bn_bwd_t<float, 1>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true);
+    if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true)
+                                             : bn_bwd_t<bf16_t, 1>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_frozen: dtype %d unsupported", (int)dtype);
 }

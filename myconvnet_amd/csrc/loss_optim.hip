@@ -345,6 +345,33 @@ extern "C" int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, fl
     return MCN_OK;
 }
 
+// ---- decoupled weight decay variants (optimizers.py:163-170) --------------------------------------------------------
+// MODE 0: w -= wd*w ; 1: w -= wd*sign(w) ; 2 (pseudo-Huber): w -= wd*w / sqrt(1 + (w/delta)^2)
+template <int MODE>
+__global__ __launch_bounds__(256) void decoupled_decay_kernel(float* __restrict__ w, long n, float wd, float delta) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = w[i];
+        float d;
+        if (MODE == 0) d = v;
+        else if (MODE == 1) d = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+        else { const float r = v / delta; d = v / sqrtf(1.f + r * r); }
+        w[i] = v - wd * d;
+    }
+}
+extern "C" int mcn_decoupled_decay(float* w, int64_t n, float wd, int32_t mode, float delta, void* stream) {
+    if (!w || n < 0 || mode < 0 || mode > 2 || (mode == 2 && !(delta > 0.f))) MCN_FAIL(MCN_E_BADARG, "decoupled_decay: bad argument (mode %d, delta %g)", (int)mode, (double)delta);
+    if (n == 0 || wd == 0.f) return MCN_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL((decoupled_decay_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta);
+    else if (mode == 1) hipLaunchKernelGGL((decoupled_decay_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta);
+    else hipLaunchKernelGGL((decoupled_decay_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
 __global__ void ema_kernel(float* __restrict__ s, const float* __restrict__ v, long n, float d) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s[i] = d * s[i] + (1.f - d) * v[i];
 }

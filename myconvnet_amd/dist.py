@@ -112,11 +112,12 @@ class DataParallel(object):
                 for name in label[1]:
                     ready[name] = idx
         st = model.store
-        variables = [(v.name, v.offset, (v.size + 3) // 4 * 4) for v in st.variables]
+        # frozen variables (blocks_to_train) have no gradient: they stay out of the exchange
+        variables = [(v.name, v.offset, (v.size + 3) // 4 * 4) for v in st.variables if v.trainable]
         missing = [v[0] for v in variables if v[0] not in ready]
         assert not missing, 'no backward completion point for {}'.format(missing[:3])
         self.reducer = GradientReducer(st.grad, variables, ready, bucket_mb, side_stream=model._train_low.bwd.side_stream)
-        assert self.reducer.covered_elements() == st.size
+        assert self.reducer.covered_elements() == sum(v[2] for v in variables)
         self.gathered_stats = torch.zeros((self.world, model.batch_stats.numel()), dtype=torch.float32, device=model.device)
         self._loss_tmp = torch.zeros(1, dtype=torch.float32, device=model.device)
         # identical initial state on every rank

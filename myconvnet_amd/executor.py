@@ -119,7 +119,8 @@ class Lowering(object):
         if self.train:
             for n in reversed(self.g.nodes):
                 f = getattr(self, 'bwd_' + n.op, None)
-                if f is not None:
+                # (no gradient reaches a node all of whose variables upstream are frozen: blocks_to_train)
+                if f is not None and any(t.needs_grad for t in n.outputs):
                     f(n)
             assert not self.lazy_grad, 'deferred residual gradients were not consumed: {}'.format(list(self.lazy_grad))
         return self
@@ -456,8 +457,7 @@ class Lowering(object):
     def bwd_bn(self, n):
         x, y = n.inputs[0], n.outputs[0]
         a = n.attrs
-        if not a['update']:
-            raise NotImplementedError('backward through a frozen batch norm (update_batch_norm=False) is not built yet')
+        frozen = not a['update']                         # statistics are constants (convnet.py:1915-1923): affine gradient
         C = x.shape[-1]
         M = x.numel // C
         skip = a.get('skip')
@@ -488,7 +488,16 @@ class Lowering(object):
             assert y.id not in self.written and not act and skip is None
             dy_ptr, mptr, yptr, act = lazy[0], lazy[1], 0, _ffi.ACT_RELU
 
+        def emit_frozen(dst):
+            mu, sg = a['mu'], a['sigma']
+            self.bwd.add(lib.mcn_bn_bwd_frozen, dy_ptr, x.buf.data_ptr(), y.buf.data_ptr(), self.vptr(g), self.vptr(b), mu.data.data_ptr(),
+                         sg.data.data_ptr(), float(a['eps']), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
+                         b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, act, MCN_DT[x.dtype],
+                         self.ws_ptr, self.ws_bytes)
+
         def emit(dst):
+            if frozen:
+                return emit_frozen(dst)
             self.bwd.add(lib.mcn_bn_bwd, dy_ptr, x.buf.data_ptr(), yptr, mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
                          st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
                          b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, act, MCN_DT[x.dtype],

@@ -300,7 +300,9 @@ class Graph(object):
             for n in self.nodes:
                 if n.op in ('input', 'labels'):
                     continue
-                if n.attrs.get('has_params') or any(t.needs_grad for t in n.inputs):
+                # (frozen variables, blocks_to_train, do not start a gradient path)
+                trains = n.attrs.get('has_params') and any(getattr(n.attrs.get(k), 'trainable', False) for k in ('w', 'b', 'gamma', 'beta'))
+                if trains or any(t.needs_grad for t in n.inputs):
                     for t in n.outputs:
                         if t.dtype in TORCH_DT and n.op not in ('softmax', 'loss'):
                             t.needs_grad = True

@@ -12,6 +12,7 @@ import time
 import numpy as np
 import torch
 
+from . import _ffi
 from ._ffi import lib
 from .graph import Program
 
@@ -67,26 +68,53 @@ class Optimizer(object):
             m.compile(loss_scale=self.loss_scaling_factor)
         self.weight_decay = kwargs.get('base_weight_decay', 0.0) * self.batch_size / 256
         self.weight_decay_scheduling = kwargs.get('weight_decay_scheduling', True)
-        if kwargs.get('l1_weight_decay', False) or kwargs.get('huber_decay_delta', None) is not None:
-            raise NotImplementedError('l1 / huber weight decay are outside the built path')
-        if any(not v.trainable for v in m.store.variables):
-            raise NotImplementedError('blocks_to_train (frozen variables) is not built yet')
+        # decay variant (optimizers.py:163-170): pseudo-Huber wins over L1 when both are given
+        self.huber_decay_delta = kwargs.get('huber_decay_delta', None)
+        if self.huber_decay_delta is not None:
+            self.decay_mode = _ffi.DECAY_HUBER
+        else:
+            self.decay_mode = _ffi.DECAY_L1 if kwargs.get('l1_weight_decay', False) else _ffi.DECAY_L2
         self.momentum = optimizer['momentum']
         self.l2_reg = float(m._parameters.get('l2_reg', 1e-4))
         self.use_ema = bool(kwargs.get('update_ema', True))
         st = m.store
         nw, n = m.n_l2_elems, st.size
+        frozen = any(not v.trainable for v in st.variables)
+        if frozen and self.gradient_threshold is not None:
+            raise NotImplementedError('gradient clipping together with blocks_to_train (frozen variables) is not built')
+        # update_vars = tf.trainable_variables() (optimizers.py:53): maximal contiguous runs of trainable / frozen variables of
+        # the flat store, cut at the end of the regularised range.  A frozen run only moves its EMA shadow (ema.apply runs
+        # for every variable, convnet.py:1400-1404).
+        runs = []                                                            # (start, end, trainable)
+        for v in st.variables:
+            s0, e0 = v.offset, v.offset + (v.size + 3) // 4 * 4
+            for s1, e1 in ((s0, min(e0, nw)), (max(s0, nw), e0)):
+                if s1 >= e1:
+                    continue
+                if runs and runs[-1][1] == s1 and runs[-1][2] == v.trainable and not (s1 == nw and nw > 0):
+                    runs[-1][1] = e1
+                else:
+                    runs.append([s1, e1, v.trainable])
         P = Program()
         ema_w = st.ema.data_ptr() if self.use_ema else 0
-        # args: w, g, accum, ema, n, lr, momentum, l2, wd, ema_decay, grad_scale
-        if nw > 0:
-            P.add(lib.mcn_sgd_nesterov_fused, st.data.data_ptr(), st.grad.data_ptr(), st.accum.data_ptr(), ema_w, nw, 0.0, self.momentum,
-                  self.l2_reg, 0.0, 0.0, 1.0)
-        if n > nw:
-            off = nw * 4
+        self._sgd_calls, self._decay_calls, self._ema_calls = [], [], []
+        for s1, e1, trainable in runs:
+            off = s1 * 4
+            if not trainable:
+                if ema_w:
+                    P.add(lib.mcn_ema_update, ema_w + off, st.data.data_ptr() + off, e1 - s1, 0.0)
+                    self._ema_calls.append(P.calls[-1][1])
+                continue
+            # args: w, g, accum, ema, n, lr, momentum, l2, wd, ema_decay, grad_scale
+            reg = s1 < nw
             P.add(lib.mcn_sgd_nesterov_fused, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
-                  (ema_w + off) if ema_w else 0, n - nw, 0.0, self.momentum, 0.0, 0.0, 0.0, 1.0)
-        self._sgd_calls = [args for _, args in P.calls]
+                  (ema_w + off) if ema_w else 0, e1 - s1, 0.0, self.momentum, self.l2_reg if reg else 0.0, 0.0, 0.0, 1.0)
+            self._sgd_calls.append((P.calls[-1][1], reg))
+            # L1 / pseudo-Huber decay of the decayed range (weights, or everything with bias_norm_decay): a pass of its own
+            # after the update, as in the reference; the plain w -= wd*w stays fused in the update kernel
+            if reg and self.decay_mode != _ffi.DECAY_L2 and self.weight_decay > 0.0:
+                P.add(lib.mcn_decoupled_decay, st.data.data_ptr() + off, e1 - s1, 0.0, self.decay_mode, float(self.huber_decay_delta or 0.0))
+                self._decay_calls.append(P.calls[-1][1])
         # per-tower clipping by global norm (optimizers.py:112-113): folds the L2 gradient into g, then scales
         self._clip = Program()
         if self.gradient_threshold is not None:
@@ -115,13 +143,17 @@ class Optimizer(object):
         d = min(m.moving_average_decay, (1.0 + m.global_step) / (10.0 + m.global_step))     # tf EMA num_updates rule
         wd = self.weight_decay * (self.curr_multiplier if self.weight_decay_scheduling else 1.0)
         gscale = 1.0 / m.world_size                                                          # tower mean, optimizers.py:138
-        for i, args in enumerate(self._sgd_calls):
+        for args, reg in self._sgd_calls:
             args[5] = lr
             args[9] = d
             args[10] = gscale
-            args[8] = wd if (i == 0 and m.n_l2_elems > 0) else 0.0
+            args[8] = wd if (reg and not self._decay_calls) else 0.0
             if self.gradient_threshold is not None:
                 args[7] = 0.0                            # the L2 gradient was folded into g by mcn_clip_by_global_norm
+        for args in self._decay_calls:
+            args[2] = wd
+        for args in self._ema_calls:
+            args[3] = d
         if len(self._pre):
             self._pre.calls[0][1][3] = d
         return lr

@@ -36,8 +36,19 @@ class V(object):
             self.g = self.q(self.g)
 
 
+def trainable_name(name, blocks_to_train):
+    """convnet.py:1384-1389: a variable trains iff its block (the `block_<id>` prefix of its name; the logits live in
+    block None) is in blocks_to_train, or blocks_to_train is None."""
+    if blocks_to_train is None:
+        return True
+    tok = name.split('/')[0]
+    assert tok.startswith('block_'), name
+    blk = None if tok == 'block_None' else int(tok[len('block_'):])
+    return blk in blocks_to_train
+
+
 class Tape(object):
-    def __init__(self, params, train=True, bn_stats=None, eps=1e-3, quant=None):
+    def __init__(self, params, train=True, bn_stats=None, eps=1e-3, quant=None, blocks_to_train=None, update_batch_norm=None):
         """quant: optional rounding function emulating low-precision STORAGE of activations / activation gradients and
         the per-use cast of the weights (reference half_precision structure, convnet.py:63,1421-1422,1878-1879: fp32
         master weights, BN statistics and all accumulation in fp32).  Used to compare the bf16 device path like with like."""
@@ -45,7 +56,9 @@ class Tape(object):
         self.params = params          # name -> ndarray
         self.pv = {}                  # name -> V (created on first use)
         self.train = train
-        self.bn_stats = bn_stats      # name -> ndarray (mu / sigma), used when train=False
+        self.bn_stats = bn_stats      # name -> ndarray (mu / sigma), used when train=False (or by a frozen BN)
+        self.blocks_to_train = blocks_to_train        # None = all; list of block ids (None = the logits block)
+        self.update_batch_norm = update_batch_norm    # True / False, or None = follow blocks_to_train (convnet.py:1781-1789)
         self.eps = eps
         self.bw = []                  # backward closures
         self.batch_stats = {}         # bn scope -> (batch_mean, batch_var_unbiased)
@@ -80,9 +93,27 @@ class Tape(object):
             return y2
         return y
 
+    def bn_updates(self, scope):
+        if isinstance(self.update_batch_norm, bool):
+            return self.update_batch_norm
+        return trainable_name(scope, self.blocks_to_train)
+
     def bn(self, x, scope):
         gamma = self.p(scope + '/gamma')
         beta = self.p(scope + '/beta')
+        if self.train and not self.bn_updates(scope):
+            # frozen statistics (convnet.py:1915-1923): fused_batch_norm(is_training=False) on the running mean / variance
+            # also while training; its gradient is the plain affine one
+            mu, sigma = self.bn_stats[scope + '/mu'], self.bn_stats[scope + '/sigma']
+            y = V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant)
+
+            def bwf():
+                dx, dg, db = ops.bn_bwd_frozen(y.g, x.a, gamma.a, mu, sigma, self.eps)
+                x.acc(dx)
+                gamma.acc(dg)
+                beta.acc(db)
+            self.bw.append(bwf)
+            return y
         if self.train:
             ya, bm, bv, sm, si = ops.bn_fwd_train(x.a, gamma.a, beta.a, self.eps)
             self.batch_stats[scope] = (bm, bv)
@@ -608,6 +639,12 @@ DEFAULT_HP = dict(image_mean=0.5, scale_factor=2.0, l2_reg=1e-4, momentum=0.9, b
                   base_weight_decay=0.0, loss_scaling_factor=1.0, eps=1e-3)
 
 
+def _regularised(name, hp):
+    """Member of the set the L2 term and the decoupled decay run over: collection 'weight_variables', plus biases and BN
+    gamma / beta with bias_norm_decay (convnet.py:535-537, optimizers.py:149-151)."""
+    return name.endswith('/weights') or bool(hp.get('bias_norm_decay', False))
+
+
 class TrainState(object):
     def __init__(self, params, stats):
         self.params = {k: v.copy() for k, v in params.items()}
@@ -622,7 +659,8 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
     hp = dict(DEFAULT_HP, **(hp or {}))
     params = state.ema if use_ema else state.params
     stats = state.ema_stats if use_ema else state.stats
-    t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'], quant=quant)
+    t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'], quant=quant, blocks_to_train=hp.get('blocks_to_train'),
+             update_batch_norm=hp.get('update_batch_norm'))
     dt = next(iter(params.values())).dtype
     x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']), quant)
     x.g = False
@@ -641,7 +679,7 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
     else:
         onehot = ops.one_hot_labels(y_float, spec.num_classes, dtype=dt)
         pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
-    weights = [v for k, v in params.items() if k.endswith('/weights')]
+    weights = [v for k, v in params.items() if _regularised(k, hp)]
     loss = float(sm_loss) + ops.l2_reg_loss(weights, hp['l2_reg'])
     out.g = dlogits if quant is None else quant(dlogits)
     return t, out, pred, loss, onehot
@@ -660,9 +698,10 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
     for (xr, yf) in towers:
         t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant)
         g = t.backward()
+        g = {k: v for k, v in g.items() if trainable_name(k, hp.get('blocks_to_train'))}      # update_vars = tf.trainable_variables(), optimizers.py:53,106
         if hp.get('gradient_threshold') is not None:
             # the reference differentiates the full loss (CE + L2) and clips per tower (optimizers.py:106-113)
-            g = {k: (v + hp['l2_reg'] * state.params[k] if k.endswith('/weights') else v) for k, v in g.items()}
+            g = {k: (v + hp['l2_reg'] * state.params[k] if _regularised(k, hp) else v) for k, v in g.items()}
             g, _ = ops.clip_by_global_norm(g, hp['gradient_threshold'])
         grads_sum = g if grads_sum is None else {k: grads_sum[k] + g[k] for k in g}
         losses.append(loss)
@@ -673,20 +712,23 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
     d = ops.ema_decay(hp['moving_average_decay'], state.step)
     m = hp['batch_norm_decay']
     # EMA of running stats (pre-assign value), then the chained running-stat update
+    for key in state.stats:                                    # ema.apply covers every statistic, also of frozen BNs (convnet.py:1812,1826)
+        state.ema_stats[key] = d * state.ema_stats[key] + (1.0 - d) * state.stats[key]
     for scope in bstats[0]:
-        for nm, idx in (('/mu', 0), ('/sigma', 1)):
-            key = scope + nm
-            state.ema_stats[key] = d * state.ema_stats[key] + (1.0 - d) * state.stats[key]
         mu, sg = ops.bn_running_update_chain(state.stats[scope + '/mu'], state.stats[scope + '/sigma'],
                                              [b[scope][0] for b in bstats], [b[scope][1] for b in bstats], m)
         state.stats[scope + '/mu'] = mu.astype(state.stats[scope + '/mu'].dtype)
         state.stats[scope + '/sigma'] = sg.astype(state.stats[scope + '/sigma'].dtype)
-    wd = hp['base_weight_decay'] * btot / 256.0 * lr_mult
+    wd = hp['base_weight_decay'] * btot / 256.0 * (lr_mult if hp.get('weight_decay_scheduling', True) else 1.0)   # optimizers.py:91,155-156
     for k in state.params:
-        is_w = k.endswith('/weights')
+        if k not in grads:                                     # frozen: only its EMA shadow moves (towards the constant value)
+            state.ema[k] = (d * state.ema[k] + (1.0 - d) * state.params[k]).astype(state.params[k].dtype)
+            continue
+        is_w = _regularised(k, hp)
         w, a, e = ops.sgd_nesterov_step(state.params[k], grads[k], state.accum[k], lr, hp['momentum'],
                                         l2=hp['l2_reg'] if (is_w and hp.get('gradient_threshold') is None) else 0.0, ema=state.ema[k], ema_d=d,
-                                        wd=wd if is_w else 0.0)
+                                        wd=wd if is_w else 0.0, l1_decay=bool(hp.get('l1_weight_decay', False)),
+                                        huber_delta=hp.get('huber_decay_delta'))
         dt = state.params[k].dtype
         state.params[k], state.accum[k], state.ema[k] = w.astype(dt), a.astype(dt), e.astype(dt)
     state.step += 1

@@ -275,6 +275,17 @@ def bn_fwd_infer(x, gamma, beta, mean, var, eps=1e-3):
     return ((x - mean) * (invstd * gamma) + beta).astype(x.dtype)
 
 
+def bn_bwd_frozen(dy, x, gamma, mean, var, eps=1e-3):
+    """Gradient of fused_batch_norm(is_training=False) (the frozen-statistics BN of update_batch_norm=False /
+    blocks_to_train, convnet.py:1915-1923): mean and variance are constants, so dx = dy*gamma*invstd,
+    dgamma = sum(dy * xhat), dbeta = sum(dy)."""
+    c = x.shape[-1]
+    invstd = 1.0 / np.sqrt(var + eps)
+    dy2 = dy.reshape(-1, c)
+    xhat = (x.reshape(-1, c) - mean) * invstd
+    return (dy * (gamma * invstd)).astype(x.dtype), (dy2 * xhat).sum(0), dy2.sum(0)
+
+
 def bn_bwd(dy, x, gamma, save_mean, save_invstd):
     """FusedBatchNormGrad: gradient through the batch statistics."""
     c = x.shape[-1]
@@ -522,13 +533,23 @@ def ema_decay(decay, step):
     return min(decay, (1.0 + step) / (10.0 + step))
 
 
-def sgd_nesterov_step(w, g, accum, lr, momentum=0.9, l2=0.0, ema=None, ema_d=None, wd=0.0, grad_scale=1.0):
+def decoupled_decay(w, wd, l1=False, huber_delta=None):
+    """The decay applied after apply_gradients (optimizers.py:163-170): w - wd*w, or w - wd*sign(w) (l1_weight_decay),
+    or the pseudo-Huber form w - wd*w/sqrt(1 + (w/delta)^2) (huber_decay_delta, which wins over l1)."""
+    if huber_delta is not None:
+        return w - wd * w / np.sqrt(1.0 + (w / huber_delta) ** 2)
+    if l1:
+        return w - wd * np.sign(w)
+    return w - wd * w
+
+
+def sgd_nesterov_step(w, g, accum, lr, momentum=0.9, l2=0.0, ema=None, ema_d=None, wd=0.0, grad_scale=1.0, l1_decay=False, huber_delta=None):
     """One update of one tensor, in the reference's order:
       1. EMA of the PRE-update value (update_ops are control dependencies of apply_gradients,
          optimizers.py:159,175): ema <- d*ema + (1-d)*w
       2. g_total = grad_scale*g + l2*w           (l2 term of the loss, convnet.py:563)
       3. accum <- momentum*accum + g_total ; w <- w - lr*g_total - lr*momentum*accum
-      4. optional decoupled decay w <- w - wd*w  (optimizers.py:169)
+      4. optional decoupled decay w <- w - wd*w, or its L1 / pseudo-Huber variants  (optimizers.py:163-170)
     Returns w, accum, ema."""
     if ema is not None:
         ema = ema_d * ema + (1.0 - ema_d) * w
@@ -536,7 +557,7 @@ def sgd_nesterov_step(w, g, accum, lr, momentum=0.9, l2=0.0, ema=None, ema_d=Non
     accum = momentum * accum + gt
     w = w - lr * gt - lr * momentum * accum
     if wd > 0.0:
-        w = w - wd * w
+        w = decoupled_decay(w, wd, l1_decay, huber_delta)
     return w, accum, ema
 
 

@@ -73,6 +73,104 @@ def test_resnet_two_steps_fp32(kind, fuse):
         assert worst[0] <= 1e-4, 'step {}: worst EMA {}'.format(step, worst)
 
 
+@pytest.mark.parametrize('variant', [dict(base_weight_decay=0.3), dict(base_weight_decay=0.3, l1_weight_decay=True),
+                                     dict(base_weight_decay=0.3, huber_decay_delta=0.05),
+                                     dict(base_weight_decay=0.3, huber_decay_delta=0.05, bias_norm_decay=True, weight_decay_scheduling=False),
+                                     dict(base_weight_decay=0.3, bias_norm_decay=True, gradient_threshold=0.5)])
+def test_resnet_decoupled_decay_variants(variant):
+    """optimizers.py:149-173: w -= wd*w / wd*sign(w) / pseudo-Huber after the update, wd = base*B/256 [* lr multiplier];
+    bias_norm_decay widens the L2 term (convnet.py:536) and the decay to biases and BN gamma / beta."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(77)
+    mk = {k: v for k, v in variant.items() if k == 'bias_norm_decay'}
+    model, spec, params, stats = make_resnet(18, 'float32', True, **mk)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=4, learning_warmup_epochs=1.0, **variant)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    hp = dict(variant)
+    for step in range(3):
+        x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+        model.feed(x, LABELS)
+        opt.curr_step = step
+        opt._update_learning_rate()                                          # the train loop's per-step call (optimizers.py:408)
+        loss, _, y_pred = opt._step(None)
+        mult = O.lr_multiplier(step, 4, opt.num_epochs, warmup_epoch=1.0)
+        assert abs(opt.curr_multiplier - mult) <= 1e-12
+        rloss, rpred, _ = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=hp, lr_mult=mult, batch_total=BATCH)
+        assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, loss, rloss)
+        got = model.get_variables('data')
+        worst = max((rel_l2(got[k], v), k) for k, v in state.params.items())
+        assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
+    # the decay was visible at this size: the oracle's own run without it ends somewhere else
+    plain = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    rng = np.random.default_rng(77)
+    for step in range(3):
+        x = rng.random((BATCH, 64, 64, 3))
+        ON.train_step(spec, plain, x.astype(np.float32).astype(np.float64), LABELS.astype(np.float64),
+                      hp={k: v for k, v in hp.items() if k == 'gradient_threshold'}, lr_mult=O.lr_multiplier(step, 4, 100, warmup_epoch=1.0), batch_total=BATCH)
+    assert max(rel_l2(state.params[k], plain.params[k]) for k in params if k.endswith('/weights')) > 1e-3
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('freeze', [dict(blocks_to_train=[4, None]),            # fine-tune the last stage + logits: no gradient below
+                                    dict(blocks_to_train=[None]),               # logits only
+                                    dict(blocks_to_train=[0, None]),            # gradient flows back THROUGH frozen blocks
+                                    dict(update_batch_norm=False),              # everything trains, statistics frozen
+                                    dict(blocks_to_train=[1, 2], update_batch_norm=True)])
+def test_resnet_frozen_blocks_and_frozen_batch_norm(freeze, dtype):
+    """blocks_to_train / update_batch_norm (convnet.py:1384-1389, 1781-1795; optimizers.py:53): frozen variables get no
+    gradient, no update and no decay but keep their EMA shadow moving; a BN outside the trained blocks normalises with
+    its running statistics also in training mode and back-propagates as an affine map (mcn_bn_bwd_frozen)."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(123)
+    model, spec, params, stats = make_resnet(18, dtype, True, **freeze)
+    for k in stats:                                                           # non-trivial running statistics
+        stats[k] = (0.2 * rng.standard_normal(stats[k].shape) if k.endswith('/mu') else 0.5 + rng.random(stats[k].shape)).astype(np.float32)
+    model.set_variables(dict(params, **stats))
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, base_weight_decay=0.01)
+    fns = [getattr(fn, '__name__', '') for fn, _ in model._train_low.bwd.calls]
+    btt = freeze.get('blocks_to_train')
+    if btt == [None]:
+        assert not any(f.startswith('mcn_conv2d') or f.startswith('mcn_bn') for f in fns), fns   # backward = the fc layer alone
+    if freeze.get('update_batch_norm') is False or btt == [0, None]:
+        assert 'mcn_bn_bwd_frozen' in fns
+    bf = dtype == 'bfloat16'
+    quant = bf16q if bf else None
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    hp = dict(freeze, base_weight_decay=0.01)
+    for step in range(2):
+        x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+        model.feed(x, LABELS)
+        loss, _, y_pred = opt._step(None)
+        rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=hp, batch_total=BATCH, quant=quant)
+        assert abs(loss - rloss) <= (3e-2 if bf else 1e-4) * abs(rloss), (step, loss, rloss)
+        trainable = set(v.name for v in model.store.variables if v.trainable)
+        assert trainable == set(rgrads), (sorted(trainable ^ set(rgrads))[:4])
+        grads = model.get_variables('grad')
+        if bf:
+            # (bf16 storage: small gamma / beta gradients are noisy tensor by tensor; test_resnet_step_bf16 has the calibration)
+            worst = min((cosine(grads[k], rgrads[k]), k) for k in rgrads if np.linalg.norm(rgrads[k]) > 1e-6)
+            assert worst[0] >= 0.9, 'step {}: worst gradient {}'.format(step, worst)
+            flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in sorted(rgrads)])
+            assert cosine(flat(grads), flat(rgrads)) >= 0.98
+        else:
+            worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
+            assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+        got, ema = model.get_variables('data'), model.get_variables('ema')
+        tol = 2e-2 if bf else 1e-4
+        worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
+        assert worst[0] <= tol, 'step {}: worst variable {}'.format(step, worst)
+        worst = max((rel_l2(ema[k], v), k) for k, v in list(state.ema.items()) + list(state.ema_stats.items()))
+        assert worst[0] <= tol, 'step {}: worst EMA {}'.format(step, worst)
+        for k in params:                                                      # frozen variables did not move, bit for bit
+            if k not in trainable:
+                np.testing.assert_array_equal(got[k], params[k])
+        for k in stats:                                                       # frozen statistics neither
+            frozen_bn = (freeze.get('update_batch_norm') is False) or (freeze.get('update_batch_norm') is None and btt is not None
+                                                                       and not ON.trainable_name(k, btt))
+            if frozen_bn:
+                np.testing.assert_array_equal(got[k], stats[k])
+
+
 def test_resnet_fp32_bn_statistics_from_conv_epilogue():
     """fuse_bn_stats / defer_dskip (default on for bf16 only): the fp32 network with the BN statistics taken in the conv
     epilogues and the residual fan-in applied in the dgrad epilogue / projection BN backward."""

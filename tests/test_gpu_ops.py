@@ -211,6 +211,53 @@ def test_bn_relu_mask_recomputed_from_x(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(4, 6, 6, 16), (3, 4, 4, 7), (8, 14, 14, 256)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_bn_bwd_frozen(shape, act, dtype):
+    """Gradient of fused_batch_norm(is_training=False) inside a training graph (update_batch_norm=False): affine in x."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    c = shape[-1]
+    m = int(np.prod(shape[:-1]))
+    x = RNG.standard_normal(shape).astype(np.float32)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    gamma = (0.5 + RNG.random(c)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    mean = (0.2 * RNG.standard_normal(c)).astype(np.float32)
+    var = (0.5 + RNG.random(c)).astype(np.float32)
+    xq, dyq = q(x, dtype), q(dy, dtype)
+    z = O.bn_fwd_infer(xq, gamma.astype(np.float64), beta.astype(np.float64), mean.astype(np.float64), var.astype(np.float64), 1e-3)
+    if act == 1:
+        yq = q(np.maximum(z, 0), dtype)
+        dz = dyq * (yq > 0)
+    elif act == 2:
+        sg = 1.0 / (1.0 + np.exp(-z))
+        yq = q(z * sg, dtype)
+        dz = dyq * (sg + z * sg * (1 - sg))
+    else:
+        yq, dz = q(z, dtype), dyq
+    rdx, rdg, rdb = O.bn_bwd_frozen(dz, xq, gamma.astype(np.float64), mean.astype(np.float64), var.astype(np.float64), 1e-3)
+    xd, dyd, yd = u.dev(x, dtype), u.dev(dy, dtype), u.dev(yq.astype(np.float32), dtype)
+    gd, bd, md, vd = u.dev(gamma), u.dev(beta), u.dev(mean), u.dev(var)
+    dx = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg, db = torch.zeros(c, dtype=torch.float32, device=u.DEV), torch.zeros(c, dtype=torch.float32, device=u.DEV)
+    ws = u.workspace(lib.mcn_bn_workspace_bytes(m, c))
+    _ffi.check(lib.mcn_bn_bwd_frozen(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr(), gd.data_ptr(), bd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1e-3,
+                                     dx.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), 0.5, m, c, act, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, u.stream()))
+    check(u.host(dx), rdx, dtype, 'dx')
+    check(u.host(dg), 0.5 * rdg, 'float32', 'dgamma', rel=2e-5 if dtype == 'float32' else 1e-2, mx=1e-3 if dtype == 'float32' else 3e-2)
+    check(u.host(db), 0.5 * rdb, 'float32', 'dbeta', rel=2e-5 if dtype == 'float32' else 1e-2, mx=1e-3 if dtype == 'float32' else 3e-2)
+    # frozen gamma / beta (blocks_to_train): null gradient pointers
+    _ffi.check(lib.mcn_bn_bwd_frozen(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr(), gd.data_ptr(), bd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1e-3,
+                                     dx.data_ptr(), 0, 0, 0, 1.0, m, c, act, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, u.stream()))
+    check(u.host(dx), rdx, dtype, 'dx (no dgamma / dbeta)')
+    if act == 1:
+        assert lib.mcn_bn_bwd_frozen(dyd.data_ptr(), xd.data_ptr(), 0, gd.data_ptr(), bd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1e-3, dx.data_ptr(), 0, 0, 0,
+                                     1.0, m, c, act, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, u.stream()) == _ffi.E_BADARG
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_bn_infer_and_affine(dtype):
     u = _u()
     from myconvnet_amd import _ffi
@@ -411,6 +458,21 @@ def test_sgd_nesterov_ema_l2_trajectory():
         check(u.host(wd_)[:n], w, 'float32', 'w step {}'.format(step), rel=1e-6)
         check(u.host(ad_)[:n], a, 'float32', 'accum step {}'.format(step), rel=1e-6)
         check(u.host(ed_)[:n], e, 'float32', 'ema step {}'.format(step), rel=1e-6)
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_decoupled_decay_variants(mode):
+    from myconvnet_amd import _ffi
+    u = _u()
+    n = 100003
+    w = (RNG.standard_normal(n) * 0.1).astype(np.float32)
+    w[:7] = 0.0                                                              # sign(0) = 0
+    wd_ = u.dev(w)
+    _ffi.check(_ffi.lib.mcn_decoupled_decay(wd_.data_ptr(), n, 0.03, mode, 0.05, u.stream()))
+    ref = O.decoupled_decay(w.astype(np.float64), 0.03, l1=(mode == 1), huber_delta=0.05 if mode == 2 else None)
+    check(u.host(wd_), ref, 'float32', 'decay mode {}'.format(mode), rel=1e-6, mx=1e-6)
+    assert _ffi.lib.mcn_decoupled_decay(wd_.data_ptr(), n, 0.03, 2, 0.0, u.stream()) == _ffi.E_BADARG
+    assert _ffi.lib.mcn_decoupled_decay(wd_.data_ptr(), n, 0.03, 3, 1.0, u.stream()) == _ffi.E_BADARG
 
 
 def test_l2_loss_ema_and_bn_chain():

@@ -238,3 +238,60 @@ def test_resnet50_known_answers():
     n = sum(int(np.prod(s)) for _, s, k in spec.variables() if k not in ('mu', 'sigma'))
     assert n == 25557032
     assert len([1 for _, _, k in spec.variables() if k not in ('mu', 'sigma')]) == 161
+
+
+def test_decoupled_decay_variants_formulae():
+    """optimizers.py:163-170 restated in oracle.ops.decoupled_decay, against the formulae written out with torch."""
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal(1000) * 0.2
+    w[:3] = 0.0
+    wt = torch.tensor(w)
+    np.testing.assert_allclose(ops.decoupled_decay(w, 0.01), (wt - 0.01 * wt).numpy(), rtol=1e-14)
+    np.testing.assert_allclose(ops.decoupled_decay(w, 0.01, l1=True), (wt - 0.01 * torch.sign(wt)).numpy(), rtol=1e-14)
+    hub = wt - 0.01 * wt / torch.sqrt(1 + (wt / 0.1) ** 2)
+    np.testing.assert_allclose(ops.decoupled_decay(w, 0.01, l1=True, huber_delta=0.1), hub.numpy(), rtol=1e-14)   # Huber wins over L1
+    # small |w|: Huber ~ L2 decay; large |w|: ~ L1 decay with step wd*delta
+    assert abs(ops.decoupled_decay(np.array([1e-4]), 0.01, huber_delta=0.1)[0] - (1e-4 - 0.01 * 1e-4)) < 1e-10
+    assert abs(ops.decoupled_decay(np.array([50.0]), 0.01, huber_delta=0.1)[0] - (50.0 - 0.01 * 0.1)) < 1e-8
+
+
+def test_bn_frozen_statistics_gradient_matches_torch_autograd():
+    """oracle.ops.bn_bwd_frozen = autograd through F.batch_norm(training=False) (fused_batch_norm(is_training=False))."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((3, 5, 4, 6))
+    dy = rng.standard_normal(x.shape)
+    gamma, beta = 0.5 + rng.random(6), rng.standard_normal(6)
+    mean, var = 0.3 * rng.standard_normal(6), 0.5 + rng.random(6)
+    xt = torch.tensor(x.transpose(0, 3, 1, 2), requires_grad=True)
+    gt, bt = torch.tensor(gamma, requires_grad=True), torch.tensor(beta, requires_grad=True)
+    y = F.batch_norm(xt, torch.tensor(mean), torch.tensor(var), gt, bt, training=False, eps=1e-3)
+    np.testing.assert_allclose(ops.bn_fwd_infer(x, gamma, beta, mean, var, 1e-3), y.detach().numpy().transpose(0, 2, 3, 1), rtol=1e-12, atol=1e-12)
+    y.backward(torch.tensor(dy.transpose(0, 3, 1, 2)))
+    dx, dg, db = ops.bn_bwd_frozen(dy, x, gamma, mean, var, 1e-3)
+    np.testing.assert_allclose(dx, xt.grad.numpy().transpose(0, 2, 3, 1), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(dg, gt.grad.numpy(), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-11, atol=1e-12)
+
+
+def test_blocks_to_train_freezes_variables_and_statistics_in_the_oracle():
+    spec = net.ResNetSpec.resnet18(5, 8)
+    params, stats = net.init_variables(spec.variables(), seed=1, dtype=np.float64)
+    rng = np.random.default_rng(2)
+    for k in params:
+        if k.endswith('gamma'):
+            params[k] = 0.5 + rng.random(params[k].shape)
+    state = net.TrainState(params, stats)
+    x, y = rng.random((4, 32, 32, 3)), np.array([0., 1., 2., 3.])
+    hp = dict(blocks_to_train=[4, None], base_weight_decay=0.1)
+    _, _, grads = net.train_step(spec, state, x, y, hp=hp, batch_total=4)
+    assert set(grads) == {k for k in params if k.startswith('block_4/') or k.startswith('block_None/')}
+    for k in params:
+        moved = not np.array_equal(state.params[k], params[k])
+        assert moved == (k in grads) or not np.any(grads.get(k, 1)), k
+    for k in stats:                                       # statistics follow blocks_to_train when update_batch_norm is None
+        assert np.array_equal(state.stats[k], stats[k]) == (not k.startswith('block_4/')), k
+    # update_batch_norm=True overrides: every BN uses batch statistics and updates
+    state2 = net.TrainState(params, stats)
+    net.train_step(spec, state2, x, y, hp=dict(hp, update_batch_norm=True), batch_total=4)
+    assert all(not np.array_equal(state2.stats[k], stats[k]) for k in stats)
+    assert net.trainable_name('block_None/logits/weights', [None]) and not net.trainable_name('block_3/res_0/conv_0/weights', [None])
