@@ -186,7 +186,9 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 nl = lib.mcn_conv2d_kernel_name(ops[name], ctypes.byref(gm), mdt, buf, 128)
                 key = buf.value.decode()
                 if name == 'mcn_conv2d_fwd_bnstats':                       # the instantiation with the BN-statistics epilogue
-                    key = key.replace(', false>', ', true>')
+                    key = key.replace(', 0>', ', 1>')
+                elif (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
+                    key = key.replace(', 0>', ', 2>')                      # ... with the accumulate epilogue
                 es = 4 if dtype == 'fp32' else 2
                 # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)
                 xe = gm.N * gm.H * gm.W * gm.Cin if (gm.KH > 1 or gm.SH == 1) else gm.N * oh * ow * gm.Cin

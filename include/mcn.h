@@ -112,7 +112,8 @@ int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, v
 
 /* profiling aid: writes the name of the GEMM kernel a conv call launches (as rocprofv3 prints it) into buf
  * (>= 64 bytes) and returns how many launches of it the call makes (stride-2 dgrad: one per parity class).  For
- * mcn_conv2d_fwd_bnstats the last template argument of the printed name is `true` instead of `false`. */
+ * The last template argument of the printed name is the epilogue variant: 0 as printed; 1 for mcn_conv2d_fwd_bnstats;
+ * 2 for a dgrad that accumulates (accumulate != 0, mcn_conv2d_dgrad_addmasked). */
 int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype, char* buf, size_t buflen);
 
 /* dgrad fused with the gradient fan-in of an identity shortcut (models/resnet_v1_5.py:66-70: x + skip, relu): the input

@@ -240,25 +240,30 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
     const NtTile t = kNtCand[tile];
     const int lds = reduce ? 0 : 2 * (t.bm + t.bn) * 128;
     const dim3 grid(nblocks), block(t.nw * 64);
-#define MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, STV)                                    \
+#define MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, EPIV)                                   \
     do {                                                                             \
-        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, NWV, STV>, 2 * (BMV + BNV) * 128), true); \
+        static bool once = (allow_lds(conv_gemm_nt<T, BMV, BNV, MODEV, NWV, EPIV>, 2 * (BMV + BNV) * 128), true); \
         (void)once;                                                                  \
-        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, NWV, STV>), grid, block, lds, st, p); \
+        hipLaunchKernelGGL((conv_gemm_nt<T, BMV, BNV, MODEV, NWV, EPIV>), grid, block, lds, st, p); \
     } while (0)
 #define MCN_LAUNCH_NT(BMV, BNV, NWV, MODEV)                                           \
     do {                                                                             \
-        if (p.stats) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, true); else MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, false); \
+        if (epi == NT_EPI_STATS) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_STATS);  \
+        else if (epi == NT_EPI_ACC) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_ACC); \
+        else MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_STORE);                      \
     } while (0)
 #define MCN_LAUNCH_NT_MODE(BMV, BNV, NWV)                                                 \
     do {                                                                                  \
         if (reduce) {                                                                     \
-            if (p.stats) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, true>), grid, block, 0, st, p);  \
-            else hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, false>), grid, block, 0, st, p);         \
+            if (epi == NT_EPI_STATS) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STATS>), grid, block, 0, st, p);    \
+            else if (epi == NT_EPI_ACC) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_ACC>), grid, block, 0, st, p);   \
+            else hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STORE>), grid, block, 0, st, p);                        \
         } else if (mode == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_LINEAR);            \
         else if (mode == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_UNIFORM);            \
         else MCN_LAUNCH_NT(BMV, BNV, NWV, NT_GENERIC);                                    \
     } while (0)
+    // epilogue variant: the accumulate modes have their own instantiation (batched loads), so do the BN statistics
+    const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
     if (t.bm == 256) {
         if constexpr (sizeof(T) == 2) {
             MCN_LAUNCH_NT_MODE(256, 128, 8);
@@ -736,7 +741,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return 1;
     }
     if (op == MCN_CONV_DGRAD) {
@@ -756,7 +761,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, false>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
+        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return ncls;
     }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }

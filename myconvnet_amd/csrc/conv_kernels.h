@@ -173,11 +173,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // Epilogue of conv_gemm_nt / conv_nt_sk_reduce: bias, store (or accumulate), optional BN-statistics partials.
-template <typename T, int BM, int BN, bool TAPS, int NW, bool STATS>
+// EPI: 0 = store, 1 = store + BN-statistics partials, 2 = accumulate (p.accumulate 1 / 2) — compile-time so that the plain
+// and statistics instantiations do not carry the registers of the accumulate path's batched loads.
+enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2 };
+template <typename T, int BM, int BN, bool TAPS, int NW, int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                                             typename MmaNT<T>::Acc (&acc)[BN / 2 / MmaNT<T>::MT][BM / (NW / 2) / MmaNT<T>::MT],
                                             const int m0, const int n0, const int lane, const int wm, const int wn) {
     typedef MmaNT<T> MM;
+    constexpr bool STATS = EPI == NT_EPI_STATS, ACC = EPI == NT_EPI_ACC;
     constexpr int WROWS = NW / 2;
     constexpr int WTM = BM / WROWS, WTN = BN / 2;
     constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
@@ -206,6 +210,40 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                     s1[j][g][e] = s2[j][g][e] = 0.f;
                 }
             }
+    }
+    // Accumulate modes: ALL the loads of the epilogue are issued back to back in front of the first store.  (With LDS-DMA
+    // in the kernel hipcc waits vmcnt(0) at the first use of every ordinary load, which also drains the stores in front of
+    // it: loads issued one by one ahead of their stores cost a store + a load round trip each — 32 per 128x128 tile, and
+    // the residual-add dgrads ran at half the HBM rate.)
+    typedef T TV4 __attribute__((ext_vector_type(4)));      // 4 output elements (16 B fp32 / 8 B bf16)
+    TV4 prev[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
+    unsigned char mbits[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
+    if constexpr (ACC) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * MM::MT + fr;
+            const bool mvalid = m < p.m_end;
+            const int mm = mvalid ? m : 0;
+            const int hw = p.OH * p.OW;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const long pix = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                    const int n = n0 + wn * WTN + j * MM::MT + nl;
+                    prev[i][j][g] = TV4{};
+                    mbits[i][j][g] = 0;
+                    if (mvalid && n < p.Nn) {
+                        const T* src = reinterpret_cast<const T*>(p.accumulate == 2 ? p.add_src : (const void*)p.out) + pix * p.ldo + n;
+                        prev[i][j][g] = *reinterpret_cast<const TV4*>(src);
+                        if (p.accumulate == 2) mbits[i][j][g] = sizeof(T) == 4 ? p.add_mask[pix * (p.ldo >> 2) + (n >> 2)] : p.add_mask[pix * (p.ldo >> 3) + (n >> 3)];
+                        else mbits[i][j][g] = 0xff;
+                    }
+                }
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -237,48 +275,22 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += bv[e];
                 }
-                if (sizeof(T) == 4) {
-                    f32x4* dst = reinterpret_cast<f32x4*>(orow + n);
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (p.accumulate == 1) {
-                        const f32x4 old = *dst;
-                        o += old;
-                    } else if (p.accumulate == 2) {
-                        const f32x4 sv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
-                        const unsigned mb = p.add_mask[pix * (p.ldo >> 2) + (n >> 2)];
+                if constexpr (ACC) {
+                    // accumulate 1: every bit of mbits is set; 2: the residual's ReLU mask, one bit per element
+                    const unsigned mb = sizeof(T) == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (n & 4));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += (mb >> e) & 1u ? sv[e] : 0.f;
-                    }
-                    *dst = o;
-                    if (do_stats) {
+                    for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? to_f32(prev[i][j][g][e]) : 0.f;
+                }
+                TV4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = o[e] - piv[j][g][e];
-                            s1[j][g][e] += d;
-                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
-                        }
-                    }
-                } else {
-                    bf16x4* dst = reinterpret_cast<bf16x4*>(orow + n);
-                    if (p.accumulate == 1) {
-                        const bf16x4 old = *dst;
+                for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+                *reinterpret_cast<TV4*>(orow + n) = o;
+                if (do_stats) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
-                    } else if (p.accumulate == 2) {
-                        const bf16x4 sv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(p.add_src) + pix * p.ldo + n);
-                        const unsigned mb = (unsigned)p.add_mask[pix * (p.ldo >> 3) + (n >> 3)] >> (n & 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? (float)sv[e] : 0.f;
-                    }
-                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                    *dst = o;
-                    if (do_stats) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = (float)o[e] - piv[j][g][e];
-                            s1[j][g][e] += d;
-                            s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = to_f32(o[e]) - piv[j][g][e];
+                        s1[j][g][e] += d;
+                        s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
                     }
                 }
             }
@@ -325,7 +337,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     }
 }
 
-template <typename T, int BM, int BN, int MODE, int NW = 4, bool STATS = false>
+template <typename T, int BM, int BN, int MODE, int NW = 4, int EPI = NT_EPI_STORE>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
@@ -525,11 +537,11 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
                 for (int e = 0; e < ACCSZ; ++e) dst[(size_t)((j * TM + i) * ACCSZ + e) * NT] = acc[j][i][e];
         return;
     }
-    nt_epilogue<T, BM, BN, TAPS, NW, STATS>(p, acc, m0, n0, lane, wm, wn);
+    nt_epilogue<T, BM, BN, TAPS, NW, EPI>(p, acc, m0, n0, lane, wm, wn);
 }
 
 // Stream-K reduce: tail tile blockIdx.x = the sum of its K-slices in a fixed order (deterministic), then the ordinary epilogue.
-template <typename T, int BM, int BN, int NW, bool STATS>
+template <typename T, int BM, int BN, int NW, int EPI>
 __global__ __launch_bounds__(NW * 64) void conv_nt_sk_reduce(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int NT = NW * 64;
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_sk_reduce(const GemmNTParams 
 #pragma unroll
                 for (int e = 0; e < ACCSZ; ++e) acc[j][i][e] += src[(size_t)((j * TM + i) * ACCSZ + e) * NT];
     }
-    nt_epilogue<T, BM, BN, true, NW, STATS>(p, acc, m0, n0, lane, wave >> 1, wave & 1);
+    nt_epilogue<T, BM, BN, true, NW, EPI>(p, acc, m0, n0, lane, wave >> 1, wave & 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,12 +1,19 @@
 """Lowering of graph Nodes to C-ABI launch lists (forward, backward) — the only place that calls
 libmcn_hip.  Every emit_* function cites the reference op it stands for in include/mcn.h."""
 import ctypes
+import os
 
 import torch
 
 from . import _ffi
 from ._ffi import lib
 from .graph import MCN_DT, TORCH_DT, Program, ptr
+
+
+def _env_flag(name, default):
+    """Experiment switch: MCN_<NAME>=0/1 overrides a lowering default (an explicit model kwarg still wins)."""
+    e = os.environ.get(name)
+    return default if e is None else bool(int(e))
 
 
 class Lowering(object):
@@ -26,10 +33,9 @@ class Lowering(object):
         self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
         # BN statistics in the conv epilogue: on for bf16 (+2-3 % end to end); fp32's 1x1 convs are output-bound and the
         # epilogue costs them what the skipped statistics pass saves, so fp32 keeps the separate pass unless asked
-        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', graph.dtype == 'bfloat16'))
-        # (like the statistics epilogue: +1 % in bf16, neutral in fp32 where it only moves 0.7 ms from the BN kernel into the
-        # MFMA-bound dgrad — default on for bf16 only)
-        self.defer_dskip = bool(model._parameters.get('defer_dskip', graph.dtype == 'bfloat16'))
+        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', _env_flag('MCN_FUSE_BN_STATS', graph.dtype == 'bfloat16')))
+        # (+1 % in bf16, +0.6 % in fp32 since the accumulate epilogue issues its loads in one batch)
+        self.defer_dskip = bool(model._parameters.get('defer_dskip', _env_flag('MCN_DEFER_DSKIP', True)))
         self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.scratch = {}

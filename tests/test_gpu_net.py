@@ -172,7 +172,7 @@ def test_resnet_frozen_blocks_and_frozen_batch_norm(freeze, dtype):
 
 
 def test_resnet_fp32_bn_statistics_from_conv_epilogue():
-    """fuse_bn_stats / defer_dskip (default on for bf16 only): the fp32 network with the BN statistics taken in the conv
+    """fuse_bn_stats (default on for bf16 only) / defer_dskip: the fp32 network with the BN statistics taken in the conv
     epilogues and the residual fan-in applied in the dgrad epilogue / projection BN backward."""
     import myconvnet_amd as M
     rng = np.random.default_rng(61)

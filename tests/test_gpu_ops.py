@@ -613,7 +613,7 @@ def test_conv_tile_candidates_agree(case, dtype):
         _ffi.check(lib.mcn_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
         np.testing.assert_array_equal(u.host(dx), dx0, err_msg='dgrad tile {}'.format(tile))
     if dtype == 'bfloat16' and cout > 64:
-        assert any(', 8, false>' in nm for nm in names), names             # the 8-wave tile was exercised
+        assert any(', 8, 0>' in nm for nm in names), names             # the 8-wave tile was exercised
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
