@@ -164,6 +164,9 @@ enum { NT_LINEAR = 0, NT_UNIFORM = 1, NT_GENERIC = 2 };
 // Two LDS buffers: the DMA of step ks+1 is issued after the barrier of step ks and flies under that step's MFMAs
 // (vmcnt(0) + one barrier per K-step).  Measured against the earlier register-staged pipeline (two register sets, prefetch
 // distance 2): bf16 5-25 % faster per layer, fp32 equal (MFMA-bound).  STATS: epilogue with the BN-statistics partials.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
@@ -245,11 +248,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                 }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * MM::MT + fr;
-        if (m >= p.m_end) continue;
-        long pix;
+    // pixel of accumulator row block i for this lane (false: past the end of the GEMM rows)
+    auto row_pix = [&](int i, long& pix) -> bool {
+        const int mraw = m0 + wm * WTM + i * MM::MT + fr;
+        const bool mvalid = mraw < p.m_end;
+        const int m = mvalid ? mraw : 0;
         if (TAPS || p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf) {
             const int hw = p.OH * p.OW;
             const int img = m / hw, rem = m - img * hw;
@@ -258,40 +261,82 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
         } else {
             pix = m;
         }
-        T* orow = out + pix * p.ldo;
+        return mvalid;
+    };
+    // the 4 output values of accumulator (i, j, g) as stored: bias, accumulate, rounding; statistics of the valid ones
+    auto value = [&](int i, int j, int g, int n, bool valid) -> TV4 {
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e];
+        if (p.bias && valid) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
-                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-                const int n = n0 + wn * WTN + j * MM::MT + nl;
-                if (n >= p.Nn) continue;
-                float v[4];
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+        if constexpr (ACC) {
+            // accumulate 1: every bit of mbits is set; 2: the residual's ReLU mask, one bit per element
+            const unsigned mb = sizeof(T) == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (n & 4));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e];
-                if (p.bias) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? to_f32(prev[i][j][g][e]) : 0.f;
+        }
+        TV4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+        if (do_stats && valid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = to_f32(o[e]) - piv[j][g][e];
+                s1[j][g][e] += d;
+                s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
+            }
+        }
+        return o;
+    };
+    // bf16 / 16x16 accumulators: a lane holds 4 channels = 8 bytes of a pixel, and 8-byte stores run at 2/3 of the rate of
+    // 16-byte ones (4.5 vs 6.4-6.8 TB/s measured for these row shapes).  Lanes l and l+16 hold neighbouring channel groups
+    // of the same pixel: one v_permlane16_swap per dword trades row block 2q+1 of the even 16-lane rows for row block 2q of
+    // the odd ones, after which every lane owns 8 consecutive channels = one 16-byte store (half as many instructions).
+    constexpr bool CAN_PAIR = MM::MT == 16 && sizeof(T) == 2 && TM % 2 == 0;
+    if (CAN_PAIR && p.Nn % 8 == 0 && p.ldo % 8 == 0) {
+        if constexpr (CAN_PAIR) {
+            const bool oddrow = (lane >> 4) & 1;
+#pragma unroll
+            for (int q = 0; q < TM / 2; ++q) {
+                long pix0, pix1;
+                const bool mv0 = row_pix(2 * q, pix0), mv1 = row_pix(2 * q + 1, pix1);
+                const long pixs = oddrow ? pix1 : pix0;
+                const bool mvs = oddrow ? mv1 : mv0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * MM::MT + 4 * (lane >> 4);
+                    const bool nv = n < p.Nn;
+                    const u32x2 a = __builtin_bit_cast(u32x2, value(2 * q, j, 0, n, mv0 && nv));
+                    const u32x2 b = __builtin_bit_cast(u32x2, value(2 * q + 1, j, 0, n, mv1 && nv));
+                    const auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    // even rows: (own, partner) of row block 2q; odd rows: (partner, own) of 2q+1 — lower channels first
+                    const u32x4 w = {lo[0], hi[0], lo[1], hi[1]};
+                    const int ns = n - (oddrow ? 4 : 0);
+                    if (mvs && nv) *reinterpret_cast<u32x4*>(out + pixs * p.ldo + ns) = w;
                 }
-                if constexpr (ACC) {
-                    // accumulate 1: every bit of mbits is set; 2: the residual's ReLU mask, one bit per element
-                    const unsigned mb = sizeof(T) == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (n & 4));
+            }
+        }
+    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? to_f32(prev[i][j][g][e]) : 0.f;
-                }
-                TV4 o;
+        for (int i = 0; i < TM; ++i) {
+            long pix;
+            const bool mvalid = row_pix(i, pix);
+            T* orow = out + pix * p.ldo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
-                *reinterpret_cast<TV4*>(orow + n) = o;
-                if (do_stats) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = to_f32(o[e]) - piv[j][g][e];
-                        s1[j][g][e] += d;
-                        s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
-                    }
+                for (int g = 0; g < NG; ++g) {
+                    // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
+                    const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                    const int n = n0 + wn * WTN + j * MM::MT + nl;
+                    const bool valid = mvalid && n < p.Nn;
+                    const TV4 o = value(i, j, g, n, valid);
+                    if (valid) *reinterpret_cast<TV4*>(orow + n) = o;
                 }
             }
         }
