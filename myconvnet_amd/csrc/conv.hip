@@ -290,6 +290,8 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     p.m_end = p.M;
     const long W = (long)((p.M + t.bm - 1) / t.bm) * ((p.Nn + t.bn - 1) / t.bn);
     const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
+    static const int epi_flags = [] { const char* e = getenv("MCN_NT_EPI_FLAGS"); return e ? atoi(e) : 0; }();
+    p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
     if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
     p.sk_mode = 1;

@@ -51,6 +51,7 @@ struct GemmNTParams {
     const void* add_src;
     const unsigned char* add_mask;
     unsigned in_bytes, wt_bytes;
+    int epi_flags;          // experiments (MCN_NT_EPI_FLAGS): 1 = no lane pairing (8-byte bf16 accesses), 2 = byte-wise mask loads
     int tap[MCN_MAX_TAPS];  // (dy & 0xffff) | (dx << 16) per filter tap: 32-bit so that a wave-uniform tap index is a scalar load
                             // (byte tables are fetched with vector loads whose waits drain the LDS-DMA queue)
 };
@@ -219,34 +220,85 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     // it: loads issued one by one ahead of their stores cost a store + a load round trip each — 32 per 128x128 tile, and
     // the residual-add dgrads ran at half the HBM rate.)
     typedef T TV4 __attribute__((ext_vector_type(4)));      // 4 output elements (16 B fp32 / 8 B bf16)
+    constexpr bool CAN_PAIR = MM::MT == 16 && sizeof(T) == 2 && TM % 2 == 0;
+    const bool paired = CAN_PAIR && p.Nn % 8 == 0 && p.ldo % 8 == 0 && !(p.epi_flags & 1);      // see the store loop below
     TV4 prev[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
     unsigned char mbits[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
     if constexpr (ACC) {
+        constexpr int CEL = (int)(16 / sizeof(T));                     // elements per mask byte
+        constexpr int MB = WTN / CEL;                                  // mask bytes per pixel for this wave's WTN channels: 4, 8 or 16
+        static_assert(MB % 4 == 0, "mask bytes per wave row");
+        // one wide mask load per row block (instead of a byte per accumulator) when the wave's channel range is whole
+        const bool wide = p.accumulate == 2 && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)p.add_mask & 15) == 0 && !(p.epi_flags & 2);
+        long pixv[TM];
+        bool mval[TM];
+        unsigned mw[TM][MB / 4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * WTM + i * MM::MT + fr;
-            const bool mvalid = m < p.m_end;
-            const int mm = mvalid ? m : 0;
+            mval[i] = m < p.m_end;
+            const int mm = mval[i] ? m : 0;
             const int hw = p.OH * p.OW;
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const long pix = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
+            pixv[i] = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
+#pragma unroll
+            for (int k = 0; k < MB / 4; ++k) mw[i][k] = 0;
+            if (wide && mval[i] && n0 + wn * WTN < p.Nn) {
+                const unsigned char* mp = p.add_mask + pixv[i] * (p.ldo / CEL) + (n0 + wn * WTN) / CEL;
+                if constexpr (MB == 4) mw[i][0] = *reinterpret_cast<const unsigned*>(mp);
+                else if constexpr (MB == 8) { const u32x2 t = *reinterpret_cast<const u32x2*>(mp); mw[i][0] = t[0]; mw[i][1] = t[1]; }
+                else { const u32x4 t = *reinterpret_cast<const u32x4*>(mp); mw[i][0] = t[0]; mw[i][1] = t[1]; mw[i][2] = t[2]; mw[i][3] = t[3]; }
+            }
+        }
+        if (paired) {
+            if constexpr (CAN_PAIR) {
+                // 16-byte loads in the paired layout of the store loop, then the same swap hands every lane its own channels
+                const bool oddrow = (lane >> 4) & 1;
+#pragma unroll
+                for (int q = 0; q < TM / 2; ++q) {
+                    const long pixs = oddrow ? pixv[2 * q + 1] : pixv[2 * q];
+                    const bool mvs = oddrow ? mval[2 * q + 1] : mval[2 * q];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wn * WTN + j * MM::MT + 4 * (lane >> 4);
+                        const int ns = n - (oddrow ? 4 : 0);
+                        u32x4 w = {0u, 0u, 0u, 0u};
+                        if (mvs && n < p.Nn)
+                            w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.accumulate == 2 ? p.add_src : (const void*)p.out) + pixs * p.ldo + ns);
+                        const auto lo = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                        const auto hi = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                        prev[2 * q][j][0] = __builtin_bit_cast(TV4, u32x2{lo[0], hi[0]});
+                        prev[2 * q + 1][j][0] = __builtin_bit_cast(TV4, u32x2{lo[1], hi[1]});
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
                     const int n = n0 + wn * WTN + j * MM::MT + nl;
-                    prev[i][j][g] = TV4{};
-                    mbits[i][j][g] = 0;
-                    if (mvalid && n < p.Nn) {
-                        const T* src = reinterpret_cast<const T*>(p.accumulate == 2 ? p.add_src : (const void*)p.out) + pix * p.ldo + n;
-                        prev[i][j][g] = *reinterpret_cast<const TV4*>(src);
-                        if (p.accumulate == 2) mbits[i][j][g] = sizeof(T) == 4 ? p.add_mask[pix * (p.ldo >> 2) + (n >> 2)] : p.add_mask[pix * (p.ldo >> 3) + (n >> 3)];
-                        else mbits[i][j][g] = 0xff;
+                    const bool valid = mval[i] && n < p.Nn;
+                    if (!paired) {
+                        prev[i][j][g] = TV4{};
+                        if (valid) prev[i][j][g] = *reinterpret_cast<const TV4*>(reinterpret_cast<const T*>(p.accumulate == 2 ? p.add_src : (const void*)p.out) + pixv[i] * p.ldo + n);
+                    }
+                    if (p.accumulate != 2) {
+                        mbits[i][j][g] = valid ? 0xff : 0;
+                    } else if (wide) {
+                        const int idx = (j * MM::MT + nl) / CEL;          // byte of this accumulator within the wave row's MB bytes
+                        unsigned dw = mw[i][0];
+#pragma unroll
+                        for (int k = 1; k < MB / 4; ++k) dw = (idx >> 2) == k ? mw[i][k] : dw;
+                        mbits[i][j][g] = (unsigned char)(dw >> ((idx & 3) * 8));
+                    } else {
+                        mbits[i][j][g] = valid ? p.add_mask[pixv[i] * (p.ldo / CEL) + n / CEL] : 0;
                     }
                 }
-        }
     }
     // pixel of accumulator row block i for this lane (false: past the end of the GEMM rows)
     auto row_pix = [&](int i, long& pix) -> bool {
@@ -296,8 +348,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     // 16-byte ones (4.5 vs 6.4-6.8 TB/s measured for these row shapes).  Lanes l and l+16 hold neighbouring channel groups
     // of the same pixel: one v_permlane16_swap per dword trades row block 2q+1 of the even 16-lane rows for row block 2q of
     // the odd ones, after which every lane owns 8 consecutive channels = one 16-byte store (half as many instructions).
-    constexpr bool CAN_PAIR = MM::MT == 16 && sizeof(T) == 2 && TM % 2 == 0;
-    if (CAN_PAIR && p.Nn % 8 == 0 && p.ldo % 8 == 0) {
+    if (paired) {
         if constexpr (CAN_PAIR) {
             const bool oddrow = (lane >> 4) & 1;
 #pragma unroll
