@@ -137,6 +137,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
     mdt = _ffi.F32 if dtype == 'fp32' else _ffi.BF16
     buf = ctypes.create_string_buffer(128)
+    lbuf = ctypes.create_string_buffer(1024)
     table, rows = {}, {}
     calls = low.fwd.calls + low.bwd.calls
     low.prepack.run(sp)
@@ -183,12 +184,16 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
                 ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
                 flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout
-                nl = lib.mcn_conv2d_kernel_name(ops[name], ctypes.byref(gm), mdt, buf, 128)
-                key = buf.value.decode()
+                # one entry per GEMM launch of the call (a strided dgrad: one per stride-parity class, not all the same symbol)
+                nl = lib.mcn_conv2d_launch_list(ops[name], ctypes.byref(gm), mdt, lbuf, 1024)
+                launches = [ln.rsplit(':', 1) for ln in lbuf.value.decode().splitlines()]
+                epi = None
                 if name == 'mcn_conv2d_fwd_bnstats':                       # the instantiation with the BN-statistics epilogue
-                    key = key.replace(', 0>', ', 1>')
+                    epi = ', 1>'
                 elif (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
-                    key = key.replace(', 0>', ', 2>')                      # ... with the accumulate epilogue
+                    epi = ', 2>'                                           # ... with the accumulate epilogue
+                launches = [(k.replace(', 0>', epi) if epi else k, int(t)) for k, t in launches]
+                key = max(launches, key=lambda kt: kt[1])[0]               # (per-layer table: the launch with the most taps)
                 es = 4 if dtype == 'fp32' else 2
                 # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)
                 xe = gm.N * gm.H * gm.W * gm.Cin if (gm.KH > 1 or gm.SH == 1) else gm.N * oh * ow * gm.Cin
@@ -199,6 +204,16 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                     r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
                     r[0] += 1
                     r[1] += ms
+            if name in ops and len(launches) > 1:
+                # the bracket covers all launches of the call: split time, flops and bytes by filter taps (= by flops)
+                taps = float(sum(t for _, t in launches))
+                for k, tp in launches:
+                    t = table.setdefault(k, [0, 0.0, 0.0, 0.0])
+                    t[0] += 1
+                    t[1] += ms * tp / taps
+                    t[2] += flop * tp / taps
+                    t[3] += byt * tp / taps
+                continue
             t = table.setdefault(key, [0, 0.0, 0.0, 0.0])
             t[0] += nl
             t[1] += ms

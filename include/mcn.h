@@ -115,6 +115,10 @@ int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, v
  * The last template argument of the printed name is the epilogue variant: 0 as printed; 1 for mcn_conv2d_fwd_bnstats;
  * 2 for a dgrad that accumulates (accumulate != 0, mcn_conv2d_dgrad_addmasked). */
 int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype, char* buf, size_t buflen);
+/* the same per launch: one line "<kernel symbol>:<filter taps of that launch>\n" for every GEMM launch of the call (the
+ * stride-parity classes of a strided dgrad differ in taps, tile and addressing mode); returns the number of lines.
+ * buf >= 96 bytes per launch. */
+int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype, char* buf, size_t buflen);
 
 /* dgrad fused with the gradient fan-in of an identity shortcut (models/resnet_v1_5.py:66-70: x + skip, relu): the input
  * of a residual block receives dgrad(conv_0) + [y_block > 0] * dy_block.  add_src = dy_block (same shape and dtype as dx),

@@ -52,6 +52,7 @@ SIGNATURES = {
     'mcn_conv2d_pack_table_build': (c_int, [ctypes.POINTER(PackJob), c_int32, c_int, c_void_p, c_size_t, ctypes.POINTER(c_int32)]),
     'mcn_conv2d_pack_run': (c_int, [c_void_p, c_int32, c_int, c_void_p]),
     'mcn_conv2d_kernel_name': (c_int, [c_int, ctypes.POINTER(ConvGeom), c_int, ctypes.c_char_p, c_size_t]),
+    'mcn_conv2d_launch_list': (c_int, [c_int, ctypes.POINTER(ConvGeom), c_int, ctypes.c_char_p, c_size_t]),
     'mcn_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_bn_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'mcn_bn_relu_mask_bytes': (c_size_t, [c_int64, c_int32, c_int]),

@@ -773,6 +773,51 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     return 1;
 }
 
+// one line per GEMM launch of a conv call: "<kernel symbol as rocprofv3 prints it>:<filter taps of that launch>\n".
+// A strided dgrad launches once per stride-parity class of dx, and the classes differ in taps, pixel count (tile choice)
+// and addressing mode, so they are not always the same symbol.  Returns the number of launches (lines).
+extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype, char* buf, size_t buflen) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (!buf || buflen < 96) MCN_FAIL(MCN_E_BADARG, "launch_list: buffer too small");
+    if (op != MCN_CONV_DGRAD || !mfma_dgrad_ok(g, dtype)) {
+        char one[96];
+        const int n = mcn_conv2d_kernel_name(op, gg, dtype, one, sizeof(one));
+        if (n < 0) return n;
+        snprintf(buf, buflen, "%s:%d\n", one, g.KH * g.KW);
+        return 1;
+    }
+    const char* tn = dtype == MCN_F32 ? "float" : "bf16";
+    const int ce = ce_of(dtype), cpt = round_up(g.Cout, ce) / ce;
+    size_t used = 0;
+    int nl = 0;
+    buf[0] = 0;
+    for (int py = 0; py < g.SH && py < g.H; ++py)
+        for (int px = 0; px < g.SW && px < g.W; ++px) {
+            int nt = 0;
+            bool zero_off = true;
+            for (int r = 0; r < g.KH; ++r)
+                for (int s = 0; s < g.KW; ++s) {
+                    const int ty = py + g.pT - r * g.DH, tx = px + g.pL - s * g.DW;
+                    if (pos_mod(ty, g.SH) || pos_mod(tx, g.SW)) continue;
+                    nt++;
+                    if (ty / g.SH || tx / g.SW) zero_off = false;
+                }
+            if (!nt) continue;
+            const int OHs = (g.H - py + g.SH - 1) / g.SH, OWs = (g.W - px + g.SW - 1) / g.SW;
+            const long M = (long)g.N * OHs * OWs;
+            const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
+            const bool lin = nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
+            const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
+            const int w = snprintf(buf + used, buflen - used, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, mode, kNtCand[t].nw, nt);
+            if (w < 0 || (size_t)w >= buflen - used) MCN_FAIL(MCN_E_BADARG, "launch_list: buffer too small");
+            used += (size_t)w;
+            nl++;
+        }
+    return nl;
+}
+
 // K-slices per tail tile of the stream-K split the (first) GEMM launch of this conv uses when the workspace has room
 // (1 = every tile runs its whole K loop; tests and the bench use it to know which layers are split)
 extern "C" int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
