@@ -73,6 +73,21 @@ static bool mfma_path_ok(const Geo& g, mcn_dtype dt) {
 // dgrad writes dx with channel stride Cin through the vector epilogue
 static bool mfma_dgrad_ok(const Geo& g, mcn_dtype dt) { return mfma_path_ok(g, dt) && g.Cin % 4 == 0 && g.xcs == g.Cin; }
 
+// "skinny" 1x1 convs (conv_kernels.h): off the MFMA path because Cout is no chunk multiple, few outputs, chunked dense input
+static int skinny_co(const Geo& g) { return round_up(g.Cout, 8); }
+static bool skinny_ok(const Geo& g, mcn_dtype dt, int max_co) {
+    return g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pB == 0 && g.pL == 0 && g.pR == 0 && g.OH == g.H && g.OW == g.W &&
+           g.xcs == g.Cin && g.Cin % ce_of(dt) == 0 && skinny_co(g) <= max_co && (dt == MCN_F32 || dt == MCN_BF16);
+}
+#define MCN_SKINNY_MAX_CO 32        /* fwd / dgrad: accumulators per thread */
+#define MCN_SKINNY_MAX_CO_WGRAD 24  /* wgrad: [chunk elements][CO] accumulators per thread */
+static size_t skinny_w_bytes(const Geo& g) { return align_up((size_t)g.Cin * skinny_co(g) * sizeof(float), 256); }
+static long skinny_wgrad_slab(long M) {                  // pixels per slab: 256 threads x >= 32 pixels, at most 256 slabs
+    long slab = 256 * 32;
+    while ((M + slab - 1) / slab > 256) slab *= 2;
+    return slab;
+}
+
 static size_t fwd_pack_bytes(const Geo& g, mcn_dtype dt) {
     return align_up((size_t)g.Cout * g.KH * g.KW * round_up(g.Cin, ce_of(dt)) * mcn_dtype_size(dt), 256);
 }
@@ -132,7 +147,8 @@ static int naive_wgrad_slices(const Geo& g) {
 static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     size_t b = 0;
     if (!mfma_path_ok(g, dt)) {
-        const int sl = naive_wgrad_slices(g);
+        const long M = (long)g.N * g.OH * g.OW;
+        const int sl = skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD) ? (int)((M + skinny_wgrad_slab(M) - 1) / skinny_wgrad_slab(M)) + 1 : naive_wgrad_slices(g);
         if (sl > 1) b += align_up((size_t)sl * g.KH * g.KW * g.Cin * g.Cout * 4, 256);
     }
     if (mfma_path_ok(g, dt)) {
@@ -152,8 +168,8 @@ extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom
     if (dtype != MCN_F32 && dtype != MCN_BF16) return 0;
     switch (op) {
         /* packed weights (unless the caller keeps them) + room for the stream-K partials */
-        case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : 0;
-        case MCN_CONV_DGRAD: return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : 0;
+        case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : (skinny_ok(g, dtype, MCN_SKINNY_MAX_CO) ? skinny_w_bytes(g) : 0);
+        case MCN_CONV_DGRAD: return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : (skinny_ok(g, dtype, MCN_SKINNY_MAX_CO) ? skinny_w_bytes(g) : 0);
         case MCN_CONV_WGRAD: return wgrad_ws_bytes(g, dtype);
     }
     return 0;
@@ -365,6 +381,17 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
     if (M == 0) return MCN_OK;
     if (!mfma_path_ok(g, dt)) {
         if (stats) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd_bnstats: geometry takes the fallback kernel (mcn_conv2d_bnstats_rows() == 0)");
+        if (skinny_ok(g, dt, MCN_SKINNY_MAX_CO) && ws && ws_bytes >= skinny_w_bytes(g)) {
+            const int CO = skinny_co(g);
+            float* wp = (float*)ws;
+            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO);
+            const dim3 grid(nblocks(M, 4096));
+#define MCN_SKINNY_FWD(COV) hipLaunchKernelGGL((skinny_conv_fwd<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const float*)wp, bias, (T*)y, M, g.Cin, g.Cout)
+            if (CO == 8) MCN_SKINNY_FWD(8); else if (CO == 16) MCN_SKINNY_FWD(16); else if (CO == 24) MCN_SKINNY_FWD(24); else MCN_SKINNY_FWD(32);
+#undef MCN_SKINNY_FWD
+            MCN_CHECK_LAUNCH();
+            return MCN_OK;
+        }
         NaiveConvParams p = naive_params(g);
         p.x = x; p.w = w; p.y = y; p.bias = bias;
         hipLaunchKernelGGL((naive_conv_fwd<T>), dim3(nblocks(M * g.Cout)), dim3(256), 0, st, p);
@@ -453,6 +480,17 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
     const long Min = (long)g.N * g.H * g.W;
     if (Min == 0) return MCN_OK;
     if (!mfma_dgrad_ok(g, dt)) {
+        if (skinny_ok(g, dt, MCN_SKINNY_MAX_CO) && !add_src && ws && ws_bytes >= skinny_w_bytes(g)) {
+            const int CO = skinny_co(g);
+            float* wp = (float*)ws;
+            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO);
+            const dim3 grid(nblocks(Min, 4096));
+#define MCN_SKINNY_DGRAD(COV) hipLaunchKernelGGL((skinny_conv_dgrad<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const float*)wp, (T*)dx, Min, g.Cin, g.Cout, accumulate)
+            if (CO == 8) MCN_SKINNY_DGRAD(8); else if (CO == 16) MCN_SKINNY_DGRAD(16); else if (CO == 24) MCN_SKINNY_DGRAD(24); else MCN_SKINNY_DGRAD(32);
+#undef MCN_SKINNY_DGRAD
+            MCN_CHECK_LAUNCH();
+            return MCN_OK;
+        }
         NaiveConvParams p = naive_params(g);
         p.dy = dy; p.w = w; p.dx = dx; p.accumulate = accumulate;
         hipLaunchKernelGGL((naive_conv_dgrad<T>), dim3(nblocks(Min * g.Cin)), dim3(256), 0, st, p);
@@ -582,7 +620,20 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
     const size_t need = wgrad_ws_bytes(g, dt);
     if (need && (!ws || ws_bytes < need)) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
     char* wsp = (char*)ws;
-    if (!mfma_path_ok(g, dt)) {
+    if (!mfma_path_ok(g, dt) && skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) {
+        const int CO = skinny_co(g), ce = ce_of(dt);
+        const long slab = skinny_wgrad_slab(M), total = (long)g.Cin * g.Cout;
+        const int slabs = (int)((M + slab - 1) / slab);
+        float* part = (float*)wsp;
+        wsp += align_up((size_t)(slabs + 1) * total * 4, 256);
+        const dim3 grid(g.Cin / ce, slabs);
+#define MCN_SKINNY_WGRAD(COV) hipLaunchKernelGGL((skinny_conv_wgrad<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, part, M, g.Cin, g.Cout, slab)
+        if (CO == 8) MCN_SKINNY_WGRAD(8); else if (CO == 16) MCN_SKINNY_WGRAD(16); else MCN_SKINNY_WGRAD(24);
+#undef MCN_SKINNY_WGRAD
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
+        MCN_CHECK_LAUNCH();
+    } else if (!mfma_path_ok(g, dt)) {
         NaiveConvParams p = naive_params(g);
         p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
         const long total = (long)g.KH * g.KW * g.Cin * g.Cout;
@@ -738,6 +789,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     const int ce = ce_of(dtype);
     const NtTile* cand = kNtCand;
     if (op == MCN_CONV_FWD) {
+        if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_fwd<%s, %d>", tn, skinny_co(g)); return 1; }
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
         const long M = (long)g.N * g.OH * g.OW;
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
@@ -747,6 +799,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         return 1;
     }
     if (op == MCN_CONV_DGRAD) {
+        if (!mfma_dgrad_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_dgrad<%s, %d>", tn, skinny_co(g)); return 1; }
         if (!mfma_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_dgrad<%s>", tn); return 1; }
         int ncls = 0, nt0 = 0;
         for (int py = 0; py < g.SH && py < g.H; ++py)
@@ -766,6 +819,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return ncls;
     }
+    if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_co(g)); return 1; }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);

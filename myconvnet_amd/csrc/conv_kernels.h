@@ -1125,6 +1125,120 @@ __global__ __launch_bounds__(256) void naive_wgrad_reduce(const float* __restric
     dw[i] = s * scale;
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Skinny" 1x1 convolutions: few output channels that are not a chunk multiple on top of a chunked input (the class-logit
+// conv of the segmentation head: 256 -> 19 at 129x129).  One thread per pixel; the weights sit in a zero-padded fp32 table
+// [Cin][CO] in the workspace (rounded per use in bf16 mode, like every weight), read with wave-uniform (scalar) loads, so
+// the inner loop is one v_fmac per (channel, output) with an SGPR operand.  VALU bound: 2*M*Cin*CO flops at fp32 rate.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void skinny_pack_w(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CO) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * CO) return;
+    const int c = i / CO, n = i - c * CO;
+    wp[i] = n < Cout ? to_f32(from_f32<T>(w[(long)c * Cout + n])) : 0.f;
+}
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void skinny_conv_fwd(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                       T* __restrict__ y, long M, int Cin, int Cout) {
+    constexpr int CE = VecTraits<T>::CE;
+    const int nch = Cin / CE;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < M; pix += (long)gridDim.x * blockDim.x) {
+        float acc[CO];
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[n] = 0.f;
+        const T* xr = x + pix * Cin;
+        for (int ch = 0; ch < nch; ++ch) {
+            const Chunk<T> c = load_chunk<T>(xr + ch * CE);
+            const float* wr = wp + (long)ch * CE * CO;            // wave-uniform address: scalar loads
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                const float xv = c.get(e);
+#pragma unroll
+                for (int n = 0; n < CO; ++n) acc[n] = fmaf(xv, wr[e * CO + n], acc[n]);
+            }
+        }
+        T* yr = y + pix * Cout;
+#pragma unroll
+        for (int n = 0; n < CO; ++n)
+            if (n < Cout) yr[n] = from_f32<T>(acc[n] + (bias ? bias[n] : 0.f));
+    }
+}
+// dx[pixel][c] = sum_n dy[pixel][n] * w[c][n]  (accumulate: += the old value)
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void skinny_conv_dgrad(const T* __restrict__ dy, const float* __restrict__ wp, T* __restrict__ dx, long M, int Cin,
+                                                         int Cout, int accumulate) {
+    constexpr int CE = VecTraits<T>::CE;
+    const int nch = Cin / CE;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < M; pix += (long)gridDim.x * blockDim.x) {
+        float g[CO];
+        const T* dr = dy + pix * Cout;
+#pragma unroll
+        for (int n = 0; n < CO; ++n) g[n] = n < Cout ? to_f32(dr[n]) : 0.f;
+        T* xr = dx + pix * Cin;
+        for (int ch = 0; ch < nch; ++ch) {
+            const float* wr = wp + (long)ch * CE * CO;
+            Chunk<T> o;
+            Chunk<T> old;
+            if (accumulate) old = load_chunk<T>(xr + ch * CE);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int n = 0; n < CO; ++n) a = fmaf(g[n], wr[e * CO + n], a);
+                if (accumulate) a += old.get(e);
+                o.set(e, a);
+            }
+            store_chunk<T>(xr + ch * CE, o);
+        }
+    }
+}
+// dw[c][n] = sum_pixels x[pixel][c] * dy[pixel][n]: blockIdx.x = channel chunk, blockIdx.y = pixel slab; per-thread
+// accumulators [CE][CO], folded over the wave by shuffles and over the block's waves through LDS; slab partials are summed
+// in a fixed order by naive_wgrad_reduce (deterministic).
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void skinny_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, long M, int Cin,
+                                                         int Cout, long slab) {
+    constexpr int CE = VecTraits<T>::CE;
+    __shared__ float red[4][CE * CO];
+    const int ch = blockIdx.x;
+    const long p0 = (long)blockIdx.y * slab, p1 = min(M, p0 + slab);
+    float acc[CE][CO];
+#pragma unroll
+    for (int e = 0; e < CE; ++e)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[e][n] = 0.f;
+    for (long pix = p0 + threadIdx.x; pix < p1; pix += 256) {
+        const Chunk<T> c = load_chunk<T>(x + pix * Cin + ch * CE);
+        const T* dr = dy + pix * Cout;
+        float g[CO];
+#pragma unroll
+        for (int n = 0; n < CO; ++n) g[n] = n < Cout ? to_f32(dr[n]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const float xv = c.get(e);
+#pragma unroll
+            for (int n = 0; n < CO; ++n) acc[e][n] = fmaf(xv, g[n], acc[e][n]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < CE; ++e)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) {
+            float v = acc[e][n];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red[wave][e * CO + n] = v;
+        }
+    __syncthreads();
+    const long total = (long)Cin * Cout;
+    for (int i = threadIdx.x; i < CE * CO; i += 256) {
+        const int e = i / CO, n = i - e * CO;
+        if (n < Cout) part[(long)blockIdx.y * total + (long)(ch * CE + e) * Cout + n] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
 // column sums of a [M][C] matrix -> fp32 [C] (bias gradient); two-stage, deterministic
 template <typename T>
 __global__ void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C, int rows_per_block) {

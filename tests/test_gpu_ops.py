@@ -55,6 +55,9 @@ CONV_CASES = [
     (1, 14, 14, 16, 16, 3, 1, 'SAME', 2),        # dilated (DeepLab row)
     (2, 8, 6, 5, 7, 3, 1, 'SAME', 1),            # odd channels: naive fallback kernels
     (1, 1, 1, 32, 16, 3, 1, 'SAME', 1),          # 1x1 map (VGG trunk at 8x8 ends here)
+    (2, 9, 9, 64, 19, 1, 1, 'SAME', 1),          # "skinny" 1x1: 19 class logits on a chunked input (segmentation head)
+    (3, 5, 7, 32, 5, 1, 1, 'SAME', 1),           # skinny, one accumulator bucket
+    (1, 17, 13, 256, 27, 1, 1, 'SAME', 1),       # skinny fwd / dgrad (32-wide bucket), fallback wgrad
 ]
 
 
@@ -123,6 +126,20 @@ def test_conv_bias_and_dgrad_accumulate(dtype):
     dy1 = RNG.standard_normal((2, 4, 4, 32)).astype(np.float32)
     ref = q(base, dtype) + O.conv2d_dgrad(q(dy1, dtype), q(w1, dtype), x.shape, 2, 'SAME')
     check(u.conv_dgrad(dy1, w1, x.shape, 2, 'SAME', 1, dtype, accumulate_into=base), ref, dtype, 'strided dgrad accumulate')
+    # skinny 1x1 (19 outputs): bias in the forward, accumulate in the dgrad; the kernel the library reports is the skinny one
+    from myconvnet_amd import _ffi
+    xs = RNG.standard_normal((2, 6, 5, 64)).astype(np.float32)
+    ws_ = (RNG.standard_normal((1, 1, 64, 19)) / 8).astype(np.float32)
+    bs = RNG.standard_normal(19).astype(np.float32)
+    buf = ctypes.create_string_buffer(128)
+    g = u.geom(xs.shape, ws_.shape, 1, 'SAME')
+    for op, nm in ((_ffi.CONV_FWD, 'skinny_conv_fwd'), (_ffi.CONV_DGRAD, 'skinny_conv_dgrad'), (_ffi.CONV_WGRAD, 'skinny_conv_wgrad')):
+        assert _ffi.lib.mcn_conv2d_kernel_name(op, ctypes.byref(g), u.MDT[dtype], buf, 128) == 1 and buf.value.decode().startswith(nm), buf.value
+    check(u.conv_fwd(xs, ws_, 1, 'SAME', 1, dtype, bias=bs), O.conv2d_fwd(q(xs, dtype), q(ws_, dtype), 1, 'SAME') + bs, dtype, 'skinny conv+bias')
+    dys = RNG.standard_normal((2, 6, 5, 19)).astype(np.float32)
+    bases = RNG.standard_normal(xs.shape).astype(np.float32)
+    ref = q(bases, dtype) + O.conv2d_dgrad(q(dys, dtype), q(ws_, dtype), xs.shape, 1, 'SAME')
+    check(u.conv_dgrad(dys, ws_, xs.shape, 1, 'SAME', 1, dtype, accumulate_into=bases), ref, dtype, 'skinny dgrad accumulate')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
