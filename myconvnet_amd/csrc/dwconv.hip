@@ -48,11 +48,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, co
     const int chunk = chunk0 + tx;
     if (ty >= p.TY || chunk >= cch) return;
     const float* wl = sw + tx * CE;
-    for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
-        const int ox = (int)(q % p.OW);
-        const long t1 = q / p.OW;
-        const int oy = (int)(t1 % p.OH);
-        const long n = t1 / p.OH;
+    for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < (unsigned)p.npix; q += gridDim.y * (unsigned)p.TY) {   // (32-bit: 64-bit divisions cost more than the taps)
+        const unsigned t1 = q / (unsigned)p.OW;
+        const int ox = (int)(q - t1 * (unsigned)p.OW);
+        const long n = t1 / (unsigned)p.OH;
+        const int oy = (int)(t1 - (unsigned)n * (unsigned)p.OH);
         float acc[CE];
 #pragma unroll
         for (int i = 0; i < CE; ++i) acc[i] = 0.f;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, co
         Chunk<T> o;
 #pragma unroll
         for (int i = 0; i < CE; ++i) o.set(i, acc[i]);
-        store_chunk<T>(y + q * p.C + (long)chunk * CE, o);
+        store_chunk<T>(y + (long)q * p.C + (long)chunk * CE, o);
     }
 }
 
@@ -102,11 +102,11 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, 
     const float* wl = sw + tx * CE;
     const int nsx = (p.OW + S - 1) / S;
     const long nstrips = (long)p.N * p.OH * nsx;
-    for (long q = (long)blockIdx.y * p.TY + ty; q < nstrips; q += (long)gridDim.y * p.TY) {
-        const int sx = (int)(q % nsx);
-        const long t1 = q / nsx;
-        const int oy = (int)(t1 % p.OH);
-        const long n = t1 / p.OH;
+    for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < (unsigned)nstrips; q += gridDim.y * (unsigned)p.TY) {
+        const unsigned t1 = q / (unsigned)nsx;
+        const int sx = (int)(q - t1 * (unsigned)nsx);
+        const long n = t1 / (unsigned)p.OH;
+        const int oy = (int)(t1 - (unsigned)n * (unsigned)p.OH);
         const int ox0 = sx * S;
         float acc[S][CE];
 #pragma unroll
@@ -114,34 +114,76 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int i = 0; i < CE; ++i) acc[j][i] = 0.f;
         const int ix0 = ox0 * STRIDE - p.padL;
+        if constexpr (K == 3) {
+            // 3x3: branch-free rows — every segment load goes to a clamped (valid) address and is zeroed afterwards when it lies in the
+            // padding, so the loads of row ky+1 can be issued ahead of the FMAs of row ky (with a `continue` per row each row was
+            // its own load -> wait -> compute round trip and the kernel ran at 1/3 of its VALU bound).
+            Chunk<T> raw[2][L];
+            auto load_row = [&](int ky, Chunk<T>* dst) {
+                const int iy = oy * STRIDE - p.padT + ky;
+                const bool yok = (unsigned)iy < (unsigned)p.H;
+                const T* row = x + ((n * p.H + (yok ? iy : 0)) * p.W) * p.C + (long)chunk * CE;
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int iy = oy * STRIDE - p.padT + ky;
-            if ((unsigned)iy >= (unsigned)p.H) continue;
-            const T* row = x + ((n * p.H + iy) * p.W) * p.C + (long)chunk * CE;
-            float seg[L][CE];
+                for (int j = 0; j < L; ++j) {
+                    const int ix = ix0 + j;
+                    const bool ok = yok && (unsigned)ix < (unsigned)p.W;
+                    Chunk<T> c = load_chunk<T>(row + (long)(ok ? ix : 0) * p.C);
+                    if (!ok) c = Chunk<T>{};
+                    dst[j] = c;
+                }
+            };
+            load_row(0, raw[0]);
 #pragma unroll
-            for (int j = 0; j < L; ++j) {
-                const int ix = ix0 + j;
-                if ((unsigned)ix < (unsigned)p.W) {
-                    const Chunk<T> c = load_chunk<T>(row + (long)ix * p.C);
+            for (int ky = 0; ky < K; ++ky) {
+                if (ky + 1 < K) load_row(ky + 1, raw[(ky + 1) & 1]);
+                float seg[L][CE];
 #pragma unroll
-                    for (int i = 0; i < CE; ++i) seg[j][i] = c.get(i);
-                } else {
+                for (int j = 0; j < L; ++j)
 #pragma unroll
-                    for (int i = 0; i < CE; ++i) seg[j][i] = 0.f;
+                    for (int i = 0; i < CE; ++i) seg[j][i] = raw[ky & 1][j].get(i);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* wt = wl + (ky * K + kx) * wcols;
+                    float wv[CE];
+#pragma unroll
+                    for (int i = 0; i < CE; ++i) wv[i] = wt[i];
+#pragma unroll
+                    for (int j = 0; j < S; ++j)
+#pragma unroll
+                        for (int i = 0; i < CE; ++i) acc[j][i] = fmaf(seg[j * STRIDE + kx][i], wv[i], acc[j][i]);
                 }
             }
+        } else {
+            // (5x5: the same restructuring needs 160+ VGPRs of raw chunks in flight and spills; rows stay one round trip each)
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float* wt = wl + (ky * K + kx) * wcols;
-                float wv[CE];
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = oy * STRIDE - p.padT + ky;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+                const T* row = x + ((n * p.H + iy) * p.W) * p.C + (long)chunk * CE;
+                float seg[L][CE];
 #pragma unroll
-                for (int i = 0; i < CE; ++i) wv[i] = wt[i];
+                for (int j = 0; j < L; ++j) {
+                    const int ix = ix0 + j;
+                    if ((unsigned)ix < (unsigned)p.W) {
+                        const Chunk<T> c = load_chunk<T>(row + (long)ix * p.C);
 #pragma unroll
-                for (int j = 0; j < S; ++j)
+                        for (int i = 0; i < CE; ++i) seg[j][i] = c.get(i);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < CE; ++i) acc[j][i] = fmaf(seg[j * STRIDE + kx][i], wv[i], acc[j][i]);
+                        for (int i = 0; i < CE; ++i) seg[j][i] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* wt = wl + (ky * K + kx) * wcols;
+                    float wv[CE];
+#pragma unroll
+                    for (int i = 0; i < CE; ++i) wv[i] = wt[i];
+#pragma unroll
+                    for (int j = 0; j < S; ++j)
+#pragma unroll
+                        for (int i = 0; i < CE; ++i) acc[j][i] = fmaf(seg[j * STRIDE + kx][i], wv[i], acc[j][i]);
+                }
             }
         }
         T* orow = y + ((n * p.OH + oy) * p.OW + ox0) * p.C + (long)chunk * CE;
@@ -181,11 +223,11 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
     const int chunk = chunk0 + tx;
     if (ty >= p.TY || chunk >= cch) return;
     const float* wl = sw + tx * CE;
-    for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
-        const int ix = (int)(q % p.W);
-        const long t1 = q / p.W;
-        const int iy = (int)(t1 % p.H);
-        const long n = t1 / p.H;
+    for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < (unsigned)p.npix; q += gridDim.y * (unsigned)p.TY) {   // (32-bit: 64-bit divisions cost more than the taps)
+        const unsigned t1 = q / (unsigned)p.W;
+        const int ix = (int)(q - t1 * (unsigned)p.W);
+        const long n = t1 / (unsigned)p.H;
+        const int iy = (int)(t1 - (unsigned)n * (unsigned)p.H);
         float acc[CE];
 #pragma unroll
         for (int i = 0; i < CE; ++i) acc[i] = 0.f;
@@ -207,7 +249,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
                 for (int i = 0; i < CE; ++i) acc[i] = fmaf(c.get(i), wt[i], acc[i]);
             }
         }
-        T* dst = dx + q * p.C + (long)chunk * CE;
+        T* dst = dx + (long)q * p.C + (long)chunk * CE;
         Chunk<T> o;
         if (p.accumulate) {
             const Chunk<T> old = load_chunk<T>(dst);
@@ -250,13 +292,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
     if (active) {
-        for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
-            const int ox = (int)(q % p.OW);
-            const long t1 = q / p.OW;
-            const int oy = (int)(t1 % p.OH);
-            const long n = t1 / p.OH;
+        for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < (unsigned)p.npix; q += gridDim.y * (unsigned)p.TY) {   // (32-bit: 64-bit divisions cost more than the taps)
+            const unsigned t1 = q / (unsigned)p.OW;
+            const int ox = (int)(q - t1 * (unsigned)p.OW);
+            const long n = t1 / (unsigned)p.OH;
+            const int oy = (int)(t1 - (unsigned)n * (unsigned)p.OH);
             float g[4];
-            load4<T>(dy + q * p.C + (long)grp * 4, g);
+            load4<T>(dy + (long)q * p.C + (long)grp * 4, g);
             const int iy0 = oy * p.SH - p.padT, ix0 = ox * p.SW - p.padL;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
@@ -312,11 +354,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
     if (active) {
         const int nsx = (p.OW + S - 1) / S;
         const long nstrips = (long)p.N * p.OH * nsx;
-        for (long q = (long)blockIdx.y * p.TY + ty; q < nstrips; q += (long)gridDim.y * p.TY) {
-            const int sx = (int)(q % nsx);
-            const long t1 = q / nsx;
-            const int oy = (int)(t1 % p.OH);
-            const long n = t1 / p.OH;
+        for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < (unsigned)nstrips; q += gridDim.y * (unsigned)p.TY) {
+            const unsigned t1 = q / (unsigned)nsx;
+            const int sx = (int)(q - t1 * (unsigned)nsx);
+            const long n = t1 / (unsigned)p.OH;
+            const int oy = (int)(t1 - (unsigned)n * (unsigned)p.OH);
             const int ox0 = sx * S;
             float g[S][4];
             const T* drow = dy + ((n * p.OH + oy) * p.OW + ox0) * p.C + (long)grp * 4;
@@ -378,15 +420,15 @@ __global__ __launch_bounds__(256) void dw_wgrad_tap_kernel(const T* __restrict__
     const int grp = blockIdx.x * p.TX + tx;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (ty < p.TY && grp < c4) {
-        for (long q = (long)blockIdx.y * p.TY + ty; q < p.npix; q += (long)gridDim.y * p.TY) {
-            const int ox = (int)(q % p.OW);
-            const long t1 = q / p.OW;
-            const int oy = (int)(t1 % p.OH);
-            const long n = t1 / p.OH;
+        for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < (unsigned)p.npix; q += gridDim.y * (unsigned)p.TY) {   // (32-bit: 64-bit divisions cost more than the taps)
+            const unsigned t1 = q / (unsigned)p.OW;
+            const int ox = (int)(q - t1 * (unsigned)p.OW);
+            const long n = t1 / (unsigned)p.OH;
+            const int oy = (int)(t1 - (unsigned)n * (unsigned)p.OH);
             const int iy = oy * p.SH - p.padT + ky * p.DH, ix = ox * p.SW - p.padL + kx * p.DW;
             if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
             float g[4], v[4];
-            load4<T>(dy + q * p.C + (long)grp * 4, g);
+            load4<T>(dy + (long)q * p.C + (long)grp * 4, g);
             load4<T>(x + ((n * p.H + iy) * p.W + ix) * p.C + (long)grp * 4, v);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = fmaf(v[i], g[i], acc[i]);
@@ -426,6 +468,7 @@ static int dw_check(const mcn_conv_geom* g, mcn_dtype dt, const char* what) {
     if (g->Cin % (dt == MCN_F32 ? 4 : 8)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: C=%d must be a multiple of the 16-byte chunk", what, g->Cin);
     if (g->x_cs && g->x_cs != g->Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: strided input channels are not built", what);
     if (g->KH * g->KW > 121) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: filter too large", what);
+    if ((long)g->N * g->H * g->W >= 0x40000000L) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: more than 2^30 pixels (32-bit pixel indices)", what);
     return MCN_OK;
 }
 static inline int dw_out(int in, int k, int s, int d, int pa, int pb) { return (in + pa + pb - (k - 1) * d - 1) / s + 1; }
