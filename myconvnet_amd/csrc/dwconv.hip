@@ -409,6 +409,86 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
     }
 }
 
+// row-split form: a thread owns one 16-byte chunk of channels and ONE filter row ky; per strip of S outputs it loads the S dy
+// chunks and the one input row segment it needs (16-byte loads, S + L per K*S*CE FMAs) and keeps K*CE accumulators, so the
+// 5x5 case needs 40 registers of accumulators instead of 100 and half as many, twice as wide loads per FMA as the 4-channel
+// strip kernel above.  The K threads that share a strip sit next to each other in the block (their dy loads hit L1).
+// Measured (B = 512, EfficientNet-B0 layers): bf16 5x5 -18...-49 % per layer; 3x3 (24 accumulators: too little work per
+// load) and fp32 (the strip kernel's loads are already 16 bytes) are slower with it and keep the strip kernel.
+template <typename T, int K, int STRIDE, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const DwParams p) {
+    constexpr int CE = VecTraits<T>::CE;
+    constexpr int TAPS = K * K;
+    constexpr int L = (S - 1) * STRIDE + K;
+    extern __shared__ float red[];                               // [TY][TX*CE]
+    const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+    const int cch = p.C / CE;
+    const int chunk = blockIdx.x * p.TX + tx;
+    const int tys = p.TY / K;                                    // strips walked side by side in a block
+    const int ky = ty % K, sl = ty / K;
+    const bool active = sl < tys && chunk < cch;
+    float acc[K][CE];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int i = 0; i < CE; ++i) acc[kx][i] = 0.f;
+    if (active) {
+        const int nsx = (p.OW + S - 1) / S;
+        const unsigned nstrips = (unsigned)((long)p.N * p.OH * nsx);
+        for (unsigned q = blockIdx.y * (unsigned)tys + sl; q < nstrips; q += gridDim.y * (unsigned)tys) {
+            const unsigned t1 = q / (unsigned)nsx;
+            const int sx = (int)(q - t1 * (unsigned)nsx);
+            const long n = t1 / (unsigned)p.OH;
+            const int oy = (int)(t1 - (unsigned)n * (unsigned)p.OH);
+            const int iy = oy * STRIDE - p.padT + ky;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            const int ox0 = sx * S, ix0 = ox0 * STRIDE - p.padL;
+            const T* drow = dy + ((n * p.OH + oy) * p.OW + ox0) * p.C + (long)chunk * CE;
+            const T* row = x + ((n * p.H + iy) * p.W) * p.C + (long)chunk * CE;
+            Chunk<T> gr[S], sr[L];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const bool ok = ox0 + j < p.OW;
+                gr[j] = load_chunk<T>(drow + (long)(ok ? j : 0) * p.C);
+                if (!ok) gr[j] = Chunk<T>{};
+            }
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const int ix = ix0 + j;
+                const bool ok = (unsigned)ix < (unsigned)p.W;
+                sr[j] = load_chunk<T>(row + (long)(ok ? ix : 0) * p.C);
+                if (!ok) sr[j] = Chunk<T>{};
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                float g[CE];
+#pragma unroll
+                for (int i = 0; i < CE; ++i) g[i] = gr[j].get(i);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int i = 0; i < CE; ++i) acc[kx][i] = fmaf(sr[j * STRIDE + kx].get(i), g[i], acc[kx][i]);
+            }
+        }
+    }
+    const int cols = p.TX * CE;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+        for (int i = 0; i < CE; ++i) red[ty * cols + tx * CE + i] = active ? acc[kx][i] : 0.f;
+        __syncthreads();
+        if (ty < K && chunk < cch) {                              // ty = filter row; fold the block's strip lanes
+#pragma unroll
+            for (int i = 0; i < CE; ++i) {
+                float sum = 0.f;
+                for (int l = 0; l < tys; ++l) sum += red[(l * K + ty) * cols + tx * CE + i];
+                part[((long)blockIdx.y * TAPS + ty * K + kx) * p.C + (long)chunk * CE + i] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // generic filter sizes: one tap per blockIdx.z (K*K passes over the data; not on the EfficientNet path)
 template <typename T>
 __global__ __launch_bounds__(256) void dw_wgrad_tap_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const DwParams p) {
@@ -556,9 +636,29 @@ extern "C" int mcn_dwconv2d_dgrad(const void* dy, const float* w, void* dx, cons
                             : dw_dgrad_t<bf16_t>(dy, w, dx, g, accumulate, (hipStream_t)stream);
 }
 
-static DwParams dw_wgrad_params(const mcn_conv_geom* g, unsigned* gx, unsigned* gy) {
+// MCN_DW_WGRAD_ROWS: 1 (default) = the row-split kernel for the bf16 5x5 case, 0 = the 4-channel strip kernel everywhere
+static bool dw_wgrad_rows() {
+    static const int v = [] { const char* e = getenv("MCN_DW_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+static DwParams dw_wgrad_params(const mcn_conv_geom* g, mcn_dtype dtype, unsigned* gx, unsigned* gy) {
     unsigned a, b;
     DwParams p = dw_params(g, 4, false, &a, &b);
+    const int ce = dtype == MCN_BF16 ? 8 : 4;
+    if (dw_wgrad_rows() && dw_strip_ok(p) && p.C % ce == 0 && dtype == MCN_BF16 && p.KH == 5) {    // (measured: 3x3 and fp32 lose with it)
+        // row-split kernel: TX chunks x TY rows of threads, TY / K strips side by side
+        const int cch = p.C / ce;
+        p.TX = best_tx(cch, 32);
+        p.TY = 256 / p.TX;
+        *gx = (unsigned)((cch + p.TX - 1) / p.TX);
+        const long tys = p.TY / p.KH;
+        const long nstrips = (long)p.N * p.OH * ((p.OW + 3) / 4);
+        long rows = (nstrips + tys - 1) / tys;
+        long want = 2048 / *gx;
+        if (want < 1) want = 1;
+        *gy = (unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want);
+        return p;
+    }
     const int c4 = p.C / 4;
     p.TX = best_tx(c4, 64);
     p.TY = 256 / p.TX;
@@ -571,15 +671,14 @@ static DwParams dw_wgrad_params(const mcn_conv_geom* g, unsigned* gx, unsigned* 
 }
 extern "C" size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom* g, mcn_dtype dtype) {
     if (!g || g->Cin <= 0 || g->Cin % 4 || g->KH <= 0 || g->KW <= 0 || g->N < 0) return 0;
-    (void)dtype;
     unsigned gx, gy;
-    dw_wgrad_params(g, &gx, &gy);
+    dw_wgrad_params(g, dtype, &gx, &gy);
     return align_up((size_t)gy * g->KH * g->KW * g->Cin * sizeof(float), 256);
 }
 template <typename T>
 static int dw_wgrad_t(const void* x, const void* dy, float* dw, const mcn_conv_geom* g, float scale, void* ws, hipStream_t st) {
     unsigned gx, gy;
-    const DwParams p = dw_wgrad_params(g, &gx, &gy);
+    const DwParams p = dw_wgrad_params(g, sizeof(T) == 2 ? MCN_BF16 : MCN_F32, &gx, &gy);
     const long n = (long)p.KH * p.KW * p.C;
     if (p.npix == 0) {
         if (hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "dwconv2d_wgrad: memset failed");
@@ -588,7 +687,13 @@ static int dw_wgrad_t(const void* x, const void* dy, float* dw, const mcn_conv_g
     float* part = (float*)ws;
     const size_t lds = (size_t)p.TY * p.TX * 4 * sizeof(float);
     const dim3 block(256);
-    if (dw_strip_ok(p)) {
+    if (dw_wgrad_rows() && dw_strip_ok(p) && p.C % VecTraits<T>::CE == 0 && sizeof(T) == 2 && p.KH == 5) {
+        const size_t rl = (size_t)p.TY * p.TX * VecTraits<T>::CE * sizeof(float);
+#define DW_WROWS(KK, SS) hipLaunchKernelGGL((dw_wgrad_rows_kernel<T, KK, SS, 4>), dim3(gx, gy), block, rl, st, (const T*)x, (const T*)dy, part, p)
+        if (p.SH == 1) DW_WROWS(5, 1);
+        else DW_WROWS(5, 2);
+#undef DW_WROWS
+    } else if (dw_strip_ok(p)) {
         constexpr int S = 4;
 #define DW_WSTRIP(KK, SS) hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, KK, SS, S>), dim3(gx, gy), block, lds, st, (const T*)x, (const T*)dy, part, p)
         if (p.KH == 3 && p.SH == 1) DW_WSTRIP(3, 1);
