@@ -265,6 +265,95 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
 // ---- wgrad: dw[ky,kx,c] = sum_{n,oy,ox} x[n,oy*s+ky*d-pt,ox*s+kx*d-pl,c] * dy[n,oy,ox,c] ---------------------------
 // A thread owns 4 channels and all K*K taps (registers) over its share of the output pixels; the block folds its TY
 // pixel rows through LDS and writes one partial [taps][C] slab; a second kernel sums the slabs in a fixed order.
+// ---- dgrad, stride 2, row-strip form -----------------------------------------------------------------------------------
+// dx[iy][ix] takes the taps (ky, kx) with (iy + padT - ky) and (ix + padL - kx) even.  A thread produces S consecutive dx
+// pixels of one row for its chunk: for every filter row of the right parity it loads ONE dy row segment (S/2 + (K-1)/2 + 1
+// chunks) and every (pixel, kx) pair of the right parity — known at compile time, PL = padL — reads it from registers.  The
+// per-pixel kernel above tests K*K taps and issues a load per hit for every pixel (2-3x the time of the forward pass).
+template <typename T, int K, int PL, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, const DwParams p) {
+    constexpr int CE = VecTraits<T>::CE;
+    constexpr int OFF = (K - 1) / 2;
+    constexpr int LS = OFF + (S - 1 + PL) / 2 + 1;
+    extern __shared__ float sw[];                                // [taps][TX*CE]
+    const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+    const int cch = p.C / CE;
+    const int chunk0 = blockIdx.x * p.TX;
+    const int wcols = p.TX * CE;
+    for (int i = threadIdx.x; i < K * K * wcols; i += 256) {
+        const int t = i / wcols, c = chunk0 * CE + (i - t * wcols);
+        sw[i] = c < p.C ? round_w<T>(w[(long)t * p.C + c]) : 0.f;
+    }
+    __syncthreads();
+    const int chunk = chunk0 + tx;
+    if (ty >= p.TY || chunk >= cch) return;
+    const float* wl = sw + tx * CE;
+    const int nsx = (p.W + S - 1) / S;
+    const unsigned nstrips = (unsigned)((long)p.N * p.H * nsx);
+    for (unsigned q = blockIdx.y * (unsigned)p.TY + ty; q < nstrips; q += gridDim.y * (unsigned)p.TY) {
+        const unsigned t1 = q / (unsigned)nsx;
+        const int sx = (int)(q - t1 * (unsigned)nsx);
+        const long n = t1 / (unsigned)p.H;
+        const int iy = (int)(t1 - (unsigned)n * (unsigned)p.H);
+        const int ix0 = sx * S;                                  // multiple of S (even)
+        float acc[S][CE];
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+#pragma unroll
+            for (int i = 0; i < CE; ++i) acc[j][i] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int ny = iy + p.padT - ky;
+            if (ny < 0 || (ny & 1)) continue;
+            const int oy = ny >> 1;
+            if (oy >= p.OH) continue;
+            const T* drow = dy + ((n * p.OH + oy) * p.OW) * p.C + (long)chunk * CE;
+            float seg[LS][CE];
+#pragma unroll
+            for (int i2 = 0; i2 < LS; ++i2) {
+                const int ox = (ix0 >> 1) + i2 - OFF;
+                const bool ok = (unsigned)ox < (unsigned)p.OW;
+                Chunk<T> c = load_chunk<T>(drow + (long)(ok ? ox : 0) * p.C);
+                if (!ok) c = Chunk<T>{};
+#pragma unroll
+                for (int i = 0; i < CE; ++i) seg[i2][i] = c.get(i);
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float* wt = wl + (ky * K + kx) * wcols;
+                float wv[CE];
+#pragma unroll
+                for (int i = 0; i < CE; ++i) wv[i] = wt[i];
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    if (((j + PL - kx) & 1) == 0) {               // compile time
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int r = (j + PL - kx + 2 * OFF) / 2;   // = (j + PL - kx) / 2 + OFF, numerator even and >= 0
+#pragma unroll
+                        for (int i = 0; i < CE; ++i) acc[j][i] = fmaf(seg[r][i], wv[i], acc[j][i]);
+                    }
+                }
+            }
+        }
+        T* orow = dx + ((n * p.H + iy) * p.W + ix0) * p.C + (long)chunk * CE;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            if (ix0 + j >= p.W) break;
+            Chunk<T> o;
+            if (p.accumulate) {
+                const Chunk<T> old = load_chunk<T>(orow + (long)j * p.C);
+#pragma unroll
+                for (int i = 0; i < CE; ++i) o.set(i, acc[j][i] + old.get(i));
+            } else {
+#pragma unroll
+                for (int i = 0; i < CE; ++i) o.set(i, acc[j][i]);
+            }
+            store_chunk<T>(orow + (long)j * p.C, o);
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float* v);
 template <>
@@ -619,6 +708,19 @@ static int dw_dgrad_t(const void* dy, const float* w, void* dx, const mcn_conv_g
         f.padT = p.KH - 1 - p.padT; f.padL = p.KW - 1 - p.padL;
         if (p.KH == 3) hipLaunchKernelGGL((dw_strip_kernel<T, 3, 1, 4, true>), grid, block, lds, st, (const T*)dy, w, (T*)dx, f);
         else hipLaunchKernelGGL((dw_strip_kernel<T, 5, 1, 4, true>), grid, block, lds, st, (const T*)dy, w, (T*)dx, f);
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
+    if (dw_strip_ok(p) && p.SH == 2 && p.padL >= 0 && p.padL <= 2 && p.padL < p.KW) {
+        // stride 2: strips of dx pixels, one dy row segment per contributing filter row (grid: strips of the INPUT grid)
+        const long nstrips = (long)p.N * p.H * ((p.W + 3) / 4);
+        long rows = (nstrips + p.TY - 1) / p.TY, want = 4096 / gx;
+        if (want < 1) want = 1;
+        const dim3 sgrid(gx, (unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want));
+#define DW_DS2(KK, PLV) hipLaunchKernelGGL((dw_dgrad_s2_kernel<T, KK, PLV, 4>), sgrid, block, lds, st, (const T*)dy, w, (T*)dx, p)
+        if (p.KH == 3) { if (p.padL == 0) DW_DS2(3, 0); else if (p.padL == 1) DW_DS2(3, 1); else DW_DS2(3, 2); }
+        else { if (p.padL == 0) DW_DS2(5, 0); else if (p.padL == 1) DW_DS2(5, 1); else DW_DS2(5, 2); }
+#undef DW_DS2
         MCN_CHECK_LAUNCH();
         return MCN_OK;
     }

@@ -27,6 +27,9 @@ DW_CASES = [
     (1, 10, 10, 40, 7, 1, 'SAME', 1),            # generic filter size (tap-per-block wgrad)
     (2, 9, 9, 16, 3, 1, 'VALID', 2),             # VALID + dilation
     (1, 1, 1, 8, 3, 1, 'SAME', 1),               # 1x1 map
+    (2, 12, 14, 48, 5, 2, 'SAME', 1),            # even H stride 2 5x5: pads (1,2) — the EfficientNet 56 -> 28 / 14 -> 7 case
+    (2, 9, 11, 24, 3, 2, 'SAME', 1),             # odd H stride 2 3x3: pads (1,1), width not a multiple of the strip
+    (1, 13, 10, 16, 5, 2, 'SAME', 1),            # odd H / even W: pads (2,2) x (1,2)
 ]
 
 
