@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per layer at start-up (untimed) instead of the library heuristic')
     ap.add_argument('--no-overlap', action='store_true', help='run wgrad on the main stream (serial kernels: the rocprofv3 per-kernel averages then equal the roofline object)')
+    ap.add_argument('--all-kernels', action='store_true', help='kernel_ms_per_step lists every C-ABI entry point / kernel, not the top 14')
     ap.add_argument('--layers', action='store_true', help='print a per-launch table (stderr) from the instrumented pass')
     args = ap.parse_args()
     if args.batch is None:
@@ -296,7 +297,7 @@ def main():
         if world == 1:
             table = instrumented_pass(model, args.dtype, layers=args.layers)
             table.pop('_bracket_us')
-            out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:14]}
+            out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 14)]}
             out['kernel_ms_total'] = round(sum(v[1] for v in table.values()), 3)
         if rank == 0:
             print(json.dumps(out))

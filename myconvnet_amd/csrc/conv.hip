@@ -79,6 +79,14 @@ static bool skinny_ok(const Geo& g, mcn_dtype dt, int max_co) {
     return g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pB == 0 && g.pL == 0 && g.pR == 0 && g.OH == g.H && g.OW == g.W &&
            g.xcs == g.Cin && g.Cin % ce_of(dt) == 0 && skinny_co(g) <= max_co && (dt == MCN_F32 || dt == MCN_BF16);
 }
+// ... and the mirror case, few INPUT channels in front of a chunked output (SE expand convs): dgrad and wgrad run the same
+// kernels with the roles of the two channel counts swapped
+static int skinny_ci(const Geo& g) { return round_up(g.Cin, 8); }
+static bool skinny_in_ok(const Geo& g, mcn_dtype dt, int max_co) {
+    return g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pB == 0 && g.pL == 0 && g.pR == 0 && g.OH == g.H && g.OW == g.W &&
+           g.xcs == g.Cin && g.Cout % ce_of(dt) == 0 && skinny_ci(g) <= max_co && (dt == MCN_F32 || dt == MCN_BF16);
+}
+static size_t skinny_in_w_bytes(const Geo& g) { return align_up((size_t)g.Cout * skinny_ci(g) * sizeof(float), 256); }
 #define MCN_SKINNY_MAX_CO 32        /* fwd / dgrad: accumulators per thread */
 #define MCN_SKINNY_MAX_CO_WGRAD 24  /* wgrad: [chunk elements][CO] accumulators per thread */
 static size_t skinny_w_bytes(const Geo& g) { return align_up((size_t)g.Cin * skinny_co(g) * sizeof(float), 256); }
@@ -148,7 +156,7 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     size_t b = 0;
     if (!mfma_path_ok(g, dt)) {
         const long M = (long)g.N * g.OH * g.OW;
-        const int sl = skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD) ? (int)((M + skinny_wgrad_slab(M) - 1) / skinny_wgrad_slab(M)) + 1 : naive_wgrad_slices(g);
+        const int sl = (skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD) || skinny_in_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) ? (int)((M + skinny_wgrad_slab(M) - 1) / skinny_wgrad_slab(M)) + 1 : naive_wgrad_slices(g);
         if (sl > 1) b += align_up((size_t)sl * g.KH * g.KW * g.Cin * g.Cout * 4, 256);
     }
     if (mfma_path_ok(g, dt)) {
@@ -169,7 +177,10 @@ extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom
     switch (op) {
         /* packed weights (unless the caller keeps them) + room for the stream-K partials */
         case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : (skinny_ok(g, dtype, MCN_SKINNY_MAX_CO) ? skinny_w_bytes(g) : 0);
-        case MCN_CONV_DGRAD: return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : (skinny_ok(g, dtype, MCN_SKINNY_MAX_CO) ? skinny_w_bytes(g) : 0);
+        case MCN_CONV_DGRAD:
+            if (mfma_dgrad_ok(g, dtype)) return dgrad_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES;
+            if (skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) return skinny_w_bytes(g);
+            return skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO) ? skinny_in_w_bytes(g) : 0;
         case MCN_CONV_WGRAD: return wgrad_ws_bytes(g, dtype);
     }
     return 0;
@@ -384,9 +395,9 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
         if (skinny_ok(g, dt, MCN_SKINNY_MAX_CO) && ws && ws_bytes >= skinny_w_bytes(g)) {
             const int CO = skinny_co(g);
             float* wp = (float*)ws;
-            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO);
+            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO, 0);
             const dim3 grid(nblocks(M, 4096));
-#define MCN_SKINNY_FWD(COV) hipLaunchKernelGGL((skinny_conv_fwd<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const float*)wp, bias, (T*)y, M, g.Cin, g.Cout)
+#define MCN_SKINNY_FWD(COV) hipLaunchKernelGGL((skinny_conv_fwd<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const float*)wp, bias, (T*)y, M, g.Cin, g.Cout, 0)
             if (CO == 8) MCN_SKINNY_FWD(8); else if (CO == 16) MCN_SKINNY_FWD(16); else if (CO == 24) MCN_SKINNY_FWD(24); else MCN_SKINNY_FWD(32);
 #undef MCN_SKINNY_FWD
             MCN_CHECK_LAUNCH();
@@ -483,11 +494,29 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         if (skinny_ok(g, dt, MCN_SKINNY_MAX_CO) && !add_src && ws && ws_bytes >= skinny_w_bytes(g)) {
             const int CO = skinny_co(g);
             float* wp = (float*)ws;
-            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO);
-            const dim3 grid(nblocks(Min, 4096));
+            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO, 0);
+            // few pixels (SE bottlenecks: Min = batch): spread the channel chunks over gridDim.y instead of one long loop per thread
+            const unsigned bx = nblocks(Min, 4096);
+            const int nch = g.Cin / ce_of(dt);
+            long gy = 2048 / bx;
+            if (gy > nch) gy = nch;
+            if (gy < 1) gy = 1;
+            const dim3 grid(bx, (unsigned)gy);
 #define MCN_SKINNY_DGRAD(COV) hipLaunchKernelGGL((skinny_conv_dgrad<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const float*)wp, (T*)dx, Min, g.Cin, g.Cout, accumulate)
             if (CO == 8) MCN_SKINNY_DGRAD(8); else if (CO == 16) MCN_SKINNY_DGRAD(16); else if (CO == 24) MCN_SKINNY_DGRAD(24); else MCN_SKINNY_DGRAD(32);
 #undef MCN_SKINNY_DGRAD
+            MCN_CHECK_LAUNCH();
+            return MCN_OK;
+        }
+        if (skinny_in_ok(g, dt, MCN_SKINNY_MAX_CO) && !add_src && ws && ws_bytes >= skinny_in_w_bytes(g)) {
+            // few input channels: dx[pixel][c] = sum_n dy[pixel][n] * w[c][n] is the skinny FORWARD over dy with the transposed table
+            const int CO = skinny_ci(g);
+            float* wp = (float*)ws;
+            hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cout * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cout, g.Cin, CO, 1);
+            const dim3 grid(nblocks(Min, 4096));
+#define MCN_SKINNY_DGRAD_IN(COV) hipLaunchKernelGGL((skinny_conv_fwd<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const float*)wp, (const float*)nullptr, (T*)dx, Min, g.Cout, g.Cin, accumulate)
+            if (CO == 8) MCN_SKINNY_DGRAD_IN(8); else if (CO == 16) MCN_SKINNY_DGRAD_IN(16); else if (CO == 24) MCN_SKINNY_DGRAD_IN(24); else MCN_SKINNY_DGRAD_IN(32);
+#undef MCN_SKINNY_DGRAD_IN
             MCN_CHECK_LAUNCH();
             return MCN_OK;
         }
@@ -627,9 +656,23 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         float* part = (float*)wsp;
         wsp += align_up((size_t)(slabs + 1) * total * 4, 256);
         const dim3 grid(g.Cin / ce, slabs);
-#define MCN_SKINNY_WGRAD(COV) hipLaunchKernelGGL((skinny_conv_wgrad<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, part, M, g.Cin, g.Cout, slab)
+#define MCN_SKINNY_WGRAD(COV) hipLaunchKernelGGL((skinny_conv_wgrad<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, part, M, g.Cin, g.Cout, slab, 0)
         if (CO == 8) MCN_SKINNY_WGRAD(8); else if (CO == 16) MCN_SKINNY_WGRAD(16); else MCN_SKINNY_WGRAD(24);
 #undef MCN_SKINNY_WGRAD
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
+        MCN_CHECK_LAUNCH();
+    } else if (!mfma_path_ok(g, dt) && skinny_in_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) {
+        // few input channels: the same kernel with the operands swapped (dy is the chunked one), partials stored transposed
+        const int CO = skinny_ci(g), ce = ce_of(dt);
+        const long slab = skinny_wgrad_slab(M), total = (long)g.Cin * g.Cout;
+        const int slabs = (int)((M + slab - 1) / slab);
+        float* part = (float*)wsp;
+        wsp += align_up((size_t)(slabs + 1) * total * 4, 256);
+        const dim3 grid(g.Cout / ce, slabs);
+#define MCN_SKINNY_WGRAD_IN(COV) hipLaunchKernelGGL((skinny_conv_wgrad<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const T*)x, part, M, g.Cout, g.Cin, slab, 1)
+        if (CO == 8) MCN_SKINNY_WGRAD_IN(8); else if (CO == 16) MCN_SKINNY_WGRAD_IN(16); else MCN_SKINNY_WGRAD_IN(24);
+#undef MCN_SKINNY_WGRAD_IN
         MCN_CHECK_LAUNCH();
         hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
         MCN_CHECK_LAUNCH();
@@ -800,6 +843,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     }
     if (op == MCN_CONV_DGRAD) {
         if (!mfma_dgrad_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_dgrad<%s, %d>", tn, skinny_co(g)); return 1; }
+        if (!mfma_dgrad_ok(g, dtype) && skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_fwd<%s, %d>", tn, skinny_ci(g)); return 1; }
         if (!mfma_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_dgrad<%s>", tn); return 1; }
         int ncls = 0, nt0 = 0;
         for (int py = 0; py < g.SH && py < g.H; ++py)
@@ -820,6 +864,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         return ncls;
     }
     if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_co(g)); return 1; }
+    if (!mfma_path_ok(g, dtype) && skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_ci(g)); return 1; }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);

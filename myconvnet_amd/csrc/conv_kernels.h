@@ -1131,16 +1131,18 @@ __global__ __launch_bounds__(256) void naive_wgrad_reduce(const float* __restric
 // [Cin][CO] in the workspace (rounded per use in bf16 mode, like every weight), read with wave-uniform (scalar) loads, so
 // the inner loop is one v_fmac per (channel, output) with an SGPR operand.  VALU bound: 2*M*Cin*CO flops at fp32 rate.
 // ------------------------------------------------------------------------------------------------
+// wp[c][n] (c < Cin "many", n < CO "few", zero beyond Cout) from w[c][n] (row stride Cout), or — transposed — from
+// w[n][c] (row stride Cin): the roles of the two channel counts swap for a conv with FEW INPUT channels (SE expand convs)
 template <typename T>
-__global__ void skinny_pack_w(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CO) {
+__global__ void skinny_pack_w(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CO, int transposed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cin * CO) return;
     const int c = i / CO, n = i - c * CO;
-    wp[i] = n < Cout ? to_f32(from_f32<T>(w[(long)c * Cout + n])) : 0.f;
+    wp[i] = n < Cout ? to_f32(from_f32<T>(transposed ? w[(long)n * Cin + c] : w[(long)c * Cout + n])) : 0.f;
 }
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void skinny_conv_fwd(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                       T* __restrict__ y, long M, int Cin, int Cout) {
+                                                       T* __restrict__ y, long M, int Cin, int Cout, int accumulate) {
     constexpr int CE = VecTraits<T>::CE;
     const int nch = Cin / CE;
     for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < M; pix += (long)gridDim.x * blockDim.x) {
@@ -1161,7 +1163,7 @@ __global__ __launch_bounds__(256) void skinny_conv_fwd(const T* __restrict__ x, 
         T* yr = y + pix * Cout;
 #pragma unroll
         for (int n = 0; n < CO; ++n)
-            if (n < Cout) yr[n] = from_f32<T>(acc[n] + (bias ? bias[n] : 0.f));
+            if (n < Cout) yr[n] = from_f32<T>(acc[n] + (bias ? bias[n] : 0.f) + (accumulate ? to_f32(yr[n]) : 0.f));
     }
 }
 // dx[pixel][c] = sum_n dy[pixel][n] * w[c][n]  (accumulate: += the old value)
@@ -1176,7 +1178,7 @@ __global__ __launch_bounds__(256) void skinny_conv_dgrad(const T* __restrict__ d
 #pragma unroll
         for (int n = 0; n < CO; ++n) g[n] = n < Cout ? to_f32(dr[n]) : 0.f;
         T* xr = dx + pix * Cin;
-        for (int ch = 0; ch < nch; ++ch) {
+        for (int ch = blockIdx.y; ch < nch; ch += gridDim.y) {   // (gridDim.y > 1 when there are few pixels: SE bottlenecks, M = batch)
             const float* wr = wp + (long)ch * CE * CO;
             Chunk<T> o;
             Chunk<T> old;
@@ -1198,7 +1200,7 @@ __global__ __launch_bounds__(256) void skinny_conv_dgrad(const T* __restrict__ d
 // in a fixed order by naive_wgrad_reduce (deterministic).
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void skinny_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, long M, int Cin,
-                                                         int Cout, long slab) {
+                                                         int Cout, long slab, int transposed) {
     constexpr int CE = VecTraits<T>::CE;
     __shared__ float red[4][CE * CO];
     const int ch = blockIdx.x;
@@ -1235,7 +1237,8 @@ __global__ __launch_bounds__(256) void skinny_conv_wgrad(const T* __restrict__ x
     const long total = (long)Cin * Cout;
     for (int i = threadIdx.x; i < CE * CO; i += 256) {
         const int e = i / CO, n = i - e * CO;
-        if (n < Cout) part[(long)blockIdx.y * total + (long)(ch * CE + e) * Cout + n] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        // transposed: the caller swapped the operands (few INPUT channels): element (many = ch*CE+e, few = n) belongs at [few][many]
+        if (n < Cout) part[(long)blockIdx.y * total + (transposed ? (long)n * Cin + (ch * CE + e) : (long)(ch * CE + e) * Cout + n)] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     }
 }
 

@@ -58,6 +58,9 @@ CONV_CASES = [
     (2, 9, 9, 64, 19, 1, 1, 'SAME', 1),          # "skinny" 1x1: 19 class logits on a chunked input (segmentation head)
     (3, 5, 7, 32, 5, 1, 1, 'SAME', 1),           # skinny, one accumulator bucket
     (1, 17, 13, 256, 27, 1, 1, 'SAME', 1),       # skinny fwd / dgrad (32-wide bucket), fallback wgrad
+    (64, 1, 1, 6, 96, 1, 1, 'SAME', 1),          # few INPUT channels (SE expand conv): dgrad / wgrad run the skinny kernels mirrored
+    (3, 5, 7, 20, 64, 1, 1, 'SAME', 1),          # the same on a spatial map
+    (300, 1, 1, 1152, 48, 1, 1, 'SAME', 1),      # SE reduce conv of the widest B0 block (few pixels: chunk-parallel skinny dgrad)
 ]
 
 
@@ -140,6 +143,13 @@ def test_conv_bias_and_dgrad_accumulate(dtype):
     bases = RNG.standard_normal(xs.shape).astype(np.float32)
     ref = q(bases, dtype) + O.conv2d_dgrad(q(dys, dtype), q(ws_, dtype), xs.shape, 1, 'SAME')
     check(u.conv_dgrad(dys, ws_, xs.shape, 1, 'SAME', 1, dtype, accumulate_into=bases), ref, dtype, 'skinny dgrad accumulate')
+    # mirrored case (6 input channels): accumulate in the dgrad
+    xm = RNG.standard_normal((5, 3, 4, 6)).astype(np.float32)
+    wm = (RNG.standard_normal((1, 1, 6, 32)) / 3).astype(np.float32)
+    dym = RNG.standard_normal((5, 3, 4, 32)).astype(np.float32)
+    basem = RNG.standard_normal(xm.shape).astype(np.float32)
+    refm = q(basem, dtype) + O.conv2d_dgrad(q(dym, dtype), q(wm, dtype), xm.shape, 1, 'SAME')
+    check(u.conv_dgrad(dym, wm, xm.shape, 1, 'SAME', 1, dtype, accumulate_into=basem), refm, dtype, 'few-input dgrad accumulate')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
