@@ -54,6 +54,21 @@ def test_argument_validation_without_gpu():
     assert lib.mcn_conv2d_kernel_name(_ffi.CONV_DGRAD, ctypes.byref(g2), _ffi.F32, buf, 96) == 4        # one launch per stride-parity class
     assert lib.mcn_conv2d_kernel_name(_ffi.CONV_WGRAD, ctypes.byref(g2), _ffi.F32, buf, 96) == 1 and buf.value.startswith(b'conv_gemm_tn<float')
     assert lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) >= 16 * 9 * 16 * 4
+    # per-launch list: the stride-parity classes of a strided dgrad differ in taps (and may differ in kernel symbol)
+    lbuf = ctypes.create_string_buffer(512)
+    assert lib.mcn_conv2d_launch_list(_ffi.CONV_DGRAD, ctypes.byref(g2), _ffi.F32, lbuf, 512) == 4
+    lines = lbuf.value.decode().splitlines()
+    assert len(lines) == 4 and sorted(int(ln.rsplit(':', 1)[1]) for ln in lines) == [1, 2, 2, 4] and all(ln.startswith('conv_gemm_nt<float') for ln in lines)
+    assert lib.mcn_conv2d_launch_list(_ffi.CONV_FWD, ctypes.byref(g2), _ffi.F32, lbuf, 512) == 1 and lbuf.value.decode().endswith(':9\n')
+    assert lib.mcn_conv2d_launch_list(_ffi.CONV_FWD, ctypes.byref(g2), _ffi.F32, lbuf, 8) == _ffi.E_BADARG
+    # stream-K plan: small layers run unsplit; MCN_TILE_NOSPLIT turns the split off for a layer that has one
+    assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) == 1
+    gb = _ffi.conv_geom(256, 7, 7, 512, 512, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))
+    assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) > 1 and lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.BF16) == 1
+    gb.tile = 0x100
+    assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) == 1
+    assert lib.mcn_decoupled_decay(0, 10, 0.1, 0, 0.0, 0) == _ffi.E_BADARG
+    assert lib.mcn_bn_bwd_frozen(0, 0, 0, 0, 0, 0, 0, 1e-3, 0, 0, 0, 0, 1.0, 10, 4, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
     assert lib.mcn_bn_fwd_train(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.9, 10, 4, 1e-3, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
     assert lib.mcn_bn_workspace_bytes(1000, 64) > 0
     assert lib.mcn_relu_fwd(0, 0, 10, _ffi.F32, 0) == _ffi.E_BADARG
