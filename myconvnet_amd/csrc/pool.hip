@@ -61,41 +61,55 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         }
         const long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
         pst<T, VEC>(y + o, best);
+        signed char a[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) arg[o + i] = (int8_t)bi[i];
+        for (int i = 0; i < VEC; ++i) a[i] = (signed char)bi[i];
+        if constexpr (VEC == 8) *reinterpret_cast<unsigned long long*>(arg + o) = *reinterpret_cast<const unsigned long long*>(a);   // one store, not VEC
+        else if constexpr (VEC == 4) *reinterpret_cast<unsigned*>(arg + o) = *reinterpret_cast<const unsigned*>(a);
+        else arg[o] = a[0];
     }
 }
 
-template <typename T, int VEC>
+// KK / SS: compile-time window / stride (0 = run time).  The 3x3 / 2 pool of the ResNet stem gets constants: its divisions and
+// modulos by the stride become shifts and the tap loops unroll.
+template <typename T, int VEC, int KK = 0, int SS = 0>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ arg, T* __restrict__ dx, PoolParams p) {
-    const int cv = p.C / VEC;
-    const long total = (long)p.N * p.H * p.W * cv;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cv) * VEC;
-        long r = idx / cv;
-        const int ix = (int)(r % p.W);
-        r /= p.W;
-        const int iy = (int)(r % p.H), n = (int)(r / p.H);
+    const int KH = KK ? KK : p.KH, KW = KK ? KK : p.KW, SH = SS ? SS : p.SH, SW = SS ? SS : p.SW;
+    const unsigned cv = (unsigned)(p.C / VEC);
+    const unsigned total = (unsigned)((long)p.N * p.H * p.W * cv);          // (host: < 2^32)
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        unsigned r = idx / cv;
+        const int c = (int)(idx - r * cv) * VEC;
+        const unsigned r2 = r / (unsigned)p.W;
+        const int ix = (int)(r - r2 * (unsigned)p.W);
+        const int n = (int)(r2 / (unsigned)p.H), iy = (int)(r2 - (unsigned)n * (unsigned)p.H);
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        for (int kr = 0; kr < p.KH; ++kr) {
+#pragma unroll
+        for (int kr = 0; kr < KH; ++kr) {
             const int ty = iy + p.padT - kr;
-            if (ty < 0 || ty % p.SH) continue;
-            const int oy = ty / p.SH;
+            if (ty < 0 || ty % SH) continue;
+            const int oy = ty / SH;
             if (oy >= p.OH) continue;
-            for (int ks = 0; ks < p.KW; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < KW; ++ks) {
                 const int tx = ix + p.padL - ks;
-                if (tx < 0 || tx % p.SW) continue;
-                const int ox = tx / p.SW;
+                if (tx < 0 || tx % SW) continue;
+                const int ox = tx / SW;
                 if (ox >= p.OW) continue;
                 const long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
                 float g[VEC];
                 pld<T, VEC>(dy + o, g);
-                const int code = kr * p.KW + ks;
+                const int code = kr * KW + ks;
+                // the VEC arg-max codes of this pixel chunk in ONE load (byte loads: VEC memory instructions per tap)
+                signed char a[VEC];
+                if constexpr (VEC == 8) *reinterpret_cast<unsigned long long*>(a) = *reinterpret_cast<const unsigned long long*>(arg + o);
+                else if constexpr (VEC == 4) *reinterpret_cast<unsigned*>(a) = *reinterpret_cast<const unsigned*>(arg + o);
+                else a[0] = arg[o];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    if (arg[o + i] == code) acc[i] += g[i];
+                    if (a[i] == code) acc[i] += g[i];
             }
         }
         pst<T, VEC>(dx + (((long)n * p.H + iy) * p.W + ix) * p.C + c, acc);
@@ -285,10 +299,14 @@ extern "C" int mcn_maxpool_bwd(const void* dy, const int8_t* argmax, void* dx, i
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * H * W * C;
     if (dtype == MCN_F32) {
-        if (C % 4 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
+        if (total >= 0xffffffffL) MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: more than 2^32 elements");
+        if (C % 4 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, 3, 2>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
+        else if (C % 4 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
         else hipLaunchKernelGGL((maxpool_bwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
     } else if (dtype == MCN_BF16) {
-        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+        if (total >= 0xffffffffL) MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: more than 2^32 elements");
+        if (C % 8 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+        else if (C % 8 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
         else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
