@@ -262,14 +262,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             }
         }
         const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
-        for (long r = r0 + ty; r < r1; r += TY) {
-            const long off = r * C + (long)col * VEC;
-            float g[VEC], v[VEC], o[VEC];
-            ldv<T, VEC>(dy + off, g);
-            ldv<T, VEC>(x + off, v);
-            if (RELU == 1) ldv<T, VEC>(y + off, o);
-            unsigned bits = 0;
-            if (RELU == 4) bits = reinterpret_cast<const unsigned char*>(y)[r * (C / VEC) + col];
+        // U rows per trip with all their loads issued first: two 16-byte loads in flight per thread kept these kernels at
+        // 3.8-4.2 TB/s (the apply kernels, whose stores need no wait, reach 5.7)
+        constexpr int U = 4;
+        auto row = [&](const float* g, const float* v, const float* o, unsigned bits) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float gg = g[i];
@@ -280,6 +276,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 s1[i] += gg;
                 s2[i] = fmaf(gg, (v[i] - mu[i]) * is[i], s2[i]);
             }
+        };
+        long r = r0 + ty;
+        for (; r + (long)(U - 1) * TY < r1; r += (long)U * TY) {
+            float g[U][VEC], v[U][VEC], o[U][VEC];
+            unsigned bits[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long off = (r + (long)u * TY) * C + (long)col * VEC;
+                ldv<T, VEC>(dy + off, g[u]);
+                ldv<T, VEC>(x + off, v[u]);
+                if (RELU == 1) ldv<T, VEC>(y + off, o[u]);
+                bits[u] = 0;
+                if (RELU == 4) bits[u] = reinterpret_cast<const unsigned char*>(y)[(r + (long)u * TY) * (C / VEC) + col];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) row(g[u], v[u], o[u], bits[u]);
+        }
+        for (; r < r1; r += TY) {
+            const long off = r * C + (long)col * VEC;
+            float g[VEC], v[VEC], o[VEC];
+            ldv<T, VEC>(dy + off, g);
+            ldv<T, VEC>(x + off, v);
+            if (RELU == 1) ldv<T, VEC>(y + off, o);
+            unsigned bits = 0;
+            if (RELU == 4) bits = reinterpret_cast<const unsigned char*>(y)[r * (C / VEC) + col];
+            row(g, v, o, bits);
         }
     }
     float* r1p = red;
