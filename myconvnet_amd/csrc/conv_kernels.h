@@ -610,13 +610,17 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
         // (A three-buffer variant that keeps the DMA of step ks+2 in flight across the barrier — counted vmcnt, raw
         // s_barrier — was measured and is not faster at these tile sizes: with two workgroups per CU the other
         // workgroup already covers the wait.  It needs every other load out of the loop: see GemmNTParams::tap.)
+        // a K loop of exactly two steps fits the two buffers: both DMAs go out at once (one exposed round trip instead of two)
+        // (fp32 only: in the bf16 instantiations the third inlined copy of the staging code costs an occupancy step, -9 %)
+        const bool both = sizeof(T) == 4 && nk - ks0 == 2;
         auto gstep = [&](int ks, auto cur, auto nxt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (ks + 1 < nk) issue(ks + 1, nxt);
+            if (ks + 1 < nk && !both) issue(ks + 1, nxt);
             compute(smem + decltype(cur)::value * TILE_BYTES);
         };
         issue(ks0, S0{});
+        if (both) issue(ks0 + 1, S1{});
         for (int ks = ks0; ks < nk; ks += 2) {
             gstep(ks, S0{}, S1{});
             if (ks + 1 < nk) gstep(ks + 1, S1{}, S0{});
