@@ -210,3 +210,44 @@ def test_resnet50_step_at_baseline_size_is_finite_and_deterministic(dtype):
     (l0, w0, g0, s0), (l1, w1, g1, s1) = results
     assert l0 == l1                                                       # same kernels, same order, no atomics: bit-identical
     assert torch.equal(w0, w1) and torch.equal(g0, g1) and torch.equal(s0, s1)
+
+
+# (H, C, k, stride): the depthwise convs of EfficientNet-B0 (BASELINE configs[3], B = 512)
+B0_DW = [(112, 32, 3, 1), (112, 96, 3, 2), (56, 144, 3, 1), (56, 144, 5, 2), (28, 240, 5, 1), (28, 240, 3, 2), (14, 480, 3, 1), (14, 480, 5, 1),
+         (14, 672, 5, 1), (14, 672, 5, 2), (7, 1152, 5, 1), (7, 1152, 3, 1)]
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('layer', B0_DW, ids=lambda l: 'h{}_c{}_k{}s{}'.format(*l))
+def test_depthwise_adjoint_identities_at_b512(layer, dtype):
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    h, c, k, s = layer
+    bsz = 512
+    td = u.TDT[dtype]
+    gen = torch.Generator(device=u.DEV).manual_seed(h * 100 + c + k)
+    x = torch.randn((bsz, h, h, c), device=u.DEV, generator=gen).to(td)
+    w = (torch.randn((k, k, c), device=u.DEV, generator=gen) / k).float()
+    g = u.dw_geom((bsz, h, h, c), k, s, 'SAME')
+    oh = -(-h // s)
+    y = torch.full((bsz, oh, oh, c), float('nan'), device=u.DEV, dtype=td)
+    dy = torch.randn((bsz, oh, oh, c), device=u.DEV, generator=gen).to(td)
+    dx = torch.full((bsz, h, h, c), float('nan'), device=u.DEV, dtype=td)
+    dw = torch.full((k, k, c), float('nan'), device=u.DEV, dtype=torch.float32)
+    ws = u.workspace(lib.mcn_dwconv2d_workspace_bytes(ctypes.byref(g), u.MDT[dtype]))
+    st = u.stream()
+    _ffi.check(lib.mcn_dwconv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(g), u.MDT[dtype], st))
+    _ffi.check(lib.mcn_dwconv2d_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], st))
+    _ffi.check(lib.mcn_dwconv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ctypes.byref(g), 1.0, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, st))
+    assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all() and torch.isfinite(dw).all()
+    wq = w.to(td).float()
+    lhs = dot64(y, dy)
+    scale = float(y.double().norm().item() * dy.double().norm().item())
+    tol = 2e-5 if dtype == 'float32' else 6e-3
+    assert abs(lhs - dot64(x, dx)) <= tol * scale, ('dgrad adjoint', lhs, dot64(x, dx), scale)
+    # per channel: <y_c, dy_c> = <w_c, dw_c> — a depthwise conv is C independent bilinear forms
+    per_c = (y.double() * dy.double()).sum((0, 1, 2))
+    per_w = (wq.double() * dw.double()).sum((0, 1))
+    cs = torch.sqrt((y.double() ** 2).sum((0, 1, 2)) * (dy.double() ** 2).sum((0, 1, 2)))
+    assert float(((per_c - per_w).abs() / cs).max()) <= tol * 4, ('wgrad adjoint per channel', float(((per_c - per_w).abs() / cs).max()))
