@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                 bits |= (o > 0.f ? 1u : 0u) << i;
                 o = fmaxf(o, 0.f);
             }
-            if (ACT == 2) o = o / (1.f + expf(-o));          // swish = z*sigmoid(z) (convnet.py:2553)
+            if (ACT == 2) o = o * fast_sigmoid(o);          // swish = z*sigmoid(z) (convnet.py:2553)
             v[i] = o;
         }
         stv<T, VEC>(y + off, v);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 
 // ---- backward --------------------------------------------------------------------------------------
 __device__ __forceinline__ float swish_grad(float z) {
-    const float sg = 1.f / (1.f + expf(-z));
+    const float sg = fast_sigmoid(z);
     return sg * (1.f + z * (1.f - sg));
 }
 // part[(rb*2+0)*C + c] = sum dy', part[(rb*2+1)*C + c] = sum dy' * xhat   (dy' = dy*[y>0] if RELU)
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
             float o = fmaf(v[i], sc[i], sh[i]);
             if (SKIP) o += s[i];
             if (ACT == 1) o = fmaxf(o, 0.f);
-            if (ACT == 2) o = o / (1.f + expf(-o));          // swish = z*sigmoid(z) (convnet.py:2553)
+            if (ACT == 2) o = o * fast_sigmoid(o);          // swish = z*sigmoid(z) (convnet.py:2553)
             v[i] = o;
         }
         stv<T, VEC>(y + off, v);

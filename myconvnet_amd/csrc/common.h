@@ -53,6 +53,10 @@ __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
+// sigmoid on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1e-6 relative): the precise expf + IEEE division cost
+// ~30 VALU instructions per element, which made the BN+swish kernels VALU-bound instead of HBM-bound
+__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.f + __expf(-z)); }
+
 // 16-byte chunk <-> fp32 lanes
 template <typename T>
 struct Chunk;
