@@ -162,16 +162,13 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, 
                 const T* row = x + ((n * p.H + iy) * p.W) * p.C + (long)chunk * CE;
                 float seg[L][CE];
 #pragma unroll
-                for (int j = 0; j < L; ++j) {
+                for (int j = 0; j < L; ++j) {                     // clamped address + select: the L loads of the row issue back to back
                     const int ix = ix0 + j;
-                    if ((unsigned)ix < (unsigned)p.W) {
-                        const Chunk<T> c = load_chunk<T>(row + (long)ix * p.C);
+                    const bool ok = (unsigned)ix < (unsigned)p.W;
+                    Chunk<T> c = load_chunk<T>(row + (long)(ok ? ix : 0) * p.C);
+                    if (!ok) c = Chunk<T>{};
 #pragma unroll
-                        for (int i = 0; i < CE; ++i) seg[j][i] = c.get(i);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < CE; ++i) seg[j][i] = 0.f;
-                    }
+                    for (int i = 0; i < CE; ++i) seg[j][i] = c.get(i);
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
