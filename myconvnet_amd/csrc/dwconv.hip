@@ -449,9 +449,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
             float g[S][4];
             const T* drow = dy + ((n * p.OH + oy) * p.OW + ox0) * p.C + (long)grp * 4;
 #pragma unroll
-            for (int j = 0; j < S; ++j) {
-                if (ox0 + j < p.OW) load4<T>(drow + (long)j * p.C, g[j]);
-                else g[j][0] = g[j][1] = g[j][2] = g[j][3] = 0.f;
+            for (int j = 0; j < S; ++j) {                          // clamped address + select (no branch per load)
+                const bool ok = ox0 + j < p.OW;
+                load4<T>(drow + (long)(ok ? j : 0) * p.C, g[j]);
+                if (!ok) g[j][0] = g[j][1] = g[j][2] = g[j][3] = 0.f;
             }
             const int ix0 = ox0 * STRIDE - p.padL;
 #pragma unroll
@@ -463,8 +464,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
 #pragma unroll
                 for (int j = 0; j < L; ++j) {
                     const int ix = ix0 + j;
-                    if ((unsigned)ix < (unsigned)p.W) load4<T>(row + (long)ix * p.C, seg[j]);
-                    else seg[j][0] = seg[j][1] = seg[j][2] = seg[j][3] = 0.f;
+                    const bool ok = (unsigned)ix < (unsigned)p.W;
+                    load4<T>(row + (long)(ok ? ix : 0) * p.C, seg[j]);
+                    if (!ok) seg[j][0] = seg[j][1] = seg[j][2] = seg[j][3] = 0.f;
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx)
