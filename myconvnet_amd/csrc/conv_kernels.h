@@ -531,9 +531,10 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
                 ldA(ic, ok ? a_off[i] + toff : MCN_OOB);
             });
         } else if (MODE == NT_LINEAR) {
-            const int j = ks * 8 + cid;
-            const bool kv = j < p.nchunks;
-            static_for<AR>([&](auto ic) { ldA(ic, kv ? a_off[decltype(ic)::value] + (unsigned)ks * 128u : MCN_OOB); });
+            // K tail as arithmetic (bit 31 = out of range), not as a select: hipcc turned `kv ? off : OOB` into two DMA
+            // instructions under complementary exec masks behind a branch — 12 DMAs and 11 branches per K-step instead of 8 and 0
+            const unsigned oob = ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
+            static_for<AR>([&](auto ic) { ldA(ic, (a_off[decltype(ic)::value] + (unsigned)ks * 128u) | oob); });
         } else {
             const int j = ks * 8 + cid;
             const bool kv = j < p.nchunks;
@@ -547,8 +548,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
                 ldA(ic, ok ? a_off[i] + toff : MCN_OOB);
             });
         }
-        const bool kvb = MODE == NT_UNIFORM || (ks * 8 + cid) < p.nchunks;
-        static_for<BR>([&](auto ic) { ldB(ic, kvb ? b_off[decltype(ic)::value] + (unsigned)ks * 128u : MCN_OOB); });   // OOB + small stays OOB
+        const unsigned oobb = MODE == NT_UNIFORM ? 0u : ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
+        static_for<BR>([&](auto ic) { ldB(ic, (b_off[decltype(ic)::value] + (unsigned)ks * 128u) | oobb); });   // OOB + small stays OOB
     };
     typename MM::Acc acc[TN][TM];
 #pragma unroll
