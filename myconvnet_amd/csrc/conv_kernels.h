@@ -757,6 +757,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
     const int dn = n0 + dcc * CE;
     const bool dcol_ok = dn < p.Nn;
 
+    const unsigned xoob = xcol_ok ? 0u : MCN_OOB, doob = dcol_ok ? 0u : MCN_OOB;       // loop-invariant column masks
     static_assert(XPR * XRS == 4096 && DPR * DRS == 4096, "one staging pass of the workgroup = 4 KiB of LDS");
     __attribute__((address_space(3))) char* const wbase =
         (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
@@ -765,13 +766,15 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
         static_for<XN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + xpr + XPR * i;
-            unsigned off = MCN_OOB;
+            // out-of-range as arithmetic on bit 31 (sign bits of the range tests), not as `if (ok) off = ...`: hipcc turns that
+            // select into two DMA instructions under complementary exec masks behind a branch (8-12 branches per K-step)
+            unsigned off;
             if (LINEAR) {
-                if (xcol_ok && m < p.M) off = ((unsigned)m * (unsigned)p.Cs + (unsigned)xc) * (unsigned)sizeof(T);
+                off = (((unsigned)m * (unsigned)p.Cs + (unsigned)xc) * (unsigned)sizeof(T)) | xoob | (((unsigned)(p.M - 1 - m) >> 31) << 31);
             } else {
                 const int iy = py[i] * p.sy + tdy, ix = px[i] * p.sx + tdx;
-                if (xcol_ok && m < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
-                    off = ((unsigned)((pimg[i] * p.IH + iy) * p.IW + ix) * (unsigned)p.Cs + (unsigned)xc) * (unsigned)sizeof(T);
+                const unsigned bad = (unsigned)(p.M - 1 - m) | (unsigned)iy | (unsigned)(p.IH - 1 - iy) | (unsigned)ix | (unsigned)(p.IW - 1 - ix);
+                off = (((unsigned)((pimg[i] * p.IH + iy) * p.IW + ix) * (unsigned)p.Cs + (unsigned)xc) * (unsigned)sizeof(T)) | xoob | ((bad >> 31) << 31);
                 // advance this row's pixel coordinates by KP for the next step
                 px[i] += dKx;
                 if (px[i] >= p.OW) { px[i] -= p.OW; py[i] += 1; }
@@ -784,8 +787,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
         static_for<DN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + dpr + DPR * i;
-            unsigned off = MCN_OOB;
-            if (dcol_ok && m < p.M) off = ((unsigned)m * (unsigned)p.ldy + (unsigned)dn) * (unsigned)sizeof(T);
+            const unsigned off = (((unsigned)m * (unsigned)p.ldy + (unsigned)dn) * (unsigned)sizeof(T)) | doob | (((unsigned)(p.M - 1 - m) >> 31) << 31);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + XBYTES + i * 4096)), 16, (int)off, 0, 0, 0);
         });
     };
