@@ -48,15 +48,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 0; }
         for (int kr = 0; kr < p.KH; ++kr) {
             const int iy = oy * p.SH + kr - p.padT;
-            if (iy < 0 || iy >= p.H) continue;
+            const bool yok = (unsigned)iy < (unsigned)p.H;
             for (int ks = 0; ks < p.KW; ++ks) {
                 const int ix = ox * p.SW + ks - p.padL;
-                if (ix < 0 || ix >= p.W) continue;
+                const bool ok = yok && (unsigned)ix < (unsigned)p.W;     // clamped address + select: no branch per load
                 float v[VEC];
-                pld<T, VEC>(x + (((long)n * p.H + iy) * p.W + ix) * p.C + c, v);
+                pld<T, VEC>(x + (((long)n * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * p.C + c, v);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    if (v[i] > best[i]) { best[i] = v[i]; bi[i] = kr * p.KW + ks; }   // strict '>' : first maximum wins
+                    if (ok && v[i] > best[i]) { best[i] = v[i]; bi[i] = kr * p.KW + ks; }   // strict '>' : first maximum wins
             }
         }
         const long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
@@ -86,6 +86,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        if constexpr (KK == 3 && SS == 2) {
+            // an input pixel is seen by at most 2 x 2 outputs: (oy0, kr0) and (oy0 - 1, kr0 + 2) per axis; clamped loads + masks
+            const int ty0 = iy + p.padT, tx0 = ix + p.padL;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int oy = (ty0 >> 1) - a, kr = (ty0 & 1) + 2 * a;
+                const bool yok = kr < 3 && (unsigned)oy < (unsigned)p.OH;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int ox = (tx0 >> 1) - b, ks = (tx0 & 1) + 2 * b;
+                    const bool ok = yok && ks < 3 && (unsigned)ox < (unsigned)p.OW;
+                    const long o = (((long)n * p.OH + (ok ? oy : 0)) * p.OW + (ok ? ox : 0)) * p.C + c;
+                    float g[VEC];
+                    pld<T, VEC>(dy + o, g);
+                    signed char ac[VEC];
+                    if constexpr (VEC == 8) *reinterpret_cast<unsigned long long*>(ac) = *reinterpret_cast<const unsigned long long*>(arg + o);
+                    else if constexpr (VEC == 4) *reinterpret_cast<unsigned*>(ac) = *reinterpret_cast<const unsigned*>(arg + o);
+                    else ac[0] = arg[o];
+                    const int code = ok ? kr * 3 + ks : -1;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (ac[i] == code) acc[i] += g[i];
+                }
+            }
+            pst<T, VEC>(dx + (((long)n * p.H + iy) * p.W + ix) * p.C + c, acc);
+            continue;
+        }
 #pragma unroll
         for (int kr = 0; kr < KH; ++kr) {
             const int ty = iy + p.padT - kr;
