@@ -59,6 +59,27 @@ static ColLayout make_layout(long M, int C, int vec, int target_blocks) {
     return L;
 }
 
+// VEC per-channel fp32 parameters starting at p (16-byte aligned when VEC % 4 == 0: one or two 16-byte loads, not VEC dwords);
+// dflt when p is null
+template <int VEC>
+__device__ __forceinline__ void ldc(const float* __restrict__ p, float (&o)[VEC], float dflt = 0.f) {
+    if (!p) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = dflt;
+        return;
+    }
+    if constexpr (VEC % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+            o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = p[i];
+    }
+}
+
 // ---- forward statistics --------------------------------------------------------------------------
 // part[(rb*2 + {0,1})*C + c] = sum over the block's rows of (x - pivot), (x - pivot)^2
 template <typename T, int VEC>
@@ -196,11 +217,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const int col = blockIdx.x * TX + tx;
     if (ty >= TY || col * VEC >= C) return;
     float sc[VEC], sh[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        sc[i] = scale[col * VEC + i];
-        sh[i] = shift[col * VEC + i];
-    }
+    ldc<VEC>(scale + col * VEC, sc);
+    ldc<VEC>(shift + col * VEC, sh);
     const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
     for (long r = r0 + ty; r < r1; r += TY) {
         const long off = r * C + (long)col * VEC;
@@ -252,13 +270,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
     if (active) {
         float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+        ldc<VEC>(mean + col * VEC, mu);
+        ldc<VEC>(invstd + col * VEC, is);
+        if (RELU >= 2) {
+            ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+            ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            mu[i] = mean[col * VEC + i];
-            is[i] = invstd[col * VEC + i];
-            if (RELU >= 2) {
-                sc[i] = (gamma ? gamma[col * VEC + i] : 1.f) * is[i];
-                sh[i] = (beta ? beta[col * VEC + i] : 0.f) - mu[i] * sc[i];
+            for (int i = 0; i < VEC; ++i) {
+                sc[i] *= is[i];
+                sh[i] -= mu[i] * sc[i];
             }
         }
         const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
@@ -357,16 +377,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int col = blockIdx.x * TX + tx;
     if (ty >= TY || col * VEC >= C) return;
     float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
+    ldc<VEC>(mean + col * VEC, mu);
+    ldc<VEC>(invstd + col * VEC, is);
+    ldc<VEC>(coef + col * VEC, ca);
+    ldc<VEC>(coef + C + col * VEC, cb);
+    ldc<VEC>(coef + 2 * C + col * VEC, cc);
+    if (RELU >= 2) {
+        ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+        ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        mu[i] = mean[col * VEC + i];
-        is[i] = invstd[col * VEC + i];
-        ca[i] = coef[col * VEC + i];
-        cb[i] = coef[C + col * VEC + i];
-        cc[i] = coef[2 * C + col * VEC + i];
-        if (RELU >= 2) {
-            sc[i] = (gamma ? gamma[col * VEC + i] : 1.f) * is[i];
-            sh[i] = (beta ? beta[col * VEC + i] : 0.f) - mu[i] * sc[i];
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] *= is[i];
+            sh[i] -= mu[i] * sc[i];
         }
     }
     const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
