@@ -327,7 +327,7 @@ def main():
         out['roofline']['algorithmic_bytes_per_launch'] = int(alg_bytes / cnt)
         out['roofline'].update(pmc_traffic(name, args.dtype, args.batch))
         tot = sum(v[1] for v in table.values())
-        out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:12]}
+        out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 12)]}
         out['kernel_ms_total'] = round(tot, 3)
         conv_ms = sum(v[1] for v in convs.values())
         conv_flop = sum(v[2] for v in convs.values())

@@ -985,22 +985,47 @@ __global__ void pack_weights_kernel(const PackParams p) {
 
 // all packed operands of a model in ONE launch: blockIdx.y selects the descriptor (device table), blockIdx.x strides
 template <typename T>
-__global__ void pack_weights_batch_kernel(const PackParams* __restrict__ table) {
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackParams* __restrict__ table) {
     const PackParams& p = table[blockIdx.y];
     const long total = (long)p.rows * p.ntaps * p.Cp;
     T* out = reinterpret_cast<T*>(p.out);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int col = (int)(idx % p.Cp);
-        const long rt = idx / p.Cp;
-        const int t = (int)(rt % p.ntaps), row = (int)(rt / p.ntaps);
-        const int r = p.tr[t], s = p.ts[t];
-        float v = 0.f;
-        if (p.mode == 0) {
-            if (col < p.Cin) v = p.w[(((long)r * p.KW + s) * p.Cin + col) * p.Cout + row];
-        } else {
-            if (col < p.Cout) v = p.w[(((long)r * p.KW + s) * p.Cin + row) * p.Cout + col];
+    if (p.mode == 0) {
+        // forward operand = per-tap TRANSPOSE of the HWIO filter ([cout][tap][cin] from [tap][cin][cout]): 32x32 tiles through
+        // LDS so that both the fp32 reads (along cout) and the packed writes (along cin) are coalesced — the element-wise form
+        // below reads with a stride of Cout floats and took 260 us per step for ResNet-50's 25 M weights
+        __shared__ float tile[32][33];
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+        const int nci = (p.Cp + 31) / 32, nco = (p.rows + 31) / 32;
+        const int njobs = p.ntaps * nci * nco;
+        for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+            const int co0 = (job % nco) * 32;
+            const int rest = job / nco;
+            const int ci0 = (rest % nci) * 32, t = rest / nci;
+            const long wbase = ((long)p.tr[t] * p.KW + p.ts[t]) * p.Cin;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+                tile[ty + 8 * k][tx] = (ci < p.Cin && co < p.rows) ? p.w[(wbase + ci) * p.Cout + co] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+                if (co < p.rows && ci < p.Cp) out[((long)co * p.ntaps + t) * p.Cp + ci] = from_f32<T>(tile[tx][ty + 8 * k]);
+            }
+            __syncthreads();
         }
-        out[idx] = from_f32<T>(v);
+        return;
+    }
+    // dgrad operand ([cin][tap][cout]): every (cin, tap) row is a contiguous run of Cout weights — one job per row, no
+    // per-element 64-bit division
+    (void)total;
+    const int njobs = p.rows * p.ntaps;
+    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const int row = job / p.ntaps, t = job - row * p.ntaps;
+        const float* src = p.w + (((long)p.tr[t] * p.KW + p.ts[t]) * p.Cin + row) * p.Cout;
+        T* dst = out + (long)job * p.Cp;
+        for (int col = threadIdx.x; col < p.Cp; col += 256) dst[col] = from_f32<T>(col < p.Cout ? src[col] : 0.f);
     }
 }
 
