@@ -150,9 +150,21 @@ template <typename T, bool NCHW>
 __global__ __launch_bounds__(256) void input_prep_kernel(const float* __restrict__ x, T* __restrict__ y, long npix, int HW, int C, int out_cs,
                                                          float mean, float scale) {
     const long stride = (long)gridDim.x * blockDim.x;
+    constexpr int CE = (int)(16 / sizeof(T));
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
         T* o = y + p * out_cs;
         const long n = p / HW, r = p - n * HW;
+        if (out_cs == CE) {                                  // the padded pixel is one 16-byte chunk: one store, not out_cs
+            Chunk<T> ch;
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                float v = 0.f;
+                if (c < C) v = ((NCHW ? x[(n * C + c) * HW + r] : x[p * C + c]) - mean) * scale;
+                ch.set(c, v);
+            }
+            store_chunk<T>(o, ch);
+            continue;
+        }
         for (int c = 0; c < out_cs; ++c) {
             float v = 0.f;
             if (c < C) {
