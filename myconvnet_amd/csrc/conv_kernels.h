@@ -542,10 +542,12 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
             const int cc = j - tap * p.cpt;
             const int dy = s_tdy[tap], dx = s_tdx[tap];
             const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + (cc - cid) * 16);
+            const unsigned kbad = (unsigned)(p.nchunks - 1 - j);              // sign bit: past the end of K
             static_for<AR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                const bool ok = kv && (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
-                ldA(ic, ok ? a_off[i] + toff : MCN_OOB);
+                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                const unsigned bad = kbad | (unsigned)yy | (unsigned)(p.IH - 1 - yy) | (unsigned)xx | (unsigned)(p.IW - 1 - xx);
+                ldA(ic, (a_off[i] + toff) | ((bad >> 31) << 31));                // (arithmetic, not a select: see NT_LINEAR)
             });
         }
         const unsigned oobb = MODE == NT_UNIFORM ? 0u : ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
