@@ -96,7 +96,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         float piv[VEC];
         ldv<T, VEC>(x + (long)col * VEC, piv);
         const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
-        for (long r = r0 + ty; r < r1; r += TY) {
+        constexpr int U = 4;                  // rows per trip, loads first (one 16-byte load in flight per thread is latency bound)
+        long r = r0 + ty;
+        for (; r + (long)(U - 1) * TY < r1; r += (long)U * TY) {
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ldv<T, VEC>(x + (r + (long)u * TY) * C + (long)col * VEC, v[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float d = v[u][i] - piv[i];
+                    s1[i] += d;
+                    s2[i] = fmaf(d, d, s2[i]);
+                }
+        }
+        for (; r < r1; r += TY) {
             float v[VEC];
             ldv<T, VEC>(x + r * C + (long)col * VEC, v);
 #pragma unroll
