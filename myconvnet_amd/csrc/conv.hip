@@ -125,7 +125,10 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
     int BR, BN;
     tn_tile(rows, g.Cout, dt, conv_is_linear(g), g.tile, &BR, &BN);
     const int tiles = ((rows + BR - 1) / BR) * ((g.Cout + BN - 1) / BN);
-    int splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU in total
+    // workgroups in total: ~4 per CU in fp32; bf16 (2-3 resident per CU, HBM-side bound) prefers fewer, longer splits — same-box
+    // A/B of the whole step: 1536 / 1024 / 768 -> fp32 73.1 / 72.5 / 73.2 ms, bf16 25.6 / 25.4 / 25.1 ms; 512 / 256 -> bf16 24.95 / 25.2 ms
+    const int target = dt == MCN_F32 ? 1024 : 512;
+    int splits = (target + tiles - 1) / tiles;
     if (splits > nsteps) splits = nsteps;
     if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
