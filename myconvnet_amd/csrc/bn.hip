@@ -430,7 +430,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // ---- host ------------------------------------------------------------------------------------------
-#define BN_TARGET_BLOCKS 1024
+#define BN_TARGET_BLOCKS 1024       /* upper bound of the row blocks (workspace sizing) */
+// row blocks per kernel by element size (same-box A/B of the whole ResNet-50 step: fp32 1024 > 768 > 2048; bf16 768 > 512 ~ 1024)
+#define BN_TGT_BF16 768
+template <typename T>
+static constexpr int bn_target() { return sizeof(T) == 2 ? BN_TGT_BF16 : 1024; }
 static size_t bn_parts_bytes(long M, int C) {
     // worst case over vector widths: gy <= BN_TARGET_BLOCKS
     return align_up((size_t)BN_TARGET_BLOCKS * 2 * C * sizeof(float), 256);
@@ -444,7 +448,7 @@ template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* skip, void* y, unsigned char* relu_mask, float* save_mean,
                           float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
                           float momentum, long M, int C, float eps, mcn_act act, void* ws, hipStream_t st) {
-    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     float* part = (float*)ws;
     float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
     float* shift = scale + C;
@@ -545,7 +549,7 @@ template <typename T, int VEC>
 static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp, const float* gamma, const float* beta, const void* skip, void* y,
                           unsigned char* relu_mask, float* save_mean, float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
                           float momentum, long M, int C, float eps, mcn_act act, void* ws, hipStream_t st) {
-    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     double* fold = (double*)ws;                                  // BN_FOLD_ROWS*2*C doubles fit the partial area of the workspace
     float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
     float* shift = scale + C;
@@ -615,7 +619,7 @@ extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* 
 
 template <typename T, int VEC>
 static int channel_affine_t(const void* x, const float* scale, const float* shift, void* y, long M, int C, hipStream_t st) {
-    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     const dim3 grid(L.gx, L.gy), block(256);
     const void* skip = nullptr;
     unsigned char* relu_mask = nullptr;
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
 template <typename T, int VEC>
 static int bn_infer_t(const void* x, const float* gamma, const float* beta, const float* mean, const float* var, const void* skip, void* y,
                       long M, int C, float eps, mcn_act act, hipStream_t st) {
-    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     const dim3 grid(L.gx, L.gy), block(256);
     const int a = (int)act;
 #define BN_INFER(SK, RL)                                                                                                     \
@@ -698,7 +702,7 @@ template <typename T, int VEC>
 static int bn_bwd_t(const void* dy, const void* x, const void* y_in, const unsigned char* relu_mask, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, void* dx, void* dskip, float* dgamma, float* dbeta, float grad_scale, long M, int C, mcn_act act,
                     void* ws, hipStream_t st, bool frozen = false) {
-    const ColLayout L = make_layout(M, C, VEC, BN_TARGET_BLOCKS);
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
     const dim3 grid(L.gx, L.gy), block(256);
