@@ -269,6 +269,9 @@ int mcn_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, i
 /* tf.reduce_mean(x, axis=[1,2]) (models/resnet_v1_5.py:72-73): [N][HW][C] -> [N][C] */
 int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream);
 int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream);
+/* dx += broadcast(dy) / HW: the pooled branch's contribution when dx already holds another one (the input of a
+ * squeeze-excite block feeds both the pool and the channel scale, models/efficientnet.py:179-197) */
+int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream);
 
 /* ---- fully connected ----------------------------------------------------------------------
  * tf.matmul(x, W) + b (convnet.py:1743): x:[B][In], w:[In][Out] fp32 master, y:[B][Out]. */

@@ -86,6 +86,7 @@ SIGNATURES = {
     'mcn_avgpool_bwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 12 + [c_int, c_void_p]),
     'mcn_global_avgpool_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'mcn_global_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'mcn_global_avgpool_bwd_acc': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'mcn_fc_workspace_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int]),
     'mcn_fc_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_fc_bwd': (c_int, [c_void_p] * 6 + [c_float, c_int32, c_int32, c_int32, c_int, c_void_p, c_size_t, c_void_p]),

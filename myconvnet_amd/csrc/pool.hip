@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T
         pst<T, VEC>(y + n * C + (long)chunk * VEC, acc);
     }
 }
-template <typename T, int VEC>
+template <typename T, int VEC, bool ACC = false>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int HW, int C) {
     const int cv = C / VEC;
     const long total = (long)N * HW * cv;
@@ -270,6 +270,12 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const T* __restrict__ dy, 
         pld<T, VEC>(dy + n * C + c, g);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) g[i] *= inv;
+        if (ACC) {                                               // dx += : the second gradient contribution of an SE block's input
+            float o[VEC];
+            pld<T, VEC>(dx + pq * C + c, o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) g[i] += o[i];
+        }
         pst<T, VEC>(dx + pq * C + c, g);
     }
 }
@@ -394,6 +400,21 @@ extern "C" int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t
         if (C % 8 == 0) GAP_FWD(bf16_t, 8); else GAP_FWD(bf16_t, 1);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_fwd: dtype %d unsupported", (int)dtype);
 #undef GAP_FWD
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream) {
+    if (!dy || !dx || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "global_avgpool_bwd_acc: bad argument");
+    if (N == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * HW * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((gap_bwd_kernel<float, 4, true>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, (float*)dx, N, HW, C);
+        else hipLaunchKernelGGL((gap_bwd_kernel<float, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, N, HW, C);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+        else hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_bwd_acc: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }

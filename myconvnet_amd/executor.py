@@ -603,7 +603,9 @@ class Lowering(object):
     def bwd_gap(self, n):
         x, y = n.inputs[0], n.outputs[0]
         N, H, W, C = x.shape
-        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_global_avgpool_bwd, y.grad.data_ptr(), dst, N, H * W, C, MCN_DT[x.dtype]))
+        # (accumulating form when x.grad already holds the channel-scale branch's contribution: no scratch tensor + add pass)
+        self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_global_avgpool_bwd_acc if acc else lib.mcn_global_avgpool_bwd, y.grad.data_ptr(), dst,
+                                                         N, H * W, C, MCN_DT[x.dtype]))
 
     # ---- fc -------------------------------------------------------------------------------------------------------------------
     def fwd_fc(self, n):
