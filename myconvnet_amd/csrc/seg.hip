@@ -120,6 +120,35 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// Channel counts that are no chunk multiple (class-logit maps, C = num_classes <= 32): one thread per PIXEL with the
+// channels in an inner loop — the coordinate arithmetic runs once per pixel instead of once per element, with 32-bit indices
+// (forward: 0.41 -> 0.17 ms on the 513x513x19 logits; the same form of the gather backward has too few threads: 1.6 ms, not kept)
+#define MCN_RESIZE_PIX_MAXC 32
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_pix_kernel(const T* __restrict__ x, T* __restrict__ y, const ResizeParams p) {
+    const unsigned total = (unsigned)((long)p.N * p.OH * p.OW);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned q = i / (unsigned)p.OW;
+        const int ox = (int)(i - q * (unsigned)p.OW);
+        const unsigned n = q / (unsigned)p.OH;
+        const int oy = (int)(q - n * (unsigned)p.OH);
+        int ylo, yhi, xlo, xhi;
+        float fy, fx;
+        rs_coord(oy, p.sy, p.align, p.H, ylo, yhi, fy);
+        rs_coord(ox, p.sx, p.align, p.W, xlo, xhi, fx);
+        const T* base = x + (long)n * p.H * p.W * p.C;
+        const T* a = base + ((long)ylo * p.W + xlo) * p.C;
+        const T* b = base + ((long)ylo * p.W + xhi) * p.C;
+        const T* c = base + ((long)yhi * p.W + xlo) * p.C;
+        const T* d = base + ((long)yhi * p.W + xhi) * p.C;
+        T* o = y + (long)i * p.C;
+        for (int k = 0; k < p.C; ++k) {
+            const float top = to_f32(a[k]) * (1.f - fx) + to_f32(b[k]) * fx;
+            const float bot = to_f32(c[k]) * (1.f - fx) + to_f32(d[k]) * fx;
+            o[k] = from_f32<T>(top * (1.f - fy) + bot * fy);
+        }
+    }
+}
 static int resize_setup(const void* a, const void* b, int N, int H, int W, int C, int OH, int OW, int align, mcn_dtype dt, ResizeParams* p, const char* nm) {
     if (!a || !b || N < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) MCN_FAIL(MCN_E_BADARG, "%s: bad argument", nm);
     if (dt != MCN_F32 && dt != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", nm, (int)dt);
@@ -146,6 +175,13 @@ extern "C" int mcn_resize_bilinear_fwd(const void* x, void* y, int32_t N, int32_
     const long total = (long)N * OH * OW * (C / ce);
     if (total == 0) return MCN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (ce == 1 && C <= MCN_RESIZE_PIX_MAXC && (long)N * OH * OW < 0x7fffffffL) {
+        const long npix = (long)N * OH * OW;
+        if (dtype == MCN_F32) hipLaunchKernelGGL((resize_fwd_pix_kernel<float>), dim3(seg_blocks(npix)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+        else hipLaunchKernelGGL((resize_fwd_pix_kernel<bf16_t>), dim3(seg_blocks(npix)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
     if (dtype == MCN_F32) {
         if (ce == 4) hipLaunchKernelGGL((resize_fwd_kernel<float, 4>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
         else hipLaunchKernelGGL((resize_fwd_kernel<float, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
