@@ -78,15 +78,15 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x
 // own arithmetic so that rounding can not drop or duplicate a term.
 template <typename T, int CE>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, const ResizeParams p, float isy, float isx) {
-    const int cch = p.C / CE;
-    const long total = (long)p.N * p.H * p.W * cch;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i % cch);
-        long q = i / cch;
-        const int ix = (int)(q % p.W);
-        q /= p.W;
-        const int iy = (int)(q % p.H);
-        const long n = q / p.H;
+    const unsigned cch = (unsigned)(p.C / CE);
+    const unsigned total = (unsigned)((long)p.N * p.H * p.W * cch);          // (host: < 2^32; 64-bit divisions cost more than the taps)
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        unsigned q = i / cch;
+        const int ch = (int)(i - q * cch);
+        const unsigned q2 = q / (unsigned)p.W;
+        const int ix = (int)(q - q2 * (unsigned)p.W);
+        const long n = q2 / (unsigned)p.H;
+        const int iy = (int)(q2 - (unsigned)n * (unsigned)p.H);
         // outputs with src in (i-1, i+1); one candidate of slack on both sides
         int oy0 = (int)floorf(((float)iy - 1.f) * isy) - 1, oy1 = (int)ceilf(((float)iy + 1.f) * isy) + 1;
         int ox0 = (int)floorf(((float)ix - 1.f) * isx) - 1, ox1 = (int)ceilf(((float)ix + 1.f) * isx) + 1;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
                 for (int k = 0; k < CE; ++k) acc[k] = fmaf(g[k], w, acc[k]);
             }
         }
-        stvec<T, CE>(dx + i * CE, acc);
+        stvec<T, CE>(dx + (long)i * CE, acc);
     }
 }
 
@@ -199,6 +199,7 @@ extern "C" int mcn_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
     const int ce = C % (dtype == MCN_F32 ? 4 : 8) ? 1 : (dtype == MCN_F32 ? 4 : 8);
     const long total = (long)N * H * W * (C / ce);
     if (total == 0) return MCN_OK;
+    if (total >= 0xffffffffL) MCN_FAIL(MCN_E_UNSUPPORTED, "resize_bilinear_bwd: more than 2^32 elements");
     hipStream_t st = (hipStream_t)stream;
     // inverse steps; a zero forward step (single output row / column) means every output maps to input 0
     const float isy = p.sy > 0.f ? 1.f / p.sy : (float)OH, isx = p.sx > 0.f ? 1.f / p.sx : (float)OW;
