@@ -618,12 +618,31 @@ __global__ __launch_bounds__(256) void dw_wgrad_tap_kernel(const T* __restrict__
     }
 }
 
+// slab fold: E elements x 256/E slab lanes per block (a thread per element walking all slabs alone took 270 us on average for
+// the 600-2000 slabs x 300-29000 elements of EfficientNet-B0: more than the wgrad kernel itself); fixed summation order, double.
+template <int E>
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int slabs, float scale) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < slabs; ++b) s += (double)part[(long)b * n + i];
-    dw[i] = (float)s * scale;
+    constexpr int L = 256 / E;
+    __shared__ double red[256];
+    const int e = threadIdx.x % E, l = threadIdx.x / E;
+    const long i = (long)blockIdx.x * E + e;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < n) {
+        int b = l;
+        for (; b + 3 * L < slabs; b += 4 * L) {
+            const float v0 = part[(long)b * n + i], v1 = part[(long)(b + L) * n + i], v2 = part[(long)(b + 2 * L) * n + i], v3 = part[(long)(b + 3 * L) * n + i];
+            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        }
+        for (; b < slabs; b += L) s0 += (double)part[(long)b * n + i];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (l == 0 && i < n) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) s += red[k * E + e];
+        dw[i] = (float)s * scale;
+    }
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
@@ -806,7 +825,9 @@ static int dw_wgrad_t(const void* x, const void* dy, float* dw, const mcn_conv_g
     else if (p.KH == 5 && p.KW == 5) hipLaunchKernelGGL((dw_wgrad_kernel<T, 5>), dim3(gx, gy), block, lds, st, (const T*)x, (const T*)dy, part, p);
     else hipLaunchKernelGGL((dw_wgrad_tap_kernel<T>), dim3(gx, gy, p.KH * p.KW), block, lds, st, (const T*)x, (const T*)dy, part, p);
     MCN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, (const float*)part, dw, n, (int)gy, scale);
+    if (gy >= 64 && n <= 8192) hipLaunchKernelGGL(dw_wgrad_reduce_kernel<8>, dim3((unsigned)((n + 7) / 8)), block, 0, st, (const float*)part, dw, n, (int)gy, scale);
+    else if (gy >= 16) hipLaunchKernelGGL(dw_wgrad_reduce_kernel<32>, dim3((unsigned)((n + 31) / 32)), block, 0, st, (const float*)part, dw, n, (int)gy, scale);
+    else hipLaunchKernelGGL(dw_wgrad_reduce_kernel<256>, dim3((unsigned)((n + 255) / 256)), block, 0, st, (const float*)part, dw, n, (int)gy, scale);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
