@@ -90,9 +90,10 @@ static size_t skinny_in_w_bytes(const Geo& g) { return align_up((size_t)g.Cout *
 #define MCN_SKINNY_MAX_CO 32        /* fwd / dgrad: accumulators per thread */
 #define MCN_SKINNY_MAX_CO_WGRAD 24  /* wgrad: [chunk elements][CO] accumulators per thread */
 static size_t skinny_w_bytes(const Geo& g) { return align_up((size_t)g.Cin * skinny_co(g) * sizeof(float), 256); }
-static long skinny_wgrad_slab(long M) {                  // pixels per slab: 256 threads x >= 32 pixels, at most 256 slabs
-    long slab = 256 * 32;
-    while ((M + slab - 1) / slab > 256) slab *= 2;
+static long skinny_wgrad_slab(long M, int chunks) {      // pixels per slab: a multiple of the 32 pixel lanes, at most 256 slabs and ~2048 workgroups
+    const long gx = (chunks + 7) / 8;
+    long slab = 32;
+    while ((M + slab - 1) / slab > 256 || (M + slab - 1) / slab * gx > 2048) slab *= 2;
     return slab;
 }
 
@@ -141,8 +142,8 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
     return splits;
 }
 static size_t colsum_parts(long M) {
-    long parts = (M + 511) / 512;
-    if (parts > 256) parts = 256;
+    long parts = (M + 15) / 16;
+    if (parts > 1024) parts = 1024;
     if (parts < 1) parts = 1;
     return (size_t)parts;
 }
@@ -159,7 +160,11 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     size_t b = 0;
     if (!mfma_path_ok(g, dt)) {
         const long M = (long)g.N * g.OH * g.OW;
-        const int sl = (skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD) || skinny_in_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) ? (int)((M + skinny_wgrad_slab(M) - 1) / skinny_wgrad_slab(M)) + 1 : naive_wgrad_slices(g);
+        int sl = naive_wgrad_slices(g);
+        if (skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD) || skinny_in_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) {
+            const long slab = skinny_wgrad_slab(M, (skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD) ? g.Cin : g.Cout) / ce_of(dt));
+            sl = (int)((M + slab - 1) / slab) + 1;
+        }
         if (sl > 1) b += align_up((size_t)sl * g.KH * g.KW * g.Cin * g.Cout * 4, 256);
     }
     if (mfma_path_ok(g, dt)) {
@@ -637,10 +642,12 @@ static int colsum_t(const void* x, float* out, long M, int C, float scale, void*
     const int parts = (int)colsum_parts(M);
     const int rpb = (int)((M + parts - 1) / parts);
     float* part = (float*)ws;
-    const dim3 grid((C + 255) / 256, parts);
-    hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, st, (const T*)x, part, M, C, rpb);
+    int TX = 8;
+    while (TX < C && TX < 256) TX *= 2;
+    const dim3 grid((C + TX - 1) / TX, parts);
+    hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, st, (const T*)x, part, M, C, rpb, TX);
     MCN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part, out, parts, C, scale);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)part, out, parts, C, scale);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -654,30 +661,30 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
     char* wsp = (char*)ws;
     if (!mfma_path_ok(g, dt) && skinny_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) {
         const int CO = skinny_co(g), ce = ce_of(dt);
-        const long slab = skinny_wgrad_slab(M), total = (long)g.Cin * g.Cout;
+        const long slab = skinny_wgrad_slab(M, g.Cin / ce), total = (long)g.Cin * g.Cout;
         const int slabs = (int)((M + slab - 1) / slab);
         float* part = (float*)wsp;
         wsp += align_up((size_t)(slabs + 1) * total * 4, 256);
-        const dim3 grid(g.Cin / ce, slabs);
+        const dim3 grid((g.Cin / ce + 7) / 8, slabs);
 #define MCN_SKINNY_WGRAD(COV) hipLaunchKernelGGL((skinny_conv_wgrad<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, part, M, g.Cin, g.Cout, slab, 0)
         if (CO == 8) MCN_SKINNY_WGRAD(8); else if (CO == 16) MCN_SKINNY_WGRAD(16); else MCN_SKINNY_WGRAD(24);
 #undef MCN_SKINNY_WGRAD
         MCN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
+        hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
         MCN_CHECK_LAUNCH();
     } else if (!mfma_path_ok(g, dt) && skinny_in_ok(g, dt, MCN_SKINNY_MAX_CO_WGRAD)) {
         // few input channels: the same kernel with the operands swapped (dy is the chunked one), partials stored transposed
         const int CO = skinny_ci(g), ce = ce_of(dt);
-        const long slab = skinny_wgrad_slab(M), total = (long)g.Cin * g.Cout;
+        const long slab = skinny_wgrad_slab(M, g.Cout / ce), total = (long)g.Cin * g.Cout;
         const int slabs = (int)((M + slab - 1) / slab);
         float* part = (float*)wsp;
         wsp += align_up((size_t)(slabs + 1) * total * 4, 256);
-        const dim3 grid(g.Cout / ce, slabs);
+        const dim3 grid((g.Cout / ce + 7) / 8, slabs);
 #define MCN_SKINNY_WGRAD_IN(COV) hipLaunchKernelGGL((skinny_conv_wgrad<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const T*)x, part, M, g.Cout, g.Cin, slab, 1)
         if (CO == 8) MCN_SKINNY_WGRAD_IN(8); else if (CO == 16) MCN_SKINNY_WGRAD_IN(16); else MCN_SKINNY_WGRAD_IN(24);
 #undef MCN_SKINNY_WGRAD_IN
         MCN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
+        hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)part, dw, total, slabs, scale);
         MCN_CHECK_LAUNCH();
     } else if (!mfma_path_ok(g, dt)) {
         NaiveConvParams p = naive_params(g);
@@ -689,7 +696,7 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         hipLaunchKernelGGL((naive_conv_wgrad<T>), dim3(nblocks(total * 8), sl), dim3(256), 0, st, p, part);
         MCN_CHECK_LAUNCH();
         if (sl > 1) {
-            hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dw, total, sl, scale);
+            hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)part, dw, total, sl, scale);
             MCN_CHECK_LAUNCH();
         }
     } else {

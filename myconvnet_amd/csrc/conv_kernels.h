@@ -1151,12 +1151,22 @@ __global__ __launch_bounds__(256) void naive_conv_wgrad(const NaiveConvParams p,
         __syncthreads();
     }
 }
+// 32 elements x 8 slice lanes per block, fixed order
 __global__ __launch_bounds__(256) void naive_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long total, int slices, float scale) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    __shared__ float red[256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(long)k * total + i];
-    dw[i] = s * scale;
+    if (i < total)
+        for (int k = ty; k < slices; k += 8) s += part[(long)k * total + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + tx];
+        dw[i] = t * scale;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,34 +1239,59 @@ __global__ __launch_bounds__(256) void skinny_conv_dgrad(const T* __restrict__ d
         }
     }
 }
-// dw[c][n] = sum_pixels x[pixel][c] * dy[pixel][n]: blockIdx.x = channel chunk, blockIdx.y = pixel slab; per-thread
-// accumulators [CE][CO], folded over the wave by shuffles and over the block's waves through LDS; slab partials are summed
-// in a fixed order by naive_wgrad_reduce (deterministic).
+// dw[c][n] = sum_pixels x[pixel][c] * dy[pixel][n].  blockIdx.x = group of 8 channel chunks, blockIdx.y = pixel slab.  Lanes
+// 0-7 of every 8 hold the 8 chunks of ONE pixel (a 128-byte line of x per 8 lanes: the earlier one-chunk-per-block form
+// fetched every line of x 8 times and read dy with 2-byte loads 42 bytes apart, 478 us for the 129x129 class-logit conv);
+// the dy rows of 256 pixels are staged through LDS as zero-padded fp32 [pixel][CO] with coalesced loads and read back as
+// 16-byte broadcasts.  Per-thread accumulators [CE][CO], folded over the 8 pixel lanes of a wave by shuffles and over the
+// block's waves through LDS; slab partials are summed in a fixed order by naive_wgrad_reduce (deterministic).
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void skinny_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, long M, int Cin,
                                                          int Cout, long slab, int transposed) {
     constexpr int CE = VecTraits<T>::CE;
-    __shared__ float red[4][CE * CO];
-    const int ch = blockIdx.x;
+    static_assert(CO % 4 == 0, "CO rows are read as float4");
+    __shared__ __attribute__((aligned(16))) float sm[256 * CO];   // dy stage [256][CO]; afterwards the wave partials [4][8][CE*CO]
+    const int nch = Cin / CE;
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int ch = blockIdx.x * 8 + cl;
+    const bool chok = ch < nch;
     const long p0 = (long)blockIdx.y * slab, p1 = min(M, p0 + slab);
     float acc[CE][CO];
 #pragma unroll
     for (int e = 0; e < CE; ++e)
 #pragma unroll
         for (int n = 0; n < CO; ++n) acc[e][n] = 0.f;
-    for (long pix = p0 + threadIdx.x; pix < p1; pix += 256) {
-        const Chunk<T> c = load_chunk<T>(x + pix * Cin + ch * CE);
-        const T* dr = dy + pix * Cout;
-        float g[CO];
+    for (int i = threadIdx.x; i < 256 * CO; i += 256) sm[i] = 0.f;            // the pad columns stay zero
+    for (long q0 = p0; q0 < p1; q0 += 256) {
+        const int np = (int)min((long)256, p1 - q0);
+        __syncthreads();
+        const T* dq = dy + q0 * Cout;
+        const int nit = (np + 31) >> 5;
+        for (int i = threadIdx.x; i < nit * 32 * Cout; i += 256) {            // contiguous span of dy: coalesced
+            const int px = i / Cout, n = i - px * Cout;
+            sm[px * CO + n] = px < np ? to_f32(dq[i]) : 0.f;
+        }
+        __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            const int px = it * 32 + pl;
+            const bool ok = chok && px < np;
+            Chunk<T> c = load_chunk<T>(x + (q0 + (ok ? px : 0)) * Cin + (chok ? ch : 0) * CE);
+            if (!ok) c = Chunk<T>{};
+            float g[CO];
 #pragma unroll
-        for (int n = 0; n < CO; ++n) g[n] = n < Cout ? to_f32(dr[n]) : 0.f;
+            for (int n4 = 0; n4 < CO / 4; ++n4) {
+                const float4 v = *reinterpret_cast<const float4*>(&sm[px * CO + n4 * 4]);
+                g[n4 * 4] = v.x; g[n4 * 4 + 1] = v.y; g[n4 * 4 + 2] = v.z; g[n4 * 4 + 3] = v.w;
+            }
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-            const float xv = c.get(e);
+            for (int e = 0; e < CE; ++e) {
+                const float xv = c.get(e);
 #pragma unroll
-            for (int n = 0; n < CO; ++n) acc[e][n] = fmaf(xv, g[n], acc[e][n]);
+                for (int n = 0; n < CO; ++n) acc[e][n] = fmaf(xv, g[n], acc[e][n]);
+            }
         }
     }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < CE; ++e)
@@ -1264,33 +1299,64 @@ __global__ __launch_bounds__(256) void skinny_conv_wgrad(const T* __restrict__ x
         for (int n = 0; n < CO; ++n) {
             float v = acc[e][n];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) red[wave][e * CO + n] = v;
+            for (int o = 32; o >= 8; o >>= 1) v += __shfl_xor(v, o);
+            if (lane < 8) sm[(wave * 8 + lane) * (CE * CO) + e * CO + n] = v;
         }
     __syncthreads();
     const long total = (long)Cin * Cout;
-    for (int i = threadIdx.x; i < CE * CO; i += 256) {
-        const int e = i / CO, n = i - e * CO;
-        // transposed: the caller swapped the operands (few INPUT channels): element (many = ch*CE+e, few = n) belongs at [few][many]
-        if (n < Cout) part[(long)blockIdx.y * total + (transposed ? (long)n * Cin + (ch * CE + e) : (long)(ch * CE + e) * Cout + n)] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    for (int i = threadIdx.x; i < 8 * CE * CO; i += 256) {
+        const int c8 = i / (CE * CO), r = i - c8 * (CE * CO);
+        const int e = r / CO, n = r - e * CO;
+        const int chn = blockIdx.x * 8 + c8;
+        // transposed: the caller swapped the operands (few INPUT channels): element (many = chn*CE+e, few = n) belongs at [few][many]
+        if (chn < nch && n < Cout)
+            part[(long)blockIdx.y * total + (transposed ? (long)n * Cin + (chn * CE + e) : (long)(chn * CE + e) * Cout + n)] =
+                (sm[i] + sm[8 * CE * CO + i]) + (sm[2 * 8 * CE * CO + i] + sm[3 * 8 * CE * CO + i]);
     }
 }
 
-// column sums of a [M][C] matrix -> fp32 [C] (bias gradient); two-stage, deterministic
+// column sums of a [M][C] matrix -> fp32 [C] (bias gradient); two-stage, deterministic.  A block is TX column lanes x
+// 256/TX row lanes (TX = C rounded up to a power of two, at most 256), so narrow matrices (21 class logits) still use every
+// thread; the row lanes are folded through LDS in a fixed order.
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C, int rows_per_block, int TX) {
+    __shared__ float red[256];
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = blockIdx.x * TX + tx;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        long r = r0 + ty;
+        for (; r + 3 * TY < r1; r += 4 * TY) {
+            const T v0 = x[r * C + c], v1 = x[(r + TY) * C + c], v2 = x[(r + 2 * TY) * C + c], v3 = x[(r + 3 * TY) * C + c];
+            s0 += to_f32(v0); s1 += to_f32(v1); s2 += to_f32(v2); s3 += to_f32(v3);
+        }
+        for (; r < r1; r += TY) s0 += to_f32(x[r * C + c]);
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && c < C) {
         float s = 0.f;
-        for (long r = r0; r < r1; ++r) s += to_f32(x[r * C + c]);
+        for (int k = 0; k < TY; ++k) s += red[k * TX + tx];
         part[(long)blockIdx.y * C + c] = s;
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C, float scale) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nparts; ++k) s += part[(long)k * C + c];
-        out[c] = s * scale;
+// 32 columns x 8 part lanes per block
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C, float scale) {
+    __shared__ float red[256];
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+    const int c = blockIdx.x * 32 + tx;
+    float s = 0.f;
+    if (c < C)
+        for (int k = ty; k < nparts; k += 8) s += part[(long)k * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + tx];
+        out[c] = t * scale;
     }
 }
