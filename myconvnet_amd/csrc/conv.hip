@@ -760,6 +760,28 @@ extern "C" size_t mcn_conv2d_packed_bytes(mcn_conv_op op, const mcn_conv_geom* g
     return 0;
 }
 
+// jobs per descriptor of the batch kernel (64 workgroups each): 32x32 transpose tiles (forward) / filter rows (dgrad)
+#define MCN_PACK_SLICE_TILES 128
+#define MCN_PACK_SLICE_ROWS 512
+// appends pk cut into slices of at most `slice` jobs; returns the number of descriptors written
+static int pack_emit(const PackParams& pk, PackParams* out) {
+    const int njobs = pk.mode == 0 ? pk.ntaps * ((pk.Cp + 31) / 32) * ((pk.rows + 31) / 32) : pk.rows * pk.ntaps;
+    const int slice = pk.mode == 0 ? MCN_PACK_SLICE_TILES : MCN_PACK_SLICE_ROWS;
+    int n = 0;
+    for (int j = 0; j < njobs; j += slice) {
+        out[n] = pk;
+        out[n].job0 = j;
+        out[n].job1 = j + slice < njobs ? j + slice : njobs;
+        ++n;
+    }
+    return n;
+}
+// upper bound of the descriptors one job needs (any dtype)
+static size_t pack_desc_bound(const mcn_conv_geom& g, int op) {
+    if (op == MCN_CONV_DGRAD)
+        return (size_t)g.SH * g.SW + (size_t)g.Cin * g.KH * g.KW / MCN_PACK_SLICE_ROWS + 1;
+    return (size_t)g.KH * g.KW * ((g.Cin + 31) / 32) * ((g.Cout + 31) / 32) / MCN_PACK_SLICE_TILES + 1;
+}
 // descriptors for one job; returns how many (0 = the op does not use a packed operand)
 static int pack_descs(const Geo& g, mcn_dtype dt, mcn_conv_op op, const float* w, void* packed, PackParams* out) {
     const int ce = ce_of(dt);
@@ -772,7 +794,8 @@ static int pack_descs(const Geo& g, mcn_dtype dt, mcn_conv_op op, const float* w
         pk.ntaps = g.KH * g.KW; pk.mode = 0;
         for (int r = 0; r < g.KH; ++r)
             for (int s = 0; s < g.KW; ++s) { pk.tr[r * g.KW + s] = (signed char)r; pk.ts[r * g.KW + s] = (signed char)s; }
-        return 1;
+        const PackParams whole = pk;
+        return pack_emit(whole, out);
     }
     if (op != MCN_CONV_DGRAD || !mfma_dgrad_ok(g, dt)) return 0;
     const int Cp = round_up(g.Cout, ce);
@@ -793,7 +816,7 @@ static int pack_descs(const Geo& g, mcn_dtype dt, mcn_conv_op op, const float* w
             }
             if (pk.ntaps == 0) continue;
             pk.w = w; pk.out = dst; pk.KW = g.KW; pk.Cin = g.Cin; pk.Cout = g.Cout; pk.rows = g.Cin; pk.Cp = Cp; pk.mode = 1;
-            out[n++] = pk;
+            n += pack_emit(pk, out + n);
             dst += align_up((size_t)g.Cin * pk.ntaps * Cp * es, 256);
         }
     return n;
@@ -801,7 +824,7 @@ static int pack_descs(const Geo& g, mcn_dtype dt, mcn_conv_op op, const float* w
 
 extern "C" size_t mcn_conv2d_pack_table_bytes(const mcn_pack_job* jobs, int32_t njobs) {
     size_t n = 0;
-    for (int i = 0; i < njobs; ++i) n += jobs[i].op == MCN_CONV_DGRAD ? (size_t)jobs[i].geom.SH * jobs[i].geom.SW : 1;
+    for (int i = 0; i < njobs; ++i) n += pack_desc_bound(jobs[i].geom, jobs[i].op);
     return n * sizeof(PackParams);
 }
 extern "C" int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njobs, mcn_dtype dtype, void* host_table, size_t bytes,

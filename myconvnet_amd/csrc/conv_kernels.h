@@ -964,6 +964,7 @@ struct PackParams {
     const float* w;
     void* out;
     int KW, Cin, Cout, rows, Cp, ntaps, mode;
+    int job0, job1;      // batch kernel: the slice of this operand's jobs the descriptor covers (job1 == 0: all of them)
     signed char tr[MCN_MAX_TAPS], ts[MCN_MAX_TAPS];
 };
 template <typename T>
@@ -985,7 +986,8 @@ __global__ void pack_weights_kernel(const PackParams p) {
     }
 }
 
-// all packed operands of a model in ONE launch: blockIdx.y selects the descriptor (device table), blockIdx.x strides
+// all packed operands of a model in ONE launch: blockIdx.y selects the descriptor (device table; big operands are cut into
+// several descriptors of at most MCN_PACK_SLICE_* jobs so that no operand is left to 64 workgroups), blockIdx.x strides
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackParams* __restrict__ table) {
     const PackParams& p = table[blockIdx.y];
@@ -998,8 +1000,8 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackParam
         __shared__ float tile[32][33];
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
         const int nci = (p.Cp + 31) / 32, nco = (p.rows + 31) / 32;
-        const int njobs = p.ntaps * nci * nco;
-        for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const int njobs = p.job1 ? p.job1 : p.ntaps * nci * nco;
+        for (int job = p.job0 + blockIdx.x; job < njobs; job += gridDim.x) {
             const int co0 = (job % nco) * 32;
             const int rest = job / nco;
             const int ci0 = (rest % nci) * 32, t = rest / nci;
@@ -1022,8 +1024,8 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackParam
     // dgrad operand ([cin][tap][cout]): every (cin, tap) row is a contiguous run of Cout weights — one job per row, no
     // per-element 64-bit division
     (void)total;
-    const int njobs = p.rows * p.ntaps;
-    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+    const int njobs = p.job1 ? p.job1 : p.rows * p.ntaps;
+    for (int job = p.job0 + blockIdx.x; job < njobs; job += gridDim.x) {
         const int row = job / p.ntaps, t = job - row * p.ntaps;
         const float* src = p.w + (((long)p.tr[t] * p.KW + p.ts[t]) * p.Cin + row) * p.Cout;
         T* dst = out + (long)job * p.Cp;
@@ -1272,10 +1274,18 @@ __global__ __launch_bounds__(256) void skinny_conv_wgrad(const T* __restrict__ x
             sm[px * CO + n] = px < np ? to_f32(dq[i]) : 0.f;
         }
         __syncthreads();
+        // x chunks two iterations ahead (2 waves per SIMD at 192 accumulators: nothing else hides the load latency)
+        auto ldx = [&](int it) {
+            const int q = it * 32 + pl;
+            return load_chunk<T>(x + (q0 + ((chok && q < np) ? q : 0)) * Cin + (chok ? ch : 0) * CE);
+        };
+        Chunk<T> c0 = ldx(0), c1 = ldx(1);
         for (int it = 0; it < nit; ++it) {
             const int px = it * 32 + pl;
             const bool ok = chok && px < np;
-            Chunk<T> c = load_chunk<T>(x + (q0 + (ok ? px : 0)) * Cin + (chok ? ch : 0) * CE);
+            Chunk<T> c = c0;
+            c0 = c1;
+            c1 = ldx(it + 2);
             if (!ok) c = Chunk<T>{};
             float g[CO];
 #pragma unroll

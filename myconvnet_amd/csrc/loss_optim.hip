@@ -80,11 +80,13 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
     float* yt = xs + XR_ROWS * P;
     for (long b0 = (long)blockIdx.x * XR_ROWS; b0 < B; b0 += (long)gridDim.x * XR_ROWS) {
         const int rows = (int)min((long)XR_ROWS, B - b0);
-        const long n = (long)rows * C;
-        for (long i = threadIdx.x; i < n; i += XR_ROWS) {
-            const int r = (int)(i / C), c = (int)(i - (long)r * C);
-            zt[r * P + c] = logits[b0 * C + i];
-            yt[r * P + c] = labels[b0 * C + i];
+        const int n = rows * C;                                   // (32-bit: a 64-bit division per element cost more than the exps)
+        const float* zsrc = logits + b0 * C;
+        const float* ysrc = labels + b0 * C;
+        for (int i = threadIdx.x; i < n; i += XR_ROWS) {
+            const int r = i / C, c = i - r * C;
+            zt[r * P + c] = zsrc[i];
+            yt[r * P + c] = ysrc[i];
         }
         __syncthreads();
         if ((int)threadIdx.x < rows) {
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
             coef[b0 + threadIdx.x] = cf;
         }
         __syncthreads();
-        for (long i = threadIdx.x; i < n; i += XR_ROWS) {
-            const int r = (int)(i / C), c = (int)(i - (long)r * C);
+        for (int i = threadIdx.x; i < n; i += XR_ROWS) {
+            const int r = i / C, c = i - r * C;
             if (pred) pred[b0 * C + i] = zt[r * P + c];
             if (dlogits) dlogits[b0 * C + i] = yt[r * P + c];
         }

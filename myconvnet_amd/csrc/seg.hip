@@ -245,6 +245,17 @@ extern "C" int mcn_copy_channels(const void* src, int32_t src_stride, int32_t sr
 // SegNet labels: NaN -> 0; class = round(label - 1) (half to even, tf.math.round); class -1 (label 0) or >= C -> all-zero row
 __global__ __launch_bounds__(256) void one_hot_seg_kernel(const float* __restrict__ labels, float* __restrict__ onehot, long P, int C) {
     const long total = P * C;
+    if (total < 0x7fffffffL) {                                 // 32-bit index arithmetic (the 64-bit division per element dominated)
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+            const unsigned q = i / (unsigned)C;
+            const int c = (int)(i - q * (unsigned)C);
+            float l = labels[q];
+            if (l != l) l = 0.f;
+            const int cls = (int)rintf(l - 1.f);
+            onehot[i] = cls == c ? 1.f : 0.f;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long q = i / C;
         const int c = (int)(i - q * C);
