@@ -486,14 +486,28 @@ __device__ __forceinline__ void fused_partial(const float* __restrict__ part, in
 }
 // stage 1 (only for many partials): groups of rpg partial rows -> fold[(g*2 + {0,1})*C + c] (double)
 __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ part, double* __restrict__ fold, int nparts, int C, long M, int rpp,
-                                                               int rpg) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+                                                               int rpg, int TX) {
+    // TX channel lanes x 256/TX row lanes (narrow layers — 16-96 channels with 50 000 partial rows in EfficientNet's first
+    // blocks — left most of a channel-per-thread block idle and one thread walking 100+ rows); lanes fold in a fixed order
+    __shared__ double red[256 * 2];
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = blockIdx.x * TX + tx;
     const int r0 = blockIdx.y * rpg, r1 = min(nparts, r0 + rpg);
     double sm = 0.0, sq = 0.0;
-    for (int r = r0; r < r1; ++r) fused_partial(part, r, C, c, M, rpp, sm, sq);
-    fold[((long)blockIdx.y * 2 + 0) * C + c] = sm;
-    fold[((long)blockIdx.y * 2 + 1) * C + c] = sq;
+    if (c < C)
+        for (int r = r0 + ty; r < r1; r += TY) fused_partial(part, r, C, c, M, rpp, sm, sq);
+    red[threadIdx.x * 2] = sm;
+    red[threadIdx.x * 2 + 1] = sq;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < TY; ++k) {
+        a += red[(k * TX + tx) * 2];
+        b += red[(k * TX + tx) * 2 + 1];
+    }
+    fold[((long)blockIdx.y * 2 + 0) * C + c] = a;
+    fold[((long)blockIdx.y * 2 + 1) * C + c] = b;
 }
 // stage 2: FOLDED reads the doubles of stage 1, otherwise the raw partials
 template <bool FOLDED>
@@ -558,7 +572,9 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
     if (nparts > BN_FOLD_ROWS) {
         const int rpg = (nparts + BN_FOLD_ROWS - 1) / BN_FOLD_ROWS;
         const int n = (nparts + rpg - 1) / rpg;
-        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 255) / 256, n), dim3(256), 0, st, parts, fold, nparts, C, M, rpp, rpg);
+        int TX = 8;
+        while (TX < C && TX < 256) TX *= 2;
+        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + TX - 1) / TX, n), dim3(256), 0, st, parts, fold, nparts, C, M, rpp, rpg, TX);
         MCN_CHECK_LAUNCH();
         hipLaunchKernelGGL((bn_fwd_finalize_fused_kernel<true>), fgrid, fblock, 0, st, parts, (const double*)fold, n, rpp, M, C, gamma, beta, eps, save_mean,
                            save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);

@@ -89,6 +89,8 @@ static bool skinny_in_ok(const Geo& g, mcn_dtype dt, int max_co) {
 static size_t skinny_in_w_bytes(const Geo& g) { return align_up((size_t)g.Cout * skinny_ci(g) * sizeof(float), 256); }
 #define MCN_SKINNY_MAX_CO 32        /* fwd / dgrad: accumulators per thread */
 #define MCN_SKINNY_MAX_CO_WGRAD 24  /* wgrad: [chunk elements][CO] accumulators per thread */
+// few pixels and many channel chunks: one wave per pixel instead of one thread (skinny_conv_fwd_split)
+static bool skinny_split(long M, int chunks) { return M <= 8192 && chunks >= 16; }
 static size_t skinny_w_bytes(const Geo& g) { return align_up((size_t)g.Cin * skinny_co(g) * sizeof(float), 256); }
 static long skinny_wgrad_slab(long M, int chunks) {      // pixels per slab: a multiple of the 32 pixel lanes, at most 256 slabs and ~2048 workgroups
     const long gx = (chunks + 7) / 8;
@@ -404,6 +406,14 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
             const int CO = skinny_co(g);
             float* wp = (float*)ws;
             hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cin * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cin, g.Cout, CO, 0);
+            if (skinny_split(M, g.Cin / ce_of(dt))) {
+                const dim3 grid((unsigned)((M + 3) / 4));
+#define MCN_SKINNY_FWD(COV) hipLaunchKernelGGL((skinny_conv_fwd_split<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const float*)wp, bias, (T*)y, M, g.Cin, g.Cout, 0)
+                if (CO == 8) MCN_SKINNY_FWD(8); else if (CO == 16) MCN_SKINNY_FWD(16); else if (CO == 24) MCN_SKINNY_FWD(24); else MCN_SKINNY_FWD(32);
+#undef MCN_SKINNY_FWD
+                MCN_CHECK_LAUNCH();
+                return MCN_OK;
+            }
             const dim3 grid(nblocks(M, 4096));
 #define MCN_SKINNY_FWD(COV) hipLaunchKernelGGL((skinny_conv_fwd<T, COV>), grid, dim3(256), 0, st, (const T*)x, (const float*)wp, bias, (T*)y, M, g.Cin, g.Cout, 0)
             if (CO == 8) MCN_SKINNY_FWD(8); else if (CO == 16) MCN_SKINNY_FWD(16); else if (CO == 24) MCN_SKINNY_FWD(24); else MCN_SKINNY_FWD(32);
@@ -521,6 +531,14 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
             const int CO = skinny_ci(g);
             float* wp = (float*)ws;
             hipLaunchKernelGGL((skinny_pack_w<T>), dim3((g.Cout * CO + 255) / 256), dim3(256), 0, st, w, wp, g.Cout, g.Cin, CO, 1);
+            if (skinny_split(Min, g.Cout / ce_of(dt))) {
+                const dim3 grid((unsigned)((Min + 3) / 4));
+#define MCN_SKINNY_DGRAD_IN(COV) hipLaunchKernelGGL((skinny_conv_fwd_split<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const float*)wp, (const float*)nullptr, (T*)dx, Min, g.Cout, g.Cin, accumulate)
+                if (CO == 8) MCN_SKINNY_DGRAD_IN(8); else if (CO == 16) MCN_SKINNY_DGRAD_IN(16); else if (CO == 24) MCN_SKINNY_DGRAD_IN(24); else MCN_SKINNY_DGRAD_IN(32);
+#undef MCN_SKINNY_DGRAD_IN
+                MCN_CHECK_LAUNCH();
+                return MCN_OK;
+            }
             const dim3 grid(nblocks(Min, 4096));
 #define MCN_SKINNY_DGRAD_IN(COV) hipLaunchKernelGGL((skinny_conv_fwd<T, COV>), grid, dim3(256), 0, st, (const T*)dy, (const float*)wp, (const float*)nullptr, (T*)dx, Min, g.Cout, g.Cin, accumulate)
             if (CO == 8) MCN_SKINNY_DGRAD_IN(8); else if (CO == 16) MCN_SKINNY_DGRAD_IN(16); else if (CO == 24) MCN_SKINNY_DGRAD_IN(24); else MCN_SKINNY_DGRAD_IN(32);
@@ -865,7 +883,10 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     const int ce = ce_of(dtype);
     const NtTile* cand = kNtCand;
     if (op == MCN_CONV_FWD) {
-        if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_fwd<%s, %d>", tn, skinny_co(g)); return 1; }
+        if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) {
+            snprintf(buf, buflen, "skinny_conv_fwd%s<%s, %d>", skinny_split((long)g.N * g.OH * g.OW, g.Cin / ce) ? "_split" : "", tn, skinny_co(g));
+            return 1;
+        }
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
         const long M = (long)g.N * g.OH * g.OW;
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
@@ -876,7 +897,10 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     }
     if (op == MCN_CONV_DGRAD) {
         if (!mfma_dgrad_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_dgrad<%s, %d>", tn, skinny_co(g)); return 1; }
-        if (!mfma_dgrad_ok(g, dtype) && skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO)) { snprintf(buf, buflen, "skinny_conv_fwd<%s, %d>", tn, skinny_ci(g)); return 1; }
+        if (!mfma_dgrad_ok(g, dtype) && skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO)) {
+            snprintf(buf, buflen, "skinny_conv_fwd%s<%s, %d>", skinny_split((long)g.N * g.H * g.W, g.Cout / ce) ? "_split" : "", tn, skinny_ci(g));
+            return 1;
+        }
         if (!mfma_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_dgrad<%s>", tn); return 1; }
         int ncls = 0, nt0 = 0;
         for (int py = 0; py < g.SH && py < g.H; ++py)

@@ -1212,6 +1212,47 @@ __global__ __launch_bounds__(256) void skinny_conv_fwd(const T* __restrict__ x, 
             if (n < Cout) yr[n] = from_f32<T>(acc[n] + (bias ? bias[n] : 0.f) + (accumulate ? to_f32(yr[n]) : 0.f));
     }
 }
+// the same for FEW pixels (squeeze-excite bottlenecks: M = batch, Cin up to 1152): one WAVE per pixel, lane = slice of the
+// channel chunks (coalesced x row), butterfly fold over the wave.  The thread-per-pixel form above ran M = 512 threads
+// through 84-144 chunks each: 60-100 us of pure latency per call.
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void skinny_conv_fwd_split(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                             T* __restrict__ y, long M, int Cin, int Cout, int accumulate) {
+    constexpr int CE = VecTraits<T>::CE;
+    static_assert(CO % 4 == 0, "weight rows are read as float4");
+    const int nch = Cin / CE;
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= M) return;                                          // (whole waves leave: no barrier below)
+    float acc[CO];
+#pragma unroll
+    for (int n = 0; n < CO; ++n) acc[n] = 0.f;
+    const T* xr = x + pix * Cin;
+    for (int ch = lane; ch < nch; ch += 64) {
+        const Chunk<T> c = load_chunk<T>(xr + ch * CE);
+        const float4* wr = reinterpret_cast<const float4*>(wp + (long)ch * CE * CO);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const float xv = c.get(e);
+#pragma unroll
+            for (int n4 = 0; n4 < CO / 4; ++n4) {
+                const float4 w4 = wr[e * (CO / 4) + n4];
+                acc[n4 * 4] = fmaf(xv, w4.x, acc[n4 * 4]);
+                acc[n4 * 4 + 1] = fmaf(xv, w4.y, acc[n4 * 4 + 1]);
+                acc[n4 * 4 + 2] = fmaf(xv, w4.z, acc[n4 * 4 + 2]);
+                acc[n4 * 4 + 3] = fmaf(xv, w4.w, acc[n4 * 4 + 3]);
+            }
+        }
+    }
+    T* yr = y + pix * Cout;
+#pragma unroll
+    for (int n = 0; n < CO; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && n < Cout) yr[n] = from_f32<T>(v + (bias ? bias[n] : 0.f) + (accumulate ? to_f32(yr[n]) : 0.f));
+    }
+}
 // dx[pixel][c] = sum_n dy[pixel][n] * w[c][n]  (accumulate: += the old value)
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void skinny_conv_dgrad(const T* __restrict__ dy, const float* __restrict__ wp, T* __restrict__ dx, long M, int Cin,

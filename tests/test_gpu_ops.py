@@ -61,6 +61,8 @@ CONV_CASES = [
     (64, 1, 1, 6, 96, 1, 1, 'SAME', 1),          # few INPUT channels (SE expand conv): dgrad / wgrad run the skinny kernels mirrored
     (3, 5, 7, 20, 64, 1, 1, 'SAME', 1),          # the same on a spatial map
     (300, 1, 1, 1152, 48, 1, 1, 'SAME', 1),      # SE reduce conv of the widest B0 block (few pixels: chunk-parallel skinny dgrad)
+    (130, 1, 1, 672, 28, 1, 1, 'SAME', 1),       # SE reduce conv, 28 outputs: wave-per-pixel skinny forward (ragged last block of 4 pixels)
+    (67, 1, 1, 20, 480, 1, 1, 'SAME', 1),        # SE expand conv: its dgrad is the wave-per-pixel skinny forward over dy
 ]
 
 
