@@ -748,7 +748,7 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
             else if (t4 >= 64 * 256 || nsp < 32) hipLaunchKernelGGL((wgrad_reduce_linear_kernel<4>), dim3(nblocks(t4 * 4, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
             else hipLaunchKernelGGL((wgrad_reduce_linear_kernel<16>), dim3(nblocks(t4 * 16, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
         } else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks(total, 2048)), dim3(256), 0, st, (const float*)wsp, dw, nsp, ntaps, Cp, g.Cin, g.Cout, scale);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)wsp, dw, nsp, ntaps, Cp, g.Cin, g.Cout, scale);
         MCN_CHECK_LAUNCH();
         wsp += align_up((size_t)splits * p.rows * g.Cout * 4, 256);
     }

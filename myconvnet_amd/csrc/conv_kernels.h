@@ -900,18 +900,34 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
             }
 }
 
-// dw[t][c][n] = scale * sum_split slab[split][t*Cp + c][n]   (c < Cin)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int ntaps, int Cp,
-                                    int Cin, int Nn, float scale) {
+// dw[t][c][n] = scale * sum_split slab[split][t*Cp + c][n]   (c < Cin).  16 outputs x 16 split lanes per block (the stem: 9408
+// outputs, up to 1024 splits — a thread per output walking them alone took 170 us); lanes fold through LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int ntaps, int Cp,
+                                                           int Cin, int Nn, float scale) {
+    __shared__ float red[256];
     const long total = (long)ntaps * Cin * Nn;
     const long rowsNn = (long)ntaps * Cp * Nn;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const long idx = (long)blockIdx.x * 16 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < total) {
         const int n = (int)(idx % Nn);
         const long tc = idx / Nn;
         const int c = (int)(tc % Cin), t = (int)(tc / Cin);
-        const long src = ((long)t * Cp + c) * Nn + n;
+        const float* src = slab + ((long)t * Cp + c) * Nn + n;
+        int k = ty;
+        for (; k + 48 < splits; k += 64) {
+            const float v0 = src[(long)k * rowsNn], v1 = src[(long)(k + 16) * rowsNn], v2 = src[(long)(k + 32) * rowsNn], v3 = src[(long)(k + 48) * rowsNn];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; k < splits; k += 16) s0 += src[(long)k * rowsNn];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && idx < total) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(long)k * rowsNn + src];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) s += red[l * 16 + tx];
         dw[idx] = s * scale;
     }
 }
