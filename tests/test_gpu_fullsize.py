@@ -251,3 +251,49 @@ def test_depthwise_adjoint_identities_at_b512(layer, dtype):
     per_w = (wq.double() * dw.double()).sum((0, 1))
     cs = torch.sqrt((y.double() ** 2).sum((0, 1, 2)) * (dy.double() ** 2).sum((0, 1, 2)))
     assert float(((per_c - per_w).abs() / cs).max()) <= tol * 4, ('wgrad adjoint per channel', float(((per_c - per_w).abs() / cs).max()))
+
+
+# the 1x1 convs that run OFF the MFMA path at their BASELINE sizes: the DeepLabv3+ class-logit conv (configs[4]: 16 x 129 x 129 pixels,
+# 256 -> 21 with bias) and the squeeze-excite convs of EfficientNet-B0's widest blocks (configs[3]: M = batch = 512 pixels)
+SKINNY_FULL = [(16, 129, 256, 21), (512, 1, 672, 28), (512, 1, 28, 672), (512, 1, 1152, 48), (512, 1, 48, 1152)]
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('layer', SKINNY_FULL, ids=lambda l: 'n{}_h{}_{}to{}'.format(*l))
+def test_skinny_and_se_convs_at_baseline_sizes(layer, dtype):
+    """forward / dgrad / wgrad / bias gradient against float64 matmuls of the SAME (storage-rounded) operands: a 1x1 conv is a
+    matrix product, so torch gives an independent reference at any size."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, cin, cout = layer
+    td = u.TDT[dtype]
+    gen = torch.Generator(device=u.DEV).manual_seed(n + h + cin)
+    x = torch.randn((n, h, h, cin), device=u.DEV, generator=gen).to(td)
+    w = (torch.randn((1, 1, cin, cout), device=u.DEV, generator=gen) / cin ** 0.5).float()
+    b = torch.randn((cout,), device=u.DEV, generator=gen).float()
+    dy = torch.randn((n, h, h, cout), device=u.DEV, generator=gen).to(td)
+    g = u.geom((n, h, h, cin), (1, 1, cin, cout), 1, 'SAME')
+    y = torch.full((n, h, h, cout), float('nan'), device=u.DEV, dtype=td)
+    dx = torch.full((n, h, h, cin), float('nan'), device=u.DEV, dtype=td)
+    dw = torch.full((1, 1, cin, cout), float('nan'), device=u.DEV, dtype=torch.float32)
+    db = torch.full((cout,), float('nan'), device=u.DEV, dtype=torch.float32)
+    ws = u.workspace(max(lib.mcn_conv2d_workspace_bytes(op, ctypes.byref(g), u.MDT[dtype]) for op in (_ffi.CONV_FWD, _ffi.CONV_DGRAD, _ffi.CONV_WGRAD)))
+    st = u.stream()
+    _ffi.check(lib.mcn_conv2d_fwd(x.data_ptr(), w.data_ptr(), 0, b.data_ptr(), y.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
+    _ffi.check(lib.mcn_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), 0, dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
+    _ffi.check(lib.mcn_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ctypes.byref(g), 1.0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(),
+                                    ws.numel() * 4, st))
+    xm, dym = x.double().reshape(-1, cin), dy.double().reshape(-1, cout)
+    wq = w.to(td).double().reshape(cin, cout)                       # weights are rounded to the storage type per use
+    out_tol = 1e-4 if dtype == 'float32' else 1e-2                  # outputs are stored in T (bf16: 2^-8 rounding), parameter gradients in fp32
+    par_tol = 1e-4                                                  # fp32 accumulation over up to 266 256 pixels against float64
+
+    def close(got, ref, tol, what):
+        err = float((got.double().reshape(ref.shape) - ref).abs().max() / ref.abs().max())
+        assert err <= tol, (what, err)
+
+    close(y, xm @ wq + b.double(), out_tol, 'forward + bias')
+    close(dx, dym @ wq.t(), out_tol, 'dgrad')
+    close(dw, xm.t() @ dym, par_tol, 'wgrad')
+    close(db, dym.sum(0), par_tol, 'bias gradient')
