@@ -321,6 +321,63 @@ extern "C" int mcn_maxpool_fwd(const void* x, void* y, int8_t* argmax, int32_t N
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
+// 3x3 / 2 with no leading padding on an even map (the ResNet stem pool: 112 -> 56, pads (0, 1)): one thread per 2x2 block of
+// dx and channel chunk.  The block (rows 2a, 2a+1; columns 2b, 2b+1) is seen by exactly the four windows (a - da, b - db),
+// da, db in {0, 1}: their dy / arg-max chunks are loaded ONCE and routed to the four pixels (the per-pixel form loads four
+// candidate windows per pixel: 8 loads per store instead of 2).  Window (a - da, b - db) covers block row r with filter row
+// kr = r + 2 da (valid when < 3), the same for columns.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_3x3s2_block_kernel(const T* __restrict__ dy, const int8_t* __restrict__ arg, T* __restrict__ dx,
+                                                                      PoolParams p) {
+    const unsigned cv = (unsigned)(p.C / VEC);
+    const unsigned total = (unsigned)((long)p.N * p.OH * p.OW * cv);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        unsigned r = idx / cv;
+        const int c = (int)(idx - r * cv) * VEC;
+        const unsigned r2 = r / (unsigned)p.OW;
+        const int b = (int)(r - r2 * (unsigned)p.OW);
+        const int n = (int)(r2 / (unsigned)p.OH), a = (int)(r2 - (unsigned)n * (unsigned)p.OH);
+        float acc[2][2][VEC];
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[y][x][i] = 0.f;
+#pragma unroll
+        for (int da = 0; da < 2; ++da)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bool ok = a - da >= 0 && b - db >= 0;
+                const long o = (((long)n * p.OH + (ok ? a - da : 0)) * p.OW + (ok ? b - db : 0)) * p.C + c;
+                float g[VEC];
+                pld<T, VEC>(dy + o, g);
+                signed char ac[VEC];
+                if constexpr (VEC == 8) *reinterpret_cast<unsigned long long*>(ac) = *reinterpret_cast<const unsigned long long*>(arg + o);
+                else *reinterpret_cast<unsigned*>(ac) = *reinterpret_cast<const unsigned*>(arg + o);
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const int kr = y + 2 * da;
+                    if (kr >= 3) continue;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        const int ks = x + 2 * db;
+                        if (ks >= 3) continue;
+                        const int code = ok ? kr * 3 + ks : -1;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            if (ac[i] == code) acc[y][x][i] += g[i];
+                    }
+                }
+            }
+        T* o0 = dx + (((long)n * p.H + 2 * a) * p.W + 2 * b) * p.C + c;
+        pst<T, VEC>(o0, acc[0][0]);
+        pst<T, VEC>(o0 + p.C, acc[0][1]);
+        pst<T, VEC>(o0 + (long)p.W * p.C, acc[1][0]);
+        pst<T, VEC>(o0 + (long)p.W * p.C + p.C, acc[1][1]);
+    }
+}
+
 extern "C" int mcn_maxpool_bwd(const void* dy, const int8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH,
                                int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype,
                                void* stream) {
@@ -331,14 +388,18 @@ extern "C" int mcn_maxpool_bwd(const void* dy, const int8_t* argmax, void* dx, i
     const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * H * W * C;
+    // every dx pixel lies in exactly one 2x2 block and every window is one of the four a block sees
+    const bool blockable = KH == 3 && KW == 3 && SH == 2 && SW == 2 && padT == 0 && padL == 0 && H % 2 == 0 && W % 2 == 0 && OH == H / 2 && OW == W / 2;
     if (dtype == MCN_F32) {
         if (total >= 0xffffffffL) MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: more than 2^32 elements");
-        if (C % 4 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, 3, 2>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
+        if (C % 4 == 0 && blockable) hipLaunchKernelGGL((maxpool_bwd_3x3s2_block_kernel<float, 4>), dim3(pool_blocks(total / 16)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
+        else if (C % 4 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, 3, 2>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
         else if (C % 4 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
         else hipLaunchKernelGGL((maxpool_bwd_kernel<float, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, p);
     } else if (dtype == MCN_BF16) {
         if (total >= 0xffffffffL) MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: more than 2^32 elements");
-        if (C % 8 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+        if (C % 8 == 0 && blockable) hipLaunchKernelGGL((maxpool_bwd_3x3s2_block_kernel<bf16_t, 8>), dim3(pool_blocks(total / 32)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+        else if (C % 8 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
         else if (C % 8 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
         else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: dtype %d unsupported", (int)dtype);

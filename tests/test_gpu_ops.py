@@ -305,7 +305,7 @@ def test_bn_infer_and_affine(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('cfg', [(16, 3, 2, 'SAME', 16), (15, 3, 2, 'SAME', 8), (8, 2, 2, 'SAME', 32), (7, 2, 2, 'SAME', 5), (1, 2, 2, 'SAME', 8),
+@pytest.mark.parametrize('cfg', [(16, 3, 2, 'SAME', 16), (12, 3, 2, 'SAME', 24), (15, 3, 2, 'SAME', 8), (8, 2, 2, 'SAME', 32), (7, 2, 2, 'SAME', 5), (1, 2, 2, 'SAME', 8),
                                  (8, 2, 2, 'VALID', 16)])
 def test_maxpool(cfg, dtype):
     u = _u()
