@@ -243,32 +243,38 @@ extern "C" int mcn_copy_channels(const void* src, int32_t src_stride, int32_t sr
 }
 
 // SegNet labels: NaN -> 0; class = round(label - 1) (half to even, tf.math.round); class -1 (label 0) or >= C -> all-zero row
-__global__ __launch_bounds__(256) void one_hot_seg_kernel(const float* __restrict__ labels, float* __restrict__ onehot, long P, int C) {
+__global__ __launch_bounds__(256) void one_hot_seg_kernel(const float* __restrict__ labels, float* __restrict__ onehot, long P, int C, int vec) {
+    // a thread writes four consecutive elements as one 16-byte store (4-byte stores ran at half the write bandwidth); the elements
+    // may straddle pixels, so the (pixel, class) pair is stepped rather than divided again
     const long total = P * C;
-    if (total < 0x7fffffffL) {                                 // 32-bit index arithmetic (the 64-bit division per element dominated)
-        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
-            const unsigned q = i / (unsigned)C;
-            const int c = (int)(i - q * (unsigned)C);
+    const long nvec = vec ? total / 4 : 0;                        // (vec: the output is 16-byte aligned)
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const long i = v * 4;
+        long q = i / C;
+        int c = (int)(i - q * C);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             float l = labels[q];
             if (l != l) l = 0.f;
-            const int cls = (int)rintf(l - 1.f);
-            onehot[i] = cls == c ? 1.f : 0.f;
+            o[k] = (int)rintf(l - 1.f) == c ? 1.f : 0.f;
+            if (++c == C) { c = 0; ++q; }
         }
-        return;
+        *reinterpret_cast<f32x4*>(onehot + i) = o;
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = nvec * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long q = i / C;
         const int c = (int)(i - q * C);
         float l = labels[q];
         if (l != l) l = 0.f;
-        const int cls = (int)rintf(l - 1.f);
-        onehot[i] = cls == c ? 1.f : 0.f;
+        onehot[i] = (int)rintf(l - 1.f) == c ? 1.f : 0.f;
     }
 }
 extern "C" int mcn_one_hot_seg(const float* labels, float* onehot, int64_t P, int32_t C, void* stream) {
     if (!labels || !onehot || P < 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "one_hot_seg: bad argument");
     if (P == 0) return MCN_OK;
-    hipLaunchKernelGGL(one_hot_seg_kernel, dim3(seg_blocks((long)P * C)), dim3(256), 0, (hipStream_t)stream, labels, onehot, (long)P, C);
+    hipLaunchKernelGGL(one_hot_seg_kernel, dim3(seg_blocks(((long)P * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, labels, onehot, (long)P, C,
+                       (((uintptr_t)onehot) & 15) == 0 ? 1 : 0);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
