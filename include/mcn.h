@@ -96,7 +96,9 @@ int mcn_conv2d_dgrad(const void* dy, const float* w_hwio, const void* w_packed, 
  * builds a descriptor table on the host, uploads it once, and runs it whenever the masters changed.
  *   bytes  = mcn_conv2d_packed_bytes(op, geom, dtype)           (0: this op takes no packed operand)
  *   mcn_conv2d_pack_table_build(jobs, n, dtype, host_table, mcn_conv2d_pack_table_bytes(jobs, n), &ndesc)
- *   copy host_table to the device;  mcn_conv2d_pack_run(dev_table, ndesc, dtype, stream)            */
+ *   copy host_table to the device;  mcn_conv2d_pack_run(dev_table, ndesc, dtype, stream)
+ * The table is opaque; pack_table_bytes() is an upper bound (big operands are cut into several descriptors so that the one
+ * launch stays balanced), ndesc is the number of descriptors actually written.                     */
 typedef struct {
     const float* w_hwio; /* device pointer: fp32 master [KH][KW][Cin][Cout] */
     void* packed;        /* device pointer: mcn_conv2d_packed_bytes() bytes */
