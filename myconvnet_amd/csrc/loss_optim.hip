@@ -94,24 +94,31 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
             float* yv = yt + threadIdx.x * P;
             float mx = -INFINITY;
             for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
-            float se = 0.f, sy = 0.f, bw = 0.f;
+            // one exponential per class: e = exp(z - max) is kept in the row's LDS slot and pred = e / sum(e) (the second
+            // exp(log-softmax) per class made this kernel VALU bound at 21 classes x 4.2 M pixels); the loss uses
+            // -sum(lab * lsm) = lse * sum(lab) - sum(lab * (z - max))
+            float se = 0.f, sy = 0.f, bw = 0.f, slz = 0.f;
             for (int c = 0; c < C; ++c) {
-                se += expf(z[c] - mx);
+                const float d = z[c] - mx;
+                const float e = expf(d);
+                se += e;
                 const float y = yv[c];
                 sy += y;
                 bw += y * (class_w ? class_w[c] : 1.f);
+                const float lab = ls > 0.f ? y * (1.f - ls) + ls / (float)C : y;
+                slz += lab * d;
+                z[c] = e;
             }
             const float lse = logf(se);
+            const float inv = 1.f / se;
             const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
             const float cf = bw * valid;
             const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
             const float gscale = cf * loss_scale / (float)B;
-            float cel = 0.f;
+            const float cel = lse * lab_sum - slz;
             for (int c = 0; c < C; ++c) {
-                const float lsm = z[c] - mx - lse;
-                const float pr = expf(lsm);
+                const float pr = z[c] * inv;
                 const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
-                cel -= lab * lsm;
                 z[c] = pr;
                 yv[c] = (pr * lab_sum - lab) * gscale;
             }
