@@ -11,8 +11,11 @@ At N=1 the line also carries:
   roofline     — the dominant kernel's algorithmic FLOP/s (HIP events around every launch of that kernel in an extra,
                  instrumented pass over the same launch lists; torch's current stream IS the launch stream) against the
                  dense MFMA peak of the dtype (MI355X_MICROARCH.md: fp32 157.3 TFLOP/s, bf16 2500 TFLOP/s)
-  cpu_baseline — the NumPy oracle ("port"; the reference's TF-CPU path cannot run here) timed on the host cores on a
-                 bounded sample (same network, B=8)
+  cpu_baseline — a torch-CPU (oneDNN) restatement of the same step (oracle/torch_cpu.py, "port": the reference's TF-CPU path
+                 cannot run here) timed on the host cores on a bounded sample (same network, B=32, 5 steps); the NumPy oracle
+                 of record rides along as `numpy_port` (B=8)
+  config.fetch = false: the timed step skips the reference's per-step device->host copy of Y_all / pred and the numpy
+                 score (optimizers.py:590-594, :410); everything else of `_step` is inside the timed region
   bf16         — a secondary measurement of the same step in bf16 (the north-star arithmetic), unless --dtype bf16.
 roofline.traffic = HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh; null if absent).
 --model efficientnet_b0 | deeplabv3plus: BASELINE configs[3] / configs[4] on one GPU (secondary workloads, no roofline object).
@@ -237,30 +240,45 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
 
 
 def cpu_baseline():
-    """The oracle (NumPy port of the path) timed on the host cores, bounded sample: ResNet-50, 224x224, B=8, fp32."""
+    """CPU stand-ins for the reference's `num_gpus=0` TensorFlow path (which cannot run in this image), timed on the host
+    cores in the same run — BASELINE.md §4: the same ResNet-v1.5-50 fp32 training step at B=32, 2 warm-up + 5 timed steps,
+    median.  Primary: oracle/torch_cpu.py (torch-CPU ops = oneDNN, autograd), pinned to the NumPy oracle by
+    tests/test_oracle_vs_torch.py.  Secondary key `numpy_port`: the NumPy oracle of record itself (B=8, mostly
+    single-threaded).  Neither is TensorFlow; both are labelled stand-ins."""
     from oracle import net as ON
+    from oracle.torch_cpu import ResNetTorchCPU
     spec = ON.ResNetSpec.resnet50(1000)
     params, stats = ON.init_variables(spec.variables(), seed=0, dtype=np.float32)
-    st = ON.TrainState(params, stats)
     rng = np.random.default_rng(1234)
-    B = 8
+    B = 32
     x = rng.random((B, 224, 224, 3), dtype=np.float32)
     y = rng.integers(0, 1000, B).astype(np.float32)
-    ON.train_step(spec, st, x, y, batch_total=256)                         # warm-up (BLAS threads, page faults)
+    threads = torch.get_num_threads()
+    tc = ResNetTorchCPU(spec, params, stats, channels_last=True)
+    for _ in range(2):
+        tc.train_step(x, y, batch_total=256)
     times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        tc.train_step(x, y, batch_total=256)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    out = dict(value=round(B / med, 3), unit='images/sec', cores=threads, kind='port', ms_per_step=round(med * 1e3, 1),
+               impl='torch-CPU (oneDNN) stand-in, not TensorFlow', host_cpus=os.cpu_count(), omp_num_threads=os.environ.get('OMP_NUM_THREADS'),
+               sample='ResNet-v1.5-50 fp32 224x224 training step (fwd + autograd bwd + Nesterov/L2/EMA), B=32, median of 5 steps after '
+                      '2 warm-up, torch intra-op threads = `cores`; the reference TF-1.x CPU path cannot run in this image')
+    del tc
+    st = ON.TrainState(params, stats)
+    xs, ys = x[:8], y[:8]
+    ON.train_step(spec, st, xs, ys, batch_total=256)                      # warm-up (BLAS threads, page faults)
+    t2 = []
     for _ in range(2):
         t0 = time.perf_counter()
-        ON.train_step(spec, st, x, y, batch_total=256)
-        times.append(time.perf_counter() - t0)
-    try:                                               # threads the BLAS under NumPy actually uses (the rest of the oracle is single-threaded)
-        from threadpoolctl import threadpool_info
-        cores = max([int(i.get('num_threads', 1)) for i in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
-    return dict(value=round(B / float(np.median(times)), 3), unit='images/sec', cores=cores, kind='port',
-                sample='NumPy(OpenBLAS) oracle, ResNet-v1.5-50 fp32 224x224 training step, B=8, median of 2 steps after 1 warm-up (BLAS matmuls '
-                       'multi-threaded on `cores` threads, the rest single-threaded); '
-                       'the reference TF-1.x CPU path cannot run in this image')
+        ON.train_step(spec, st, xs, ys, batch_total=256)
+        t2.append(time.perf_counter() - t0)
+    out['numpy_port'] = dict(value=round(8 / float(np.median(t2)), 3), unit='images/sec',
+                             sample='NumPy(OpenBLAS) oracle of record, same step, B=8, median of 2 steps after 1 warm-up')
+    return out
 
 
 def local_device():
@@ -292,7 +310,7 @@ def main():
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
                'config': {'workload': '{} {} {}x{} synthetic training step (BASELINE {}), batch={}/GPU'.format(title[0], args.dtype, title[1], title[1], title[2], args.batch),
-                          'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world), 'ema': not args.no_ema},
+                          'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world), 'ema': not args.no_ema, 'fetch': False},
                'conv_macs_per_image': int(model.conv_macs), 'params': int(model.params)}
         if world == 1:
             table = instrumented_pass(model, args.dtype, layers=args.layers)
@@ -309,7 +327,7 @@ def main():
         'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': 'ResNet-v1.5-50 {} 224x224 synthetic ImageNet-1k training step (fwd+bwd+Nesterov/L2/EMA), batch={}/GPU'
                    .format(args.dtype, args.batch), 'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world),
-                   'ema': not args.no_ema},
+                   'ema': not args.no_ema, 'fetch': False},
         'train_flop_per_image': TRAIN_FLOP_PER_IMAGE,
         'e2e_mfma_frac': round(ips / world * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
     }

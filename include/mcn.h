@@ -48,6 +48,9 @@ typedef enum {
 
 int mcn_version(void);
 const char* mcn_last_error(void);
+/* hex digest of the sources (csrc/ *.hip *.h + this header) the library was built from; the binding compares it with the
+ * tree it is imported from and refuses a stale binary (myconvnet_amd/_ffi.py, build.py) */
+const char* mcn_build_id(void);
 
 /* ---- convolution ------------------------------------------------------------------------
  * Geometry shared by the three conv entry points.  x:[N][H][W][x_cs] (x_cs = channel stride in

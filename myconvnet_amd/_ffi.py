@@ -40,6 +40,7 @@ class PackJob(ctypes.Structure):
 SIGNATURES = {
     'mcn_version': (c_int, []),
     'mcn_last_error': (c_char_p, []),
+    'mcn_build_id': (c_char_p, []),
     'mcn_conv2d_tile_candidates': (c_int, [c_int]),
     'mcn_conv2d_workspace_bytes': (c_size_t, [c_int, ctypes.POINTER(ConvGeom), c_int]),
     'mcn_conv2d_kslices': (c_int32, [c_int, ctypes.POINTER(ConvGeom), c_int]),
@@ -117,7 +118,23 @@ def load(path=LIB_PATH):
     return lib
 
 
+def _check_fresh(lib):
+    """Refuse a binary built from other sources than the tree it is imported from (editing csrc/ or include/mcn.h and
+    running tests / bench without rebuilding used to run the stale library silently).  MCN_SKIP_BUILD_CHECK=1 overrides."""
+    if os.environ.get('MCN_SKIP_BUILD_CHECK') == '1':
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_mcn_build', os.path.join(_HERE, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    have, want = lib.mcn_build_id().decode(), mod.source_digest()
+    if have != want:
+        raise ImportError('libmcn_hip.so is stale: built from sources {}..., the tree has {}... — rebuild with '
+                          '`python myconvnet_amd/build.py`'.format(have[:12], want[:12]))
+
+
 lib = load()
+_check_fresh(lib)
 
 
 def last_error():

@@ -21,6 +21,16 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
          '-Wno-unused-variable', '-ffp-contract=fast']
 
 
+def source_digest():
+    """sha256 over the kernel sources and headers, in a fixed order: the identity of what libmcn_hip.so must be built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read() + b'\0')
+    return h.hexdigest()
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -40,6 +50,16 @@ def build(force=False, verbose=True):
     def run(cmd):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         return cmd, r.returncode, r.stdout
+
+    # the build id travels in a generated one-line translation unit, recompiled whenever the digest changes
+    digest = source_digest()
+    id_src, id_obj = os.path.join(OBJ, 'build_id.cpp'), os.path.join(OBJ, 'build_id.o')
+    line = 'extern "C" const char* mcn_build_id(void) { return "%s"; }\n' % digest
+    if force or not os.path.exists(id_obj) or not os.path.exists(id_src) or open(id_src).read() != line:
+        with open(id_src, 'w') as fh:
+            fh.write(line)
+        jobs.append([os.environ.get('CXX', 'g++'), '-O1', '-fPIC', '-c', id_src, '-o', id_obj])
+    objs.append(id_obj)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:

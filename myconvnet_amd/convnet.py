@@ -305,9 +305,22 @@ class ConvNet(object):
 
     # ---- compile: storage + launch lists -----------------------------------------------------------------------------------
     def compile(self, loss_scale=1.0):
+        """Allocate storage and initialise the variables (once), then lower the graph to launch lists.  Calling it again
+        (e.g. with another loss scale) only re-lowers: variables, EMA shadows, momentum and running statistics are kept."""
         from .executor import Lowering
         if self.device.type != 'cuda':
             raise RuntimeError('ConvNet.compile() needs an MI355X (cuda device); the HIP path has no CPU fallback')
+        g = self.graph
+        if not getattr(self, '_allocated', False):
+            self._allocate()
+            self._allocated = True
+        self.loss_scale = float(loss_scale)
+        self._train_low = Lowering(g, self, 'train', loss_scale).lower()
+        self._eval_low = Lowering(g, self, 'eval', 1.0).lower()
+        self.compiled = True
+        return self
+
+    def _allocate(self):
         g = self.graph
         if self.fuse and not getattr(self, '_fused', False):
             g.fuse()
@@ -351,11 +364,6 @@ class ConvNet(object):
                 self.loss_buf = a['loss']
                 self.valid_coef = a['coef']
         g.allocate(training=True)
-        self.loss_scale = float(loss_scale)
-        self._train_low = Lowering(g, self, 'train', loss_scale).lower()
-        self._eval_low = Lowering(g, self, 'eval', 1.0).lower()
-        self.compiled = True
-        return self
 
     def initialize_variables(self, seed=None):
         """Fill every variable from its initializer (torch.Generator seeded per SURVEY §8d), EMA shadows start at the
@@ -419,27 +427,66 @@ class ConvNet(object):
         return a
 
     def predict(self, dataset, verbose=False, return_images=True, max_examples=None, run_init_ops=True, **kwargs):
-        """reference convnet.py:609-665: forward-only loop with is_train=False (EMA weights + EMA running statistics)."""
-        batch = self.device_batch
+        """reference convnet.py:609-665: forward-only loop with is_train=False (EMA weights + EMA running statistics) over
+        GLOBAL batches of dataset.batch_size; rank r evaluates shard r of each global batch (dataset.py:113-129) and the
+        per-rank labels / predictions are all-gathered into the reference's Y_all / pred order, so every rank returns the
+        whole set.  The last, short batch is delivered as the reference's tf.data pipeline delivers it: rows past the end
+        are fed as ignored samples (NaN label) and dropped from the outputs and from that batch's loss mean."""
+        b, world = self.device_batch, self.world_size
+        assert getattr(dataset, 'num_shards', world) == world, 'Number of devices mismatch between the model and dataset'
+        gb = b * world
         pred_size = dataset.num_examples if max_examples is None else min(max_examples, dataset.num_examples)
-        num_steps = int(np.ceil(pred_size / batch))
+        num_steps = int(np.ceil(pred_size / gb))
         _X = np.zeros([pred_size] + list(self._input_size), dtype=np.float32) if return_images else np.zeros([pred_size, 4, 4, 3], np.float32)
         _Y_true = np.zeros([pred_size] + list(self.Y.shape[1:]), dtype=np.float32)
         _Y_pred = np.zeros([pred_size] + list(self.pred.shape[1:]), dtype=np.float32)
         _loss = np.zeros(num_steps, dtype=np.float32)
+        gather = None
+        if world > 1:
+            from .dist import all_gather_rows as gather, init_process_group
+            init_process_group(self.device)
         dataset.initialize()
         for i in range(num_steps):
-            X, Y = dataset.next_batch(batch)
+            X, Y = dataset.next_batch(b, shard=self.rank)
+            s = i * gb
+            num_left = min(pred_size - s, gb)
+            mine = int(np.clip(num_left - self.rank * b, 0, b))        # rows of this rank's shard that exist
+            if mine < b:
+                Y = np.array(Y, dtype=np.float32, copy=True)
+                Y[mine:] = np.nan                                        # NaN label = ignored sample (convnet.py:441-449)
             self.feed(X, Y)
             self.forward(train=False)
-            s, e = i * batch, min((i + 1) * batch, pred_size)
+            y_dev, p_dev = self.Y.buf, self.pred.buf
+            if gather is not None:
+                y_dev, p_dev = gather(y_dev), gather(p_dev)
             if return_images:
-                xin = self.X_in.cpu().numpy()
-                _X[s:e] = (xin.transpose(0, 2, 3, 1) if self._channel_first else xin)[:e - s]
-            _Y_true[s:e] = self.Y.buf.cpu().numpy()[:e - s]
-            _Y_pred[s:e] = self.pred.buf.cpu().numpy()[:e - s]
-            _loss[i] = float(self.loss_buf[0].item())
+                xin = self.X_in if gather is None else gather(self.X_in)
+                xin = xin.cpu().numpy()
+                _X[s:s + num_left] = (xin.transpose(0, 2, 3, 1) if self._channel_first else xin)[:num_left]
+            _Y_true[s:s + num_left] = y_dev.cpu().numpy()[:num_left]
+            _Y_pred[s:s + num_left] = p_dev.cpu().numpy()[:num_left]
+            _loss[i] = self._eval_batch_loss(mine, num_left, gather)
         return _X, _Y_true, _Y_pred, float(np.mean(_loss))
+
+    def _eval_batch_loss(self, mine, num_left, gather):
+        """Loss of the batch just evaluated = mean over towers (convnet.py:510); a short last batch averages its
+        cross-entropy over the rows that exist (the reference's tower sees a smaller batch), not over the padded buffer."""
+        b = self.device_batch
+        full = self.loss_buf[0]
+        if num_left < b * self.world_size:
+            n = self._loss_node.attrs
+            rows_per = n['rows'] // b                                     # 1, or H*W for per-pixel losses
+            ce_sum = (n['ce'] * n['coef']).sum()
+            l2 = full - ce_sum / n['rows']
+            full = ce_sum / max(mine * rows_per, 1) + l2 if mine > 0 else l2 * 0.0
+            if gather is not None:
+                per_rank = gather(full.reshape(1)).cpu().numpy()
+                towers = int(np.ceil(num_left / b))                       # ranks that received any row
+                return float(per_rank[:towers].mean())
+            return float(full.item())
+        if gather is not None:
+            return float(gather(full.reshape(1)).mean().item())
+        return float(full.item())
 
     # ---- layers -----------------------------------------------------------------------------------------------------------------------
     def _log_layer(self, name, shape, flops, params, nodes):

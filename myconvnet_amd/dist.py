@@ -30,6 +30,18 @@ def init_process_group(device=None):
     dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', 0)), world_size=int(os.environ.get('WORLD_SIZE', 1)), **kw)
 
 
+def all_gather_rows(t, group=None):
+    """Concatenate every rank's `t` along axis 0 in rank order (the reference's tf.concat over towers, convnet.py:503-509)."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if dist.get_backend(group) == 'nccl':
+        dist.all_gather_into_tensor(out, t, group=group)
+    else:
+        dist.all_gather(list(out.chunk(world, dim=0)), t, group=group)
+    return out
+
+
 def plan_buckets(variables, ready_index, bucket_bytes):
     """variables: [(name, offset, padded_size)] of ONE flat buffer; ready_index: name -> backward call index after
     which the gradient is final.  Returns [(launch_index, [(start, end), ...])]: element ranges to all-reduce once

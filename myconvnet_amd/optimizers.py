@@ -63,9 +63,10 @@ class Optimizer(object):
         """reference optimizers.py:89-177.  Returns the update Program; gradients come from the model's backward
         launch list (compute_gradients), averaged over ranks by the all-reduce (mean over towers, :138)."""
         m = self.model
-        self.loss_scaling_factor = float(kwargs.get('loss_scaling_factor', 1.0))
+        # the reference scales only for a factor > 1 (optimizers.py:102-103, 109-111)
+        self.loss_scaling_factor = max(float(kwargs.get('loss_scaling_factor', 1.0)), 1.0)
         if self.loss_scaling_factor != m.loss_scale:
-            m.compile(loss_scale=self.loss_scaling_factor)
+            m.compile(loss_scale=self.loss_scaling_factor)        # re-lowers only: variables and optimizer state are kept
         self.weight_decay = kwargs.get('base_weight_decay', 0.0) * self.batch_size / 256
         self.weight_decay_scheduling = kwargs.get('weight_decay_scheduling', True)
         # decay variant (optimizers.py:163-170): pseudo-Huber wins over L1 when both are given
@@ -189,7 +190,11 @@ class Optimizer(object):
         m.global_step += 1
         if fetch:
             loss = self._mean_loss()
-            return loss, m.Y.buf.cpu().numpy(), m.pred.buf.cpu().numpy()
+            y, pred = m.Y.buf, m.pred.buf
+            if self.dp is not None and m.world_size > 1:                 # Y_all / pred over all towers (convnet.py:504,508)
+                from .dist import all_gather_rows
+                y, pred = all_gather_rows(y), all_gather_rows(pred)
+            return loss, y.cpu().numpy(), pred.cpu().numpy()
         return m.loss_buf, m.Y.buf, m.pred.buf
 
     def _mean_loss(self):

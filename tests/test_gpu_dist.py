@@ -141,3 +141,55 @@ def test_rccl_calls_with_one_rank_change_nothing():
     assert res['plain'][0] == res['rccl'][0]
     for k, v in res['plain'][1].items():
         np.testing.assert_array_equal(v, res['rccl'][1][k])
+
+
+def _predict_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      MCN_DIST_BACKEND='gloo')
+    import myconvnet_amd as M
+    spec, params, stats, model, _ = _build('resnet', world, rank, 4)
+    model.set_variables(dict(params, **stats))
+    xv, yv = M.synthetic(21, (64, 64, 3), 10, seed=31)
+    val = M.DataSet(xv, yv, batch_size=8, num_shards=world)            # global batch 8 = 2 ranks x 4; 21 = 2 full batches + 5
+    _, y_true, y_pred, loss = model.predict(val, return_images=False)
+    q.put((rank, y_true, y_pred, loss))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_predict_returns_whole_set_in_order():
+    """predict() under data parallelism: rank r evaluates shard r of each global batch, the results are
+    all-gathered into dataset order on every rank; the last global batch (5 rows: rank 0 has 4, rank 1 has 1) is short."""
+    import myconvnet_amd as M
+    from oracle import net as ON
+    from oracle import ops as O
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_predict_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    spec, params, stats, _, _ = _build('resnet', world, None, 4)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    xv, yv = M.synthetic(21, (64, 64, 3), 10, seed=31)
+    _, _, pred, _, _ = ON.forward_loss(spec, state, xv.astype(np.float64), yv.astype(np.float64), train=False, use_ema=True)
+    # tower losses: mean over towers of each tower's mean over ITS rows (convnet.py:510), per global batch
+    step_losses = []
+    for s in range(0, 21, 8):
+        tl = []
+        for r in range(world):
+            lo, hi = s + 4 * r, min(s + 4 * r + 4, 21)
+            if lo < hi:
+                tl.append(ON.forward_loss(spec, state, xv[lo:hi].astype(np.float64), yv[lo:hi].astype(np.float64), train=False, use_ema=True)[3])
+        step_losses.append(np.mean(tl))
+    for rank, y_true, y_pred, loss in res:
+        assert y_pred.shape == (21, 10)
+        np.testing.assert_array_equal(y_true, O.one_hot_labels(yv, 10))
+        np.testing.assert_allclose(y_pred, pred, rtol=0, atol=2e-5)
+        np.testing.assert_array_equal(y_pred.argmax(-1), pred.argmax(-1))
+        assert abs(loss - np.mean(step_losses)) <= 1e-4 * abs(np.mean(step_losses))
+    np.testing.assert_array_equal(res[0][2], res[1][2])

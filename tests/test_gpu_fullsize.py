@@ -297,3 +297,67 @@ def test_skinny_and_se_convs_at_baseline_sizes(layer, dtype):
     close(dx, dym @ wq.t(), out_tol, 'dgrad')
     close(dw, xm.t() @ dym, par_tol, 'wgrad')
     close(db, dym.sum(0), par_tol, 'bias gradient')
+
+
+def _step_twice_at_baseline(build, x, y, check):
+    """Two fresh models, two steps each: finite, in the loss window of a random init, bit-identical when repeated."""
+    import myconvnet_amd as M
+    results = []
+    for rep in range(2):
+        model = build()
+        opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90)
+        model.fixed_random_masks = None
+        model._mask_rng = np.random.default_rng(99)                       # same stochastic-depth / dropout draws in both repeats
+        model.feed(x, y)
+        losses = []
+        for _ in range(2):
+            opt._update_learning_rate()
+            loss, y_true, y_pred = opt._step(None)
+            losses.append(loss)
+        assert np.isfinite(losses).all(), losses
+        check(losses, y_true, y_pred)
+        grads = model.store.grad.detach().clone()
+        assert torch.isfinite(grads).all() and float(grads.abs().max()) > 0
+        assert torch.isfinite(model.store.data).all() and torch.isfinite(model.stats.data).all()
+        results.append((losses, model.store.data.detach().clone(), grads, model.stats.data.detach().clone()))
+        del model, opt
+        torch.cuda.empty_cache()
+    (l0, w0, g0, s0), (l1, w1, g1, s1) = results
+    assert l0 == l1
+    assert torch.equal(w0, w1) and torch.equal(g0, g1) and torch.equal(s0, s1)
+
+
+def test_efficientnet_b0_step_at_baseline_size_is_finite_and_deterministic():
+    """BASELINE configs[3]: EfficientNet-B0 bf16, 224x224, B = 512 on one GPU (depthwise + swish + squeeze-excite +
+    stochastic depth + dropout path), whole network, He / variance-scaling init."""
+    import myconvnet_amd as M
+    Bn = 512
+    rng = np.random.default_rng(1234)
+    x = rng.random((Bn, 224, 224, 3), dtype=np.float32)
+    y = rng.integers(0, 1000, Bn).astype(np.float32)
+
+    def check(losses, y_true, y_pred):
+        assert np.log(1000.0) - 0.5 <= losses[0] <= np.log(1000.0) + 8.0, losses
+        assert y_pred.shape == (Bn, 1000) and abs(float(y_pred.sum(1).mean()) - 1.0) <= 1e-3
+        np.testing.assert_array_equal(y_true.argmax(1), y.astype(np.int64))
+    _step_twice_at_baseline(lambda: M.EfficientNetB0([224, 224, 3], 1000, batch_size=Bn, num_gpus=1, half_precision=True, seed=0), x, y, check)
+
+
+def test_deeplabv3plus_step_at_baseline_size_is_finite_and_deterministic():
+    """BASELINE configs[4] on one GPU: DeepLabv3+ (ResNet-50 OS16), 513x513 synthetic Cityscapes (19 classes, label 0 =
+    ignored pixel), B = 16, bf16: dilated 3x3 convs, ASPP, align_corners resize, concat, per-pixel loss."""
+    import myconvnet_amd as M
+    Bn, S, C = 16, 513, 19
+    rng = np.random.default_rng(1234)
+    x = rng.random((Bn, S, S, 3), dtype=np.float32)
+    y = rng.integers(0, C + 1, (Bn, S, S)).astype(np.float32)
+
+    def check(losses, y_true, y_pred):
+        # per-pixel CE averaged over ALL pixels (ignored ones contribute 0, convnet.py:594): ~ (C/(C+1)) ln C at a random init
+        assert 0.5 * np.log(C) <= losses[0] <= np.log(C) + 8.0, losses
+        assert y_pred.shape == (Bn, S, S, C)
+        valid = y > 0
+        np.testing.assert_array_equal(y_true.sum(-1) == 1, valid)
+        np.testing.assert_array_equal(y_true.argmax(-1)[valid], (y[valid] - 1).astype(np.int64))
+        assert abs(float(y_pred[0].sum(-1).mean()) - 1.0) <= 1e-3
+    _step_twice_at_baseline(lambda: M.DeepLabV3PlusResNet50([S, S, 3], C, batch_size=Bn, num_gpus=1, half_precision=True, seed=0), x, y, check)

@@ -174,3 +174,27 @@ def test_accuracy_evaluator_matches_reference_rule():
     y_true = O.one_hot_labels(np.array([1, 2, np.nan, 0]), 3)
     y_pred = np.array([[0.1, 0.8, 0.1], [0.5, 0.2, 0.3], [0.3, 0.3, 0.4], [0.9, 0.05, 0.05]])
     assert ev.score(y_true, y_pred) == pytest.approx(O.accuracy_score(y_true, y_pred)) == pytest.approx(0.75)
+
+
+def test_dataset_shards_visit_every_example_exactly_once():
+    """Shard-per-device contract (reference dataset.py:113-129): global batch k = examples [k*B, (k+1)*B), rank r reads
+    its r-th contiguous piece; ranks advance the cursor in lock step, so one pass touches every example exactly once and
+    the rank-order concatenation (Y_all, convnet.py:504) is the dataset order — what predict() relies on."""
+    x = np.arange(24, dtype=np.float32).reshape(24, 1)
+    y = np.arange(24, dtype=np.float32)
+    world, b = 2, 4
+    sets = [M.DataSet(x, y, batch_size=b * world, num_shards=world) for _ in range(world)]     # one DataSet object per process
+    seen = []
+    for step in range(3):
+        parts = [sets[r].next_batch(b, shard=r)[1] for r in range(world)]
+        seen.append(np.concatenate(parts))
+        np.testing.assert_array_equal(seen[-1], np.arange(step * 8, step * 8 + 8))
+    assert sorted(np.concatenate(seen).tolist()) == list(range(24))
+
+
+def test_loss_scale_rule_and_relower_contract():
+    """optimizers.py:102-111 scales only for a factor > 1; compile() twice must not reallocate the stores (host-side check
+    of the split: _allocate runs once)."""
+    import inspect
+    src = inspect.getsource(M.ConvNet.compile)
+    assert '_allocated' in src and 'initialize_variables' not in src

@@ -295,3 +295,31 @@ def test_blocks_to_train_freezes_variables_and_statistics_in_the_oracle():
     net.train_step(spec, state2, x, y, hp=dict(hp, update_batch_norm=True), batch_total=4)
     assert all(not np.array_equal(state2.stats[k], stats[k]) for k in stats)
     assert net.trainable_name('block_None/logits/weights', [None]) and not net.trainable_name('block_3/res_0/conv_0/weights', [None])
+
+
+def test_torch_cpu_step_matches_oracle():
+    """oracle/torch_cpu.py (the timed CPU stand-in of bench.py's cpu_baseline) performs the same training step as the NumPy
+    oracle of record: loss, updated parameters, EMA shadows and BN running statistics after two steps, float64."""
+    from oracle.torch_cpu import ResNetTorchCPU
+    spec = net.ResNetSpec.resnet50(10, width_div=8)
+    params, stats = net.init_variables(spec.variables(), seed=3, dtype=np.float64)
+    rng = np.random.default_rng(21)
+    for k in params:
+        if k.endswith('gamma'):
+            params[k] = 0.5 + rng.random(params[k].shape)
+    state = net.TrainState({k: v.copy() for k, v in params.items()}, {k: v.copy() for k, v in stats.items()})
+    tc = ResNetTorchCPU(spec, params, stats, channels_last=False)
+    for step in range(2):
+        x = rng.random((4, 32, 32, 3))
+        y = rng.integers(0, 10, 4).astype(np.float64)
+        rloss, rpred, _ = net.train_step(spec, state, x, y, batch_total=4)
+        loss, logits = tc.train_step(x, y, batch_total=4)
+        assert loss == pytest.approx(rloss, rel=1e-9)
+        np.testing.assert_allclose(torch.softmax(logits, -1).numpy(), rpred, rtol=1e-7, atol=1e-10)
+    got = tc.params_hwio()
+    for k, v in state.params.items():
+        np.testing.assert_allclose(got[k], v, rtol=1e-6, atol=1e-9, err_msg=k)
+    for k, v in state.stats.items():
+        np.testing.assert_allclose(tc.S[k].numpy(), v, rtol=1e-6, atol=1e-10, err_msg=k)
+    for k, v in state.ema_stats.items():
+        np.testing.assert_allclose(tc.ema_stats[k].numpy(), v, rtol=1e-6, atol=1e-10, err_msg=k)
