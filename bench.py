@@ -239,6 +239,27 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     return table
 
 
+def host_threads():
+    """CPU threads this process may really use: the cgroup CPU quota if there is one (a GPU box exposes 256 CPUs but gives a
+    one-GPU job a share of 16: 128 oneDNN threads on that share ran the step 2.6x slower than 8 threads on 8 cores), else
+    the scheduler affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:
+                q, p = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, (q + p // 2) // p))
+        except (OSError, ValueError):
+            pass
+    return int(os.environ.get('MCN_CPU_THREADS', n))
+
+
 def cpu_baseline():
     """CPU stand-ins for the reference's `num_gpus=0` TensorFlow path (which cannot run in this image), timed on the host
     cores in the same run — BASELINE.md §4: the same ResNet-v1.5-50 fp32 training step at B=32, 2 warm-up + 5 timed steps,
@@ -253,7 +274,8 @@ def cpu_baseline():
     B = 32
     x = rng.random((B, 224, 224, 3), dtype=np.float32)
     y = rng.integers(0, 1000, B).astype(np.float32)
-    threads = torch.get_num_threads()
+    threads = host_threads()
+    torch.set_num_threads(threads)
     tc = ResNetTorchCPU(spec, params, stats, channels_last=True)
     for _ in range(2):
         tc.train_step(x, y, batch_total=256)

@@ -34,7 +34,10 @@ extern "C" {
 
 #define MCN_VERSION 100 /* 0.1.0 */
 
-typedef enum { MCN_F32 = 0, MCN_BF16 = 1, MCN_F16 = 2 /* reserved: MCN_E_UNSUPPORTED */ } mcn_dtype;
+/* storage type of activations / activation gradients.  MCN_F16 is the reference's own low precision (tf.float16,
+ * convnet.py:63) and needs its loss scaling (optimizers.py:102-111: loss_scale / grad_scale arguments); MCN_BF16 is the
+ * MI355X-native choice (fp32 exponent range, no scaling).  Same kernels, same MFMA rate. */
+typedef enum { MCN_F32 = 0, MCN_BF16 = 1, MCN_F16 = 2 } mcn_dtype;
 typedef enum { MCN_NHWC = 0, MCN_NCHW = 1 } mcn_layout;
 typedef enum { MCN_OK = 0, MCN_E_BADARG = -1, MCN_E_UNSUPPORTED = -2, MCN_E_LAUNCH = -3, MCN_E_WORKSPACE = -4 } mcn_status;
 

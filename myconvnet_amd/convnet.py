@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from .graph import FlatStore, Graph, Variable, out_size, same_pads
+from .graph import TORCH_DT, FlatStore, Graph, Variable, out_size, same_pads
 
 
 # ---- initializers (reference passes tf.initializers.* objects) -----------------------------------------
@@ -83,8 +83,12 @@ class ConvNet(object):
         self._backbone_only = backbone_only
         self._parameters = kwargs
 
-        # reference: tf.float16 when half_precision (convnet.py:63); the MI355X build computes in bf16
-        self._dtype = 'bfloat16' if kwargs.get('half_precision', False) else 'float32'
+        # reference: tf.float16 when half_precision (convnet.py:63).  The MI355X build defaults its low precision to bf16
+        # (fp32 exponent range: no loss scaling needed); half_precision_dtype='float16' selects the reference's own type,
+        # to be used with the optimizer's loss_scaling_factor (optimizers.py:102-111) exactly as in the reference
+        lp = str(kwargs.get('half_precision_dtype', 'bfloat16'))
+        assert lp in ('bfloat16', 'float16'), 'half_precision_dtype must be bfloat16 or float16'
+        self._dtype = lp if kwargs.get('half_precision', False) else 'float32'
         self._channel_first = kwargs.get('channel_first', False)
         self._argmax_output = kwargs.get('argmax_output', False)
 
@@ -264,7 +268,7 @@ class ConvNet(object):
         H, W, C = self._input_size
         g = self.graph
         # X: prepared input; channels zero-padded to one 16-byte chunk so the stem conv takes the MFMA path
-        chunk = 8 if self._dtype == 'bfloat16' else 4
+        chunk = 4 if self._dtype == 'float32' else 8
         self.X = g.tensor((B, H, W, C), self._dtype, 'X', self._channel_first)
         self.X.cs = (C + chunk - 1) // chunk * chunk
         g.node('input', [], [self.X], image_mean=self.image_mean, scale_factor=self.scale_factor, src_nchw=self._channel_first)
@@ -351,9 +355,9 @@ class ConvNet(object):
                                   bmean=self.batch_stats[mu.offset:mu.offset + c], bvar=self.batch_stats[sg.offset:sg.offset + c])
             elif n.op == 'mulmask':
                 x = n.inputs[0]
-                ce = 8 if x.dtype == 'bfloat16' else 4
+                ce = 4 if x.dtype == 'float32' else 8
                 cols = ce if n.attrs['kind'] == 'sample' else x.shape[-1]
-                n.attrs['mask'] = torch.ones((x.shape[0], cols), dtype=torch.bfloat16 if x.dtype == 'bfloat16' else torch.float32, device=dev)
+                n.attrs['mask'] = torch.ones((x.shape[0], cols), dtype=TORCH_DT[x.dtype], device=dev)
             elif n.op == 'loss':
                 a = n.attrs
                 a['pred'] = self.pred

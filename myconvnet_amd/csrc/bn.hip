@@ -605,6 +605,9 @@ extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials
     if (dtype == MCN_BF16) {
         if (C % 8 == 0) return bn_fwd_fused_t<bf16_t, 8>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
         MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: bf16 needs C %% 8 == 0");
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) return bn_fwd_fused_t<f16_t, 8>(x, stats_partials, nparts, rows_per_partial, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: bf16 needs C %% 8 == 0");
     }
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused: dtype %d unsupported", (int)dtype);
 }
@@ -628,6 +631,9 @@ extern "C" int mcn_bn_fwd_train(const void* x, const float* gamma, const float* 
     if (dtype == MCN_BF16) {
         if (C % 8 == 0) return bn_fwd_train_t<bf16_t, 8>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
         return bn_fwd_train_t<bf16_t, 1>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) return bn_fwd_train_t<f16_t, 8>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
+        return bn_fwd_train_t<f16_t, 1>(x, gamma, beta, skip, y, relu_mask, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, M, C, eps, act, ws, st);
     }
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train: dtype %d unsupported", (int)dtype);
 }
@@ -650,6 +656,7 @@ extern "C" int mcn_channel_affine(const void* x, const float* scale, const float
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return C % 4 == 0 ? channel_affine_t<float, 4>(x, scale, shift, y, M, C, st) : channel_affine_t<float, 1>(x, scale, shift, y, M, C, st);
     if (dtype == MCN_BF16) return C % 8 == 0 ? channel_affine_t<bf16_t, 8>(x, scale, shift, y, M, C, st) : channel_affine_t<bf16_t, 1>(x, scale, shift, y, M, C, st);
+    else if (dtype == MCN_F16) return C % 8 == 0 ? channel_affine_t<f16_t, 8>(x, scale, shift, y, M, C, st) : channel_affine_t<f16_t, 1>(x, scale, shift, y, M, C, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "channel_affine: dtype %d unsupported", (int)dtype);
 }
 
@@ -711,6 +718,8 @@ extern "C" int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* 
                                             : bn_infer_t<float, 1>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st);
     if (dtype == MCN_BF16) return C % 8 == 0 ? bn_infer_t<bf16_t, 8>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st)
                                              : bn_infer_t<bf16_t, 1>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st);
+    else if (dtype == MCN_F16) return C % 8 == 0 ? bn_infer_t<f16_t, 8>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st)
+                                             : bn_infer_t<f16_t, 1>(x, gamma, beta, mean, var, skip, y, M, C, eps, act, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_infer: dtype %d unsupported", (int)dtype);
 }
 
@@ -757,6 +766,8 @@ extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const ui
                                             : bn_bwd_t<float, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
     if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
                                              : bn_bwd_t<bf16_t, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
+    else if (dtype == MCN_F16) return C % 8 == 0 ? bn_bwd_t<f16_t, 8>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
+                                             : bn_bwd_t<f16_t, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
 }
 
@@ -780,5 +791,7 @@ extern "C" int mcn_bn_bwd_frozen(const void* dy, const void* x, const void* y, c
                                             : bn_bwd_t<float, 1>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true);
     if (dtype == MCN_BF16) return C % 8 == 0 ? bn_bwd_t<bf16_t, 8>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true)
                                              : bn_bwd_t<bf16_t, 1>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true);
+    else if (dtype == MCN_F16) return C % 8 == 0 ? bn_bwd_t<f16_t, 8>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true)
+                                             : bn_bwd_t<f16_t, 1>(dy, x, y, nullptr, gamma, beta, mean, invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st, true);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_frozen: dtype %d unsupported", (int)dtype);
 }

@@ -8,6 +8,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;                              // fp16 storage: the reference's own low precision (convnet.py:63), with loss scaling
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -42,16 +45,37 @@ struct VecTraits<float> {
 template <>
 struct VecTraits<bf16_t> {
     static constexpr int CE = 8;
+    typedef bf16x8 V8;
+    typedef bf16x4 V4;
 };
+template <>
+struct VecTraits<f16_t> {
+    static constexpr int CE = 8;
+    typedef f16x8 V8;
+    typedef f16x4 V4;
+};
+// mcn_dtype of a storage type (host side: tile heuristics, workspace sizes)
+template <typename T>
+struct DtypeOf;
+template <>
+struct DtypeOf<float> { static constexpr mcn_dtype value = MCN_F32; };
+template <>
+struct DtypeOf<bf16_t> { static constexpr mcn_dtype value = MCN_BF16; };
+template <>
+struct DtypeOf<f16_t> { static constexpr mcn_dtype value = MCN_F16; };
+static inline bool mcn_dtype_ok(mcn_dtype t) { return t == MCN_F32 || t == MCN_BF16 || t == MCN_F16; }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T>
 __device__ __forceinline__ T from_f32(float v);
 template <>
 __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }          // round to nearest even, overflow -> inf (as tf.cast)
 
 // sigmoid on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1e-6 relative): the precise expf + IEEE division cost
 // ~30 VALU instructions per element, which made the BN+swish kernels VALU-bound instead of HBM-bound
@@ -73,6 +97,14 @@ struct Chunk<bf16_t> {
     bf16x8 v;
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+template <>
+struct Chunk<f16_t> {
+    static constexpr int N = 8;
+    f16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (f16_t)f; }
 };
 
 template <typename T>

@@ -77,14 +77,14 @@ static bool mfma_dgrad_ok(const Geo& g, mcn_dtype dt) { return mfma_path_ok(g, d
 static int skinny_co(const Geo& g) { return round_up(g.Cout, 8); }
 static bool skinny_ok(const Geo& g, mcn_dtype dt, int max_co) {
     return g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pB == 0 && g.pL == 0 && g.pR == 0 && g.OH == g.H && g.OW == g.W &&
-           g.xcs == g.Cin && g.Cin % ce_of(dt) == 0 && skinny_co(g) <= max_co && (dt == MCN_F32 || dt == MCN_BF16);
+           g.xcs == g.Cin && g.Cin % ce_of(dt) == 0 && skinny_co(g) <= max_co && mcn_dtype_ok(dt);
 }
 // ... and the mirror case, few INPUT channels in front of a chunked output (SE expand convs): dgrad and wgrad run the same
 // kernels with the roles of the two channel counts swapped
 static int skinny_ci(const Geo& g) { return round_up(g.Cin, 8); }
 static bool skinny_in_ok(const Geo& g, mcn_dtype dt, int max_co) {
     return g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pB == 0 && g.pL == 0 && g.pR == 0 && g.OH == g.H && g.OW == g.W &&
-           g.xcs == g.Cin && g.Cout % ce_of(dt) == 0 && skinny_ci(g) <= max_co && (dt == MCN_F32 || dt == MCN_BF16);
+           g.xcs == g.Cin && g.Cout % ce_of(dt) == 0 && skinny_ci(g) <= max_co && mcn_dtype_ok(dt);
 }
 static size_t skinny_in_w_bytes(const Geo& g) { return align_up((size_t)g.Cout * skinny_ci(g) * sizeof(float), 256); }
 #define MCN_SKINNY_MAX_CO 32        /* fwd / dgrad: accumulators per thread */
@@ -183,7 +183,7 @@ extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return 4; }    /* NT
 extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
     if (geo_from(gg, &g) != MCN_OK) return 0;
-    if (dtype != MCN_F32 && dtype != MCN_BF16) return 0;
+    if (!mcn_dtype_ok(dtype)) return 0;
     switch (op) {
         /* packed weights (unless the caller keeps them) + room for the stream-K partials */
         case MCN_CONV_FWD: return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) + MCN_SK_MAX_BYTES : (skinny_ok(g, dtype, MCN_SKINNY_MAX_CO) ? skinny_w_bytes(g) : 0);
@@ -343,7 +343,7 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
 template <typename T>
 static int launch_tn(const GemmTNParams& p, bool linear, int splits, int forced_tile, hipStream_t st) {
     int BR, BN;
-    tn_tile(p.rows, p.Nn, sizeof(T) == 4 ? MCN_F32 : MCN_BF16, linear, forced_tile, &BR, &BN);
+    tn_tile(p.rows, p.Nn, DtypeOf<T>::value, linear, forced_tile, &BR, &BN);
     const int tiles = ((p.rows + BR - 1) / BR) * ((p.Nn + BN - 1) / BN);
     const dim3 grid(tiles, splits), block(256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
@@ -470,7 +470,8 @@ extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const void* w_packe
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
     if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
-    MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd: dtype %d unsupported (fp16 reserved; use bf16)", (int)dtype);
+    else if (dtype == MCN_F16) return conv_fwd_t<f16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd: dtype %d unsupported", (int)dtype);
 }
 
 // forward conv that also emits the batch-norm statistics partials of its output (consumed by mcn_bn_fwd_train_fused)
@@ -478,7 +479,7 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     Geo g;
     if (rows_per_partial) *rows_per_partial = 0;
     if (!gg || geo_from(gg, &g)) return 0;
-    if ((dtype != MCN_F32 && dtype != MCN_BF16) || !mfma_path_ok(g, dtype)) return 0;
+    if (!mcn_dtype_ok(dtype) || !mfma_path_ok(g, dtype)) return 0;
     const long M = (long)g.N * g.OH * g.OW;
     if (M <= 0) return 0;
     const NtTile* cand = kNtCand;
@@ -497,6 +498,7 @@ extern "C" int mcn_conv2d_fwd_bnstats(const void* x, const float* w, const void*
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return conv_fwd_t<float>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st, stats_partials);
     if (dtype == MCN_BF16) return conv_fwd_t<bf16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st, stats_partials);
+    else if (dtype == MCN_F16) return conv_fwd_t<f16_t>(x, w, w_packed, bias, y, g, dtype, ws, ws_bytes, st, stats_partials);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_fwd_bnstats: dtype %d unsupported", (int)dtype);
 }
 
@@ -629,6 +631,7 @@ extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, const void* w_pa
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
     if (dtype == MCN_BF16) return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
+    else if (dtype == MCN_F16) return conv_dgrad_t<f16_t>(dy, w, w_packed, dx, g, accumulate, dtype, ws, ws_bytes, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: dtype %d unsupported", (int)dtype);
 }
 
@@ -637,7 +640,7 @@ extern "C" int mcn_conv2d_dgrad(const void* dy, const float* w, const void* w_pa
 extern "C" int32_t mcn_conv2d_dgrad_addmasked_ok(const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
     if (!gg || geo_from(gg, &g)) return 0;
-    if (dtype != MCN_F32 && dtype != MCN_BF16) return 0;
+    if (!mcn_dtype_ok(dtype)) return 0;
     return (g.SH == 1 && g.SW == 1 && g.xcs == g.Cin && mfma_dgrad_ok(g, dtype) && g.Cin % ce_of(dtype) == 0) ? 1 : 0;
 }
 extern "C" int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w, const void* w_packed, void* dx, const void* add_src,
@@ -651,6 +654,7 @@ extern "C" int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w, const 
     if (!mcn_conv2d_dgrad_addmasked_ok(gg, dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_addmasked: geometry not eligible (see mcn_conv2d_dgrad_addmasked_ok)");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
+    if (dtype == MCN_F16) return conv_dgrad_t<f16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
     return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
 }
 
@@ -766,13 +770,14 @@ extern "C" int mcn_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MCN_F32) return conv_wgrad_t<float>(x, dy, dw, dbias, g, grad_scale, dtype, ws, ws_bytes, st);
     if (dtype == MCN_BF16) return conv_wgrad_t<bf16_t>(x, dy, dw, dbias, g, grad_scale, dtype, ws, ws_bytes, st);
+    else if (dtype == MCN_F16) return conv_wgrad_t<f16_t>(x, dy, dw, dbias, g, grad_scale, dtype, ws, ws_bytes, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_wgrad: dtype %d unsupported", (int)dtype);
 }
 
 // ---- packed operands kept by the caller: sizes, one-launch batch packing, kernel introspection --------------------------------
 extern "C" size_t mcn_conv2d_packed_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
-    if (geo_from(gg, &g) != MCN_OK || (dtype != MCN_F32 && dtype != MCN_BF16)) return 0;
+    if (geo_from(gg, &g) != MCN_OK || !mcn_dtype_ok(dtype)) return 0;
     if (op == MCN_CONV_FWD) return mfma_path_ok(g, dtype) ? fwd_pack_bytes(g, dtype) : 0;
     if (op == MCN_CONV_DGRAD) return mfma_dgrad_ok(g, dtype) ? dgrad_pack_bytes(g, dtype) : 0;
     return 0;
@@ -849,7 +854,7 @@ extern "C" int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njo
                                            int32_t* ndesc) {
     if (!jobs || !host_table || !ndesc || njobs < 0) MCN_FAIL(MCN_E_BADARG, "pack_table_build: bad argument");
     if (bytes < mcn_conv2d_pack_table_bytes(jobs, njobs)) MCN_FAIL(MCN_E_WORKSPACE, "pack_table_build: table buffer too small");
-    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "pack_table_build: dtype %d unsupported", (int)dtype);
+    if (!mcn_dtype_ok(dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "pack_table_build: dtype %d unsupported", (int)dtype);
     PackParams* out = (PackParams*)host_table;
     int n = 0;
     for (int i = 0; i < njobs; ++i) {
@@ -868,6 +873,7 @@ extern "C" int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dty
     const dim3 grid(64, ndesc), block(256);
     if (dtype == MCN_F32) hipLaunchKernelGGL((pack_weights_batch_kernel<float>), grid, block, 0, (hipStream_t)stream, (const PackParams*)dev_table);
     else if (dtype == MCN_BF16) hipLaunchKernelGGL((pack_weights_batch_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const PackParams*)dev_table);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((pack_weights_batch_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (const PackParams*)dev_table);
     else MCN_FAIL(MCN_E_UNSUPPORTED, "pack_run: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -879,7 +885,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     int rc = geo_from(gg, &g);
     if (rc) return rc;
     if (!buf || buflen < 64) MCN_FAIL(MCN_E_BADARG, "kernel_name: buffer too small");
-    const char* tn = dtype == MCN_F32 ? "float" : "bf16";
+    const char* tn = dtype == MCN_F32 ? "float" : (dtype == MCN_F16 ? "_Float16" : "bf16");
     const int ce = ce_of(dtype);
     const NtTile* cand = kNtCand;
     if (op == MCN_CONV_FWD) {
@@ -944,7 +950,7 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
         snprintf(buf, buflen, "%s:%d\n", one, g.KH * g.KW);
         return 1;
     }
-    const char* tn = dtype == MCN_F32 ? "float" : "bf16";
+    const char* tn = dtype == MCN_F32 ? "float" : (dtype == MCN_F16 ? "_Float16" : "bf16");
     const int ce = ce_of(dtype), cpt = round_up(g.Cout, ce) / ce;
     size_t used = 0;
     int nl = 0;
@@ -978,7 +984,7 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
 // (1 = every tile runs its whole K loop; tests and the bench use it to know which layers are split)
 extern "C" int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
-    if (!gg || geo_from(gg, &g) || (dtype != MCN_F32 && dtype != MCN_BF16) || (g.tile & MCN_TILE_NOSPLIT)) return 1;
+    if (!gg || geo_from(gg, &g) || !mcn_dtype_ok(dtype) || (g.tile & MCN_TILE_NOSPLIT)) return 1;
     const int ce = ce_of(dtype);
     long M;
     int Nn, nchunks;

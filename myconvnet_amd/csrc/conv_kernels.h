@@ -97,6 +97,20 @@ struct MmaNT<bf16_t> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
     }
 };
+// fp16: the bf16 policy with the f16 MFMA (same cycles, same operand / accumulator lane maps)
+template <>
+struct MmaNT<f16_t> {
+    static constexpr int MT = 16;
+    static constexpr int SLABS = 2;
+    static constexpr int CPS = 4;
+    typedef f32x4 Acc;
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int frag_chunk(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ void mma(Acc& acc, const Frag& w, const Frag& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, acc, 0, 0, 0);
+    }
+};
 // fp32: 32x32x2; a 16-byte fragment (4 consecutive k) feeds 4 MFMAs (k pairs {e, 4+e})
 template <>
 struct MmaNT<float> {
@@ -686,10 +700,25 @@ struct TNCfg<bf16_t> {
     static constexpr int MT = 16;
 };
 template <>
+struct TNCfg<f16_t> {
+    static constexpr int KP = 64;
+    static constexpr int MT = 16;
+};
+template <>
 struct TNCfg<float> {
     static constexpr int KP = 32;
     static constexpr int MT = 32;
 };
+// transposing LDS read + MFMA of the 2-byte storage types
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p, bf16_t) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+typedef __fp16 fp16v4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));      // the builtin's own vector type (same bits as f16x4)
+__device__ __forceinline__ f16x4 lds_tr16(const char* p, f16_t) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16v4_t*)p));
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // bf16 pixel-major tile: row stride RS bytes, 32-byte granule g of pixel row p stored at granule g ^ key(p)
 __device__ __forceinline__ int tn_key(int p) { return (p & 3) | (((p >> 3) & 1) << 2); }
@@ -817,7 +846,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
             const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
 #pragma unroll
             for (int s = 0; s < KP / 32; ++s) {
-                bf16x4 xh[2][TR], dh[2][TNn];
+                typename VecTraits<T>::V4 xh[2][TR], dh[2][TNn];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int pix = 32 * s + 8 * g + 4 * h + q;
@@ -825,14 +854,12 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         const int gran = wr * (WTR / 16) + i;
-                        xh[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(xs + pix * XRS + ((gran ^ (key & XGM)) << 5) + 8 * pp));
+                        xh[h][i] = lds_tr16(xs + pix * XRS + ((gran ^ (key & XGM)) << 5) + 8 * pp, T{});
                     }
 #pragma unroll
                     for (int j = 0; j < TNn; ++j) {
                         const int gran = wc * (WTN / 16) + j;
-                        dh[h][j] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(ds + pix * DRS + ((gran ^ (key & DGM)) << 5) + 8 * pp));
+                        dh[h][j] = lds_tr16(ds + pix * DRS + ((gran ^ (key & DGM)) << 5) + 8 * pp, T{});
                     }
                 }
 #pragma unroll
@@ -840,9 +867,9 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
 #pragma unroll
                     for (int j = 0; j < TNn; ++j) {
                         f32x4 a = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        const bf16x8 xa = __builtin_shufflevector(xh[0][i], xh[1][i], 0, 1, 2, 3, 4, 5, 6, 7);
-                        const bf16x8 db = __builtin_shufflevector(dh[0][j], dh[1][j], 0, 1, 2, 3, 4, 5, 6, 7);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, db, a, 0, 0, 0);
+                        const typename VecTraits<T>::V8 xa = __builtin_shufflevector(xh[0][i], xh[1][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const typename VecTraits<T>::V8 db = __builtin_shufflevector(dh[0][j], dh[1][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                        a = mfma16(xa, db, a);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[i][j][e] = a[e];
                     }

@@ -17,7 +17,7 @@ struct DwParams {
 
 template <typename T>
 __device__ __forceinline__ float round_w(float w) {
-    return sizeof(T) == 2 ? (float)(bf16_t)w : w;
+    return to_f32(from_f32<T>(w));       // the weight as the conv kernels see it (rounded to the storage type)
 }
 
 // largest divisor of n that is <= cap (>= 1)
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, co
     constexpr int CE = VecTraits<T>::CE;
     extern __shared__ float sw[];                                // [taps][TX*CE]
     const int KH = K ? K : p.KH, KW = K ? K : p.KW;
+    constexpr int UNR = K ? K : 1;                   // K = 0: run-time filter size, nothing to unroll
     const int taps = KH * KW;
     const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
     const int cch = p.C / CE;
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int i = 0; i < CE; ++i) acc[i] = 0.f;
         const int iy0 = oy * p.SH - p.padT, ix0 = ox * p.SW - p.padL;
-#pragma unroll
+#pragma unroll UNR
         for (int ky = 0; ky < KH; ++ky) {
             const int iy = iy0 + ky * p.DH;
             if ((unsigned)iy >= (unsigned)p.H) continue;
-#pragma unroll
+#pragma unroll UNR
             for (int kx = 0; kx < KW; ++kx) {
                 const int ix = ix0 + kx * p.DW;
                 if ((unsigned)ix >= (unsigned)p.W) continue;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
     constexpr int CE = VecTraits<T>::CE;
     extern __shared__ float sw[];
     const int KH = K ? K : p.KH, KW = K ? K : p.KW;
+    constexpr int UNR = K ? K : 1;                   // K = 0: run-time filter size, nothing to unroll
     const int taps = KH * KW;
     const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
     const int cch = p.C / CE;
@@ -228,13 +230,13 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
         float acc[CE];
 #pragma unroll
         for (int i = 0; i < CE; ++i) acc[i] = 0.f;
-#pragma unroll
+#pragma unroll UNR
         for (int ky = 0; ky < KH; ++ky) {
             const int ny = iy + p.padT - ky * p.DH;
             if (ny < 0 || ny % p.SH) continue;
             const int oy = ny / p.SH;
             if (oy >= p.OH) continue;
-#pragma unroll
+#pragma unroll UNR
             for (int kx = 0; kx < KW; ++kx) {
                 const int nx = ix + p.padL - kx * p.DW;
                 if (nx < 0 || nx % p.SW) continue;
@@ -361,6 +363,11 @@ __device__ __forceinline__ void load4<float>(const float* p, float* v) {
 template <>
 __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
     const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <>
+__device__ __forceinline__ void load4<f16_t>(const f16_t* p, float* v) {
+    const f16x4 t = *reinterpret_cast<const f16x4*>(p);
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 
@@ -651,7 +658,7 @@ static int dw_check(const mcn_conv_geom* g, mcn_dtype dt, const char* what) {
     if (g->N < 0 || g->H <= 0 || g->W <= 0 || g->Cin <= 0 || g->KH <= 0 || g->KW <= 0 || g->SH <= 0 || g->SW <= 0 || g->DH <= 0 || g->DW <= 0)
         MCN_FAIL(MCN_E_BADARG, "%s: bad geometry", what);
     if (g->Cout != g->Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: channel multiplier %d/%d != 1 is not built", what, g->Cout, g->Cin);
-    if (dt != MCN_F32 && dt != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", what, (int)dt);
+    if (!mcn_dtype_ok(dt)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", what, (int)dt);
     if (g->Cin % (dt == MCN_F32 ? 4 : 8)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: C=%d must be a multiple of the 16-byte chunk", what, g->Cin);
     if (g->x_cs && g->x_cs != g->Cin) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: strided input channels are not built", what);
     if (g->KH * g->KW > 121) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: filter too large", what);
@@ -708,6 +715,7 @@ static int dw_fwd_t(const void* x, const float* w, void* y, const mcn_conv_geom*
 extern "C" int mcn_dwconv2d_fwd(const void* x, const float* w, void* y, const mcn_conv_geom* g, mcn_dtype dtype, void* stream) {
     if (int rc = dw_check(g, dtype, "dwconv2d_fwd")) return rc;
     if (!x || !w || !y) MCN_FAIL(MCN_E_BADARG, "dwconv2d_fwd: null pointer");
+    if (dtype == MCN_F16) return dw_fwd_t<f16_t>(x, w, y, g, (hipStream_t)stream);
     return dtype == MCN_F32 ? dw_fwd_t<float>(x, w, y, g, (hipStream_t)stream) : dw_fwd_t<bf16_t>(x, w, y, g, (hipStream_t)stream);
 }
 
@@ -752,6 +760,7 @@ extern "C" int mcn_dwconv2d_dgrad(const void* dy, const float* w, void* dx, cons
                                   void* stream) {
     if (int rc = dw_check(g, dtype, "dwconv2d_dgrad")) return rc;
     if (!dy || !w || !dx) MCN_FAIL(MCN_E_BADARG, "dwconv2d_dgrad: null pointer");
+    if (dtype == MCN_F16) return dw_dgrad_t<f16_t>(dy, w, dx, g, accumulate, (hipStream_t)stream);
     return dtype == MCN_F32 ? dw_dgrad_t<float>(dy, w, dx, g, accumulate, (hipStream_t)stream)
                             : dw_dgrad_t<bf16_t>(dy, w, dx, g, accumulate, (hipStream_t)stream);
 }
@@ -764,8 +773,8 @@ static bool dw_wgrad_rows() {
 static DwParams dw_wgrad_params(const mcn_conv_geom* g, mcn_dtype dtype, unsigned* gx, unsigned* gy) {
     unsigned a, b;
     DwParams p = dw_params(g, 4, false, &a, &b);
-    const int ce = dtype == MCN_BF16 ? 8 : 4;
-    if (dw_wgrad_rows() && dw_strip_ok(p) && p.C % ce == 0 && dtype == MCN_BF16 && p.KH == 5) {    // (measured: 3x3 and fp32 lose with it)
+    const int ce = dtype == MCN_F32 ? 4 : 8;
+    if (dw_wgrad_rows() && dw_strip_ok(p) && p.C % ce == 0 && dtype != MCN_F32 && p.KH == 5) {    // (measured: 3x3 and fp32 lose with it)
         // row-split kernel: TX chunks x TY rows of threads, TY / K strips side by side
         const int cch = p.C / ce;
         p.TX = best_tx(cch, 32);
@@ -798,7 +807,7 @@ extern "C" size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom* g, mcn_dtype
 template <typename T>
 static int dw_wgrad_t(const void* x, const void* dy, float* dw, const mcn_conv_geom* g, float scale, void* ws, hipStream_t st) {
     unsigned gx, gy;
-    const DwParams p = dw_wgrad_params(g, sizeof(T) == 2 ? MCN_BF16 : MCN_F32, &gx, &gy);
+    const DwParams p = dw_wgrad_params(g, DtypeOf<T>::value, &gx, &gy);
     const long n = (long)p.KH * p.KW * p.C;
     if (p.npix == 0) {
         if (hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "dwconv2d_wgrad: memset failed");
@@ -836,6 +845,7 @@ extern "C" int mcn_dwconv2d_wgrad(const void* x, const void* dy, float* dw, cons
     if (int rc = dw_check(g, dtype, "dwconv2d_wgrad")) return rc;
     if (!x || !dy || !dw) MCN_FAIL(MCN_E_BADARG, "dwconv2d_wgrad: null pointer");
     if (!ws || ws_bytes < mcn_dwconv2d_workspace_bytes(g, dtype)) MCN_FAIL(MCN_E_WORKSPACE, "dwconv2d_wgrad: workspace too small");
+    if (dtype == MCN_F16) return dw_wgrad_t<f16_t>(x, dy, dw, g, grad_scale, ws, (hipStream_t)stream);
     return dtype == MCN_F32 ? dw_wgrad_t<float>(x, dy, dw, g, grad_scale, ws, (hipStream_t)stream)
                             : dw_wgrad_t<bf16_t>(x, dy, dw, g, grad_scale, ws, (hipStream_t)stream);
 }
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(256) void chscale_fwd_kernel(const T* __restrict__ 
 }
 extern "C" int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream) {
     if (!x || !m || !y || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_fwd: bad argument");
-    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: dtype %d unsupported", (int)dtype);
+    if (!mcn_dtype_ok(dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: dtype %d unsupported", (int)dtype);
     const int ce = dtype == MCN_F32 ? 4 : 8;
     if (C % ce) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: C=%d must be a multiple of the 16-byte chunk", C);
     const long total = (long)N * HW * (C / ce);
@@ -865,6 +875,7 @@ extern "C" int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int3
     long b = (total + 255) / 256;
     if (b > 4096) b = 4096;
     if (dtype == MCN_F32) hipLaunchKernelGGL((chscale_fwd_kernel<float>), dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)m, (float*)y, total, (long)HW, C / ce);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((chscale_fwd_kernel<f16_t>), dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, (const f16_t*)m, (f16_t*)y, total, (long)HW, C / ce);
     else hipLaunchKernelGGL((chscale_fwd_kernel<bf16_t>), dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)m, (bf16_t*)y, total, (long)HW, C / ce);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -918,7 +929,7 @@ __global__ __launch_bounds__(256) void chscale_bwd_kernel(const T* __restrict__ 
 extern "C" int mcn_channel_scale_bwd(const void* dy, const void* x, const void* m, void* dx, void* dm, int32_t N, int64_t HW, int32_t C,
                                      mcn_dtype dtype, void* stream) {
     if (!dy || !x || !m || !dx || !dm || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_bwd: bad argument");
-    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd: dtype %d unsupported", (int)dtype);
+    if (!mcn_dtype_ok(dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd: dtype %d unsupported", (int)dtype);
     const int ce = dtype == MCN_F32 ? 4 : 8;
     if (C % ce) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd: C=%d must be a multiple of the 16-byte chunk", C);
     if (N == 0) return MCN_OK;
@@ -927,6 +938,7 @@ extern "C" int mcn_channel_scale_bwd(const void* dy, const void* x, const void* 
     const dim3 grid((unsigned)((cch + TX - 1) / TX), (unsigned)N), block(256);
     const size_t lds = (size_t)TY * TX * ce * sizeof(float);
     if (dtype == MCN_F32) hipLaunchKernelGGL((chscale_bwd_kernel<float>), grid, block, lds, (hipStream_t)stream, (const float*)dy, (const float*)x, (const float*)m, (float*)dx, (float*)dm, (long)HW, C, TX, TY);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((chscale_bwd_kernel<f16_t>), grid, block, lds, (hipStream_t)stream, (const f16_t*)dy, (const f16_t*)x, (const f16_t*)m, (f16_t*)dx, (f16_t*)dm, (long)HW, C, TX, TY);
     else hipLaunchKernelGGL((chscale_bwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)m, (bf16_t*)dx, (bf16_t*)dm, (long)HW, C, TX, TY);
     MCN_CHECK_LAUNCH();
     return MCN_OK;

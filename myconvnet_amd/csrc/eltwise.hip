@@ -55,6 +55,8 @@ static int ew_dispatch(const void* a, const void* b, void* y, long n, mcn_dtype 
         hipLaunchKernelGGL((ew_kernel<float, OP>), dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, n);
     else if (dt == MCN_BF16)
         hipLaunchKernelGGL((ew_kernel<bf16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+    else if (dt == MCN_F16)
+        hipLaunchKernelGGL((ew_kernel<f16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)y, n);
     else
         MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", name, (int)dt);
     MCN_CHECK_LAUNCH();
@@ -135,7 +137,9 @@ extern "C" int mcn_cast(const void* src, mcn_dtype sd, void* dst, mcn_dtype dd, 
     const dim3 grid(ew_blocks(n / 4 + 1)), block(256);
     if (sd == MCN_F32 && dd == MCN_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, st, (const float*)src, (bf16_t*)dst, (long)n);
     else if (sd == MCN_BF16 && dd == MCN_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, (float*)dst, (long)n);
-    else if (sd == dd && (sd == MCN_F32 || sd == MCN_BF16)) {
+    else if (sd == MCN_F32 && dd == MCN_F16) hipLaunchKernelGGL((cast_kernel<float, f16_t>), grid, block, 0, st, (const float*)src, (f16_t*)dst, (long)n);
+    else if (sd == MCN_F16 && dd == MCN_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), grid, block, 0, st, (const f16_t*)src, (float*)dst, (long)n);
+    else if (sd == dd && mcn_dtype_ok(sd)) {
         if (hipMemcpyAsync(dst, src, (size_t)n * mcn_dtype_size(sd), hipMemcpyDeviceToDevice, st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "cast: copy failed");
         return MCN_OK;
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "cast: %d -> %d unsupported", (int)sd, (int)dd);
@@ -189,6 +193,9 @@ extern "C" int mcn_input_prep(const float* x, void* y, int32_t N, int32_t H, int
     } else if (dtype == MCN_BF16) {
         if (nchw) hipLaunchKernelGGL((input_prep_kernel<bf16_t, true>), grid, block, 0, st, x, (bf16_t*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
         else hipLaunchKernelGGL((input_prep_kernel<bf16_t, false>), grid, block, 0, st, x, (bf16_t*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
+    } else if (dtype == MCN_F16) {
+        if (nchw) hipLaunchKernelGGL((input_prep_kernel<f16_t, true>), grid, block, 0, st, x, (f16_t*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
+        else hipLaunchKernelGGL((input_prep_kernel<f16_t, false>), grid, block, 0, st, x, (f16_t*)y, npix, H * W, C, out_cs, image_mean, scale_factor);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "input_prep: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;

@@ -296,6 +296,9 @@ static int pool_check(const void* a, const void* b, int N, int H, int W, int C, 
         } else if (dtype == MCN_BF16) {                                                                          \
             if (C % 8 == 0) hipLaunchKernelGGL((KERNEL<bf16_t, 8>), dim3(pool_blocks((TOTAL) / 8)), dim3(256), 0, st, __VA_ARGS__); \
             else hipLaunchKernelGGL((KERNEL<bf16_t, 1>), dim3(pool_blocks(TOTAL)), dim3(256), 0, st, __VA_ARGS__); \
+        } else if (dtype == MCN_F16) {                                                                           \
+            if (C % 8 == 0) hipLaunchKernelGGL((KERNEL<f16_t, 8>), dim3(pool_blocks((TOTAL) / 8)), dim3(256), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<f16_t, 1>), dim3(pool_blocks(TOTAL)), dim3(256), 0, st, __VA_ARGS__); \
         } else MCN_FAIL(MCN_E_UNSUPPORTED, "pool: dtype %d unsupported", (int)dtype);                            \
         MCN_CHECK_LAUNCH();                                                                                      \
     } while (0)
@@ -317,6 +320,9 @@ extern "C" int mcn_maxpool_fwd(const void* x, void* y, int8_t* argmax, int32_t N
     } else if (dtype == MCN_BF16) {
         if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p);
         else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_fwd: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -402,6 +408,12 @@ extern "C" int mcn_maxpool_bwd(const void* dy, const int8_t* argmax, void* dx, i
         else if (C % 8 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
         else if (C % 8 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
         else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, p);
+    } else if (dtype == MCN_F16) {
+        if (total >= 0xffffffffL) MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: more than 2^32 elements");
+        if (C % 8 == 0 && blockable) hipLaunchKernelGGL((maxpool_bwd_3x3s2_block_kernel<f16_t, 8>), dim3(pool_blocks(total / 32)), dim3(256), 0, st, (const f16_t*)dy, argmax, (f16_t*)dx, p);
+        else if (C % 8 == 0 && KH == 3 && KW == 3 && SH == 2 && SW == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<f16_t, 8, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)dy, argmax, (f16_t*)dx, p);
+        else if (C % 8 == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<f16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)dy, argmax, (f16_t*)dx, p);
+        else hipLaunchKernelGGL((maxpool_bwd_kernel<f16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, argmax, (f16_t*)dx, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_bwd: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -420,6 +432,9 @@ extern "C" int mcn_avgpool_fwd(const void* x, void* y, int32_t N, int32_t H, int
     } else if (dtype == MCN_BF16) {
         if (C % 8 == 0) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
         else hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((avgpool_fwd_kernel<f16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, p);
+        else hipLaunchKernelGGL((avgpool_fwd_kernel<f16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "avgpool_fwd: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -438,6 +453,9 @@ extern "C" int mcn_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, i
     } else if (dtype == MCN_BF16) {
         if (C % 8 == 0) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p);
         else hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((avgpool_bwd_kernel<f16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, p);
+        else hipLaunchKernelGGL((avgpool_bwd_kernel<f16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "avgpool_bwd: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -459,6 +477,8 @@ extern "C" int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t
         if (C % 4 == 0) GAP_FWD(float, 4); else GAP_FWD(float, 1);
     } else if (dtype == MCN_BF16) {
         if (C % 8 == 0) GAP_FWD(bf16_t, 8); else GAP_FWD(bf16_t, 1);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) GAP_FWD(f16_t, 8); else GAP_FWD(f16_t, 1);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_fwd: dtype %d unsupported", (int)dtype);
 #undef GAP_FWD
     MCN_CHECK_LAUNCH();
@@ -475,6 +495,9 @@ extern "C" int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, i
     } else if (dtype == MCN_BF16) {
         if (C % 8 == 0) hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
         else hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((gap_bwd_kernel<f16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, N, HW, C);
+        else hipLaunchKernelGGL((gap_bwd_kernel<f16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, N, HW, C);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_bwd_acc: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -490,6 +513,9 @@ extern "C" int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32
     } else if (dtype == MCN_BF16) {
         if (C % 8 == 0) hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
         else hipLaunchKernelGGL((gap_bwd_kernel<bf16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((gap_bwd_kernel<f16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, N, HW, C);
+        else hipLaunchKernelGGL((gap_bwd_kernel<f16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, N, HW, C);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_bwd: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;

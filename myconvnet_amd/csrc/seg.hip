@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void resize_fwd_pix_kernel(const T* __restrict
 }
 static int resize_setup(const void* a, const void* b, int N, int H, int W, int C, int OH, int OW, int align, mcn_dtype dt, ResizeParams* p, const char* nm) {
     if (!a || !b || N < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) MCN_FAIL(MCN_E_BADARG, "%s: bad argument", nm);
-    if (dt != MCN_F32 && dt != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", nm, (int)dt);
+    if (!mcn_dtype_ok(dt)) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", nm, (int)dt);
     p->N = N; p->H = H; p->W = W; p->C = C; p->OH = OH; p->OW = OW; p->align = align ? 1 : 0;
     if (align) {
         p->sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
@@ -178,6 +178,7 @@ extern "C" int mcn_resize_bilinear_fwd(const void* x, void* y, int32_t N, int32_
     if (ce == 1 && C <= MCN_RESIZE_PIX_MAXC && (long)N * OH * OW < 0x7fffffffL) {
         const long npix = (long)N * OH * OW;
         if (dtype == MCN_F32) hipLaunchKernelGGL((resize_fwd_pix_kernel<float>), dim3(seg_blocks(npix)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+        else if (dtype == MCN_F16) hipLaunchKernelGGL((resize_fwd_pix_kernel<f16_t>), dim3(seg_blocks(npix)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, p);
         else hipLaunchKernelGGL((resize_fwd_pix_kernel<bf16_t>), dim3(seg_blocks(npix)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
         MCN_CHECK_LAUNCH();
         return MCN_OK;
@@ -185,8 +186,12 @@ extern "C" int mcn_resize_bilinear_fwd(const void* x, void* y, int32_t N, int32_
     if (dtype == MCN_F32) {
         if (ce == 4) hipLaunchKernelGGL((resize_fwd_kernel<float, 4>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
         else hipLaunchKernelGGL((resize_fwd_kernel<float, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, p);
+    } else if (dtype == MCN_F16) {
+        if (ce == 8) hipLaunchKernelGGL((resize_fwd_kernel<f16_t, 8>), dim3(seg_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, p);
+        else hipLaunchKernelGGL((resize_fwd_kernel<f16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, p);
     } else {
         if (ce == 8) hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 8>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
+        else if (dtype == MCN_F16) hipLaunchKernelGGL((resize_fwd_kernel<f16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, p);
         else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, p);
     }
     MCN_CHECK_LAUNCH();
@@ -206,8 +211,12 @@ extern "C" int mcn_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
     if (dtype == MCN_F32) {
         if (ce == 4) hipLaunchKernelGGL((resize_bwd_kernel<float, 4>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, p, isy, isx);
         else hipLaunchKernelGGL((resize_bwd_kernel<float, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const float*)dy, (float*)dx, p, isy, isx);
+    } else if (dtype == MCN_F16) {
+        if (ce == 8) hipLaunchKernelGGL((resize_bwd_kernel<f16_t, 8>), dim3(seg_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, p, isy, isx);
+        else hipLaunchKernelGGL((resize_bwd_kernel<f16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, p, isy, isx);
     } else {
         if (ce == 8) hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 8>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p, isy, isx);
+        else if (dtype == MCN_F16) hipLaunchKernelGGL((resize_bwd_kernel<f16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, p, isy, isx);
         else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 1>), dim3(seg_blocks(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, p, isy, isx);
     }
     MCN_CHECK_LAUNCH();
@@ -230,13 +239,14 @@ extern "C" int mcn_copy_channels(const void* src, int32_t src_stride, int32_t sr
                                  int32_t C, mcn_dtype dtype, void* stream) {
     if (!src || !dst || M < 0 || C <= 0 || src_offset < 0 || dst_offset < 0 || src_offset + C > src_stride || dst_offset + C > dst_stride)
         MCN_FAIL(MCN_E_BADARG, "copy_channels: bad argument");
-    if (dtype != MCN_F32 && dtype != MCN_BF16) MCN_FAIL(MCN_E_UNSUPPORTED, "copy_channels: dtype %d unsupported", (int)dtype);
+    if (!mcn_dtype_ok(dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "copy_channels: dtype %d unsupported", (int)dtype);
     const int ce = dtype == MCN_F32 ? 4 : 8;
     if (C % ce || src_stride % ce || dst_stride % ce || src_offset % ce || dst_offset % ce)
         MCN_FAIL(MCN_E_UNSUPPORTED, "copy_channels: channel counts / offsets must be multiples of the 16-byte chunk");
     if (M == 0) return MCN_OK;
     const long total = (long)M * (C / ce);
     if (dtype == MCN_F32) hipLaunchKernelGGL((copy_channels_kernel<float>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, src_stride, src_offset, (float*)dst, dst_stride, dst_offset, (long)M, C);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((copy_channels_kernel<f16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)src, src_stride, src_offset, (f16_t*)dst, dst_stride, dst_offset, (long)M, C);
     else hipLaunchKernelGGL((copy_channels_kernel<bf16_t>), dim3(seg_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_stride, src_offset, (bf16_t*)dst, dst_stride, dst_offset, (long)M, C);
     MCN_CHECK_LAUNCH();
     return MCN_OK;

@@ -33,7 +33,7 @@ class Lowering(object):
         self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
         # BN statistics in the conv epilogue: on for bf16 (+2-3 % end to end); fp32's 1x1 convs are output-bound and the
         # epilogue costs them what the skipped statistics pass saves, so fp32 keeps the separate pass unless asked
-        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', _env_flag('MCN_FUSE_BN_STATS', graph.dtype == 'bfloat16')))
+        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', _env_flag('MCN_FUSE_BN_STATS', graph.dtype != 'float32')))
         # (+1 % in bf16, +0.6 % in fp32 since the accumulate epilogue issues its loads in one batch)
         self.defer_dskip = bool(model._parameters.get('defer_dskip', _env_flag('MCN_DEFER_DSKIP', True)))
         self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
@@ -275,7 +275,7 @@ class Lowering(object):
         self.keep.append(gm)
         bn = self._bn_consumer(n)
         rows = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, None)) if bn is not None else 0
-        if rows > 0 and y.shape[-1] % (8 if self.g.dtype == 'bfloat16' else 4) == 0:
+        if rows > 0 and y.shape[-1] % (4 if self.g.dtype == 'float32' else 8) == 0:
             cand = []
             keep = gm.tile
             for t in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_FWD) + 1):     # room for any tile the autotuner may pin

@@ -13,8 +13,8 @@ import torch
 
 from . import _ffi
 
-TORCH_DT = {'float32': torch.float32, 'bfloat16': torch.bfloat16}
-MCN_DT = {'float32': _ffi.F32, 'bfloat16': _ffi.BF16}
+TORCH_DT = {'float32': torch.float32, 'bfloat16': torch.bfloat16, 'float16': torch.float16}
+MCN_DT = {'float32': _ffi.F32, 'bfloat16': _ffi.BF16, 'float16': _ffi.F16}
 
 
 def same_pads(in_size, k, s, d=1):

@@ -14,7 +14,7 @@ class SegNet(ConvNet):
         B = self.device_batch
         H, W, C = self._input_size
         g = self.graph
-        chunk = 8 if self._dtype == 'bfloat16' else 4
+        chunk = 4 if self._dtype == 'float32' else 8
         self.X = g.tensor((B, H, W, C), self._dtype, 'X', self._channel_first)
         self.X.cs = (C + chunk - 1) // chunk * chunk
         g.node('input', [], [self.X], image_mean=self.image_mean, scale_factor=self.scale_factor, src_nchw=self._channel_first)

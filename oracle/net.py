@@ -681,6 +681,11 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
         pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
     weights = [v for k, v in params.items() if _regularised(k, hp)]
     loss = float(sm_loss) + ops.l2_reg_loss(weights, hp['l2_reg'])
+    # loss scaling (optimizers.py:102-111): the loss is multiplied by the factor (only when > 1) before differentiation, so every
+    # activation gradient is stored scaled — what matters under fp16 storage — and the parameter gradients are divided again
+    ls = float(hp.get('loss_scaling_factor', 1.0))
+    t.loss_scale = ls if ls > 1.0 else 1.0
+    dlogits = dlogits * t.loss_scale
     out.g = dlogits if quant is None else quant(dlogits)
     return t, out, pred, loss, onehot
 
@@ -698,6 +703,8 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
     for (xr, yf) in towers:
         t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant)
         g = t.backward()
+        if t.loss_scale != 1.0:
+            g = {k: v / t.loss_scale for k, v in g.items()}
         g = {k: v for k, v in g.items() if trainable_name(k, hp.get('blocks_to_train'))}      # update_vars = tf.trainable_variables(), optimizers.py:53,106
         if hp.get('gradient_threshold') is not None:
             # the reference differentiates the full loss (CE + L2) and clips per tower (optimizers.py:106-113)

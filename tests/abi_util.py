@@ -10,8 +10,8 @@ from myconvnet_amd._ffi import lib
 from oracle import ops as O
 
 DEV = 'cuda:0'
-TDT = {'float32': torch.float32, 'bfloat16': torch.bfloat16}
-MDT = {'float32': _ffi.F32, 'bfloat16': _ffi.BF16}
+TDT = {'float32': torch.float32, 'bfloat16': torch.bfloat16, 'float16': torch.float16}
+MDT = {'float32': _ffi.F32, 'bfloat16': _ffi.BF16, 'float16': _ffi.F16}
 
 
 def dev(a, dtype='float32'):
@@ -30,6 +30,13 @@ def stream():
 def bf16_round(a):
     """Round an fp32/fp64 array to bf16 precision (what the device stores), returned as float64."""
     return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
+def lp_round(a, dtype):
+    """Round to the storage precision of `dtype` (what the device stores), returned as float64."""
+    if dtype == 'float32':
+        return np.asarray(a, dtype=np.float32).astype(np.float64)
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(TDT[dtype]).float().numpy().astype(np.float64)
 
 
 def geom(x_shape, w_shape, stride, padding, dilation=1, x_cs=0):

@@ -44,8 +44,10 @@ def test_argument_validation_without_gpu():
     g = _ffi.conv_geom(1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))
     assert lib.mcn_conv2d_fwd(0, 0, 0, 0, 0, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_BADARG
     assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NCHW, 0, 0, 0) == _ffi.E_UNSUPPORTED
-    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F16, _ffi.NHWC, 0, 0, 0) == _ffi.E_UNSUPPORTED
-    assert 'fp16' in _ffi.last_error()
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), 7, _ffi.NHWC, 0, 0, 0) == _ffi.E_UNSUPPORTED      # no such dtype
+    assert 'dtype 7' in _ffi.last_error()
+    assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F16, _ffi.NHWC, 0, 0, 0) == _ffi.E_WORKSPACE        # fp16 is a storage type (f-4)
+    assert lib.mcn_conv2d_kernel_name(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F16, ctypes.create_string_buffer(96), 96) == 1
     assert lib.mcn_conv2d_fwd(1, 1, 0, 0, 1, ctypes.byref(g), _ffi.F32, _ffi.NHWC, 0, 0, 0) == _ffi.E_WORKSPACE
     assert lib.mcn_conv2d_packed_bytes(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) >= 16 * 9 * 16 * 4
     buf = ctypes.create_string_buffer(96)

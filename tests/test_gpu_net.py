@@ -29,7 +29,8 @@ def make_resnet(kind, dtype, fuse, batch=BATCH, size=64, classes=10, **kw):
     import myconvnet_amd as M
     cls = M.ResNet50 if kind == 50 else M.ResNet18
     spec = ON.ResNetSpec.resnet50(classes, 8) if kind == 50 else ON.ResNetSpec.resnet18(classes, 8)
-    model = cls([size, size, 3], classes, batch_size=batch, width_div=8, fuse=fuse, half_precision=(dtype == 'bfloat16'), num_gpus=1, **kw)
+    model = cls([size, size, 3], classes, batch_size=batch, width_div=8, fuse=fuse, half_precision=(dtype != 'float32'),
+                half_precision_dtype=(dtype if dtype != 'float32' else 'bfloat16'), num_gpus=1, **kw)
     params, stats = ON.init_variables(spec.variables(), seed=3, dtype=np.float32)
     rng = np.random.default_rng(9)
     # Non-trivial BN parameters (zero-init gammas would hide the residual branches) chosen so that the tiny test network
@@ -238,6 +239,53 @@ def test_resnet_step_bf16():
     # running statistics come from fp32 sums of the bf16 activations
     got = model.get_variables('data')
     assert rel_l2(got['block_0/conv_0/bn/mu'], state.stats['block_0/conv_0/bn/mu']) <= 1e-2
+
+
+def fp16q(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.float16).float().numpy().astype(np.float64)
+
+
+def test_resnet_step_fp16_with_loss_scaling():
+    """fp16 storage + loss_scaling_factor = 128: the reference's own low-precision recipe (convnet.py:63,
+    optimizers.py:102-111).  Like with like: the float64 oracle with fp16 rounding of every activation / activation
+    gradient / per-use weight and the same scale on the loss gradient (oracle.net: loss_scaling_factor).  fp16 keeps 11
+    significant bits, so the bounds are ~8x tighter than the bf16 test's; integer arg-max of the prediction must agree
+    with the fp16-emulating oracle wherever its top-2 margin exceeds the storage resolution."""
+    import myconvnet_amd as M
+    model, spec, params, stats = make_resnet(50, 'float16', True)
+    assert model.dtype == 'float16'
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, loss_scaling_factor=128.0)
+    assert model.loss_scale == 128.0
+    x = RNG.random((BATCH, 64, 64, 3)).astype(np.float32)
+    y = LABELS
+    model.feed(x, y)
+    loss, _, y_pred = opt._step(None)
+    st = lambda: ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})  # noqa: E731
+    state, state64 = st(), st()
+    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH, quant=fp16q,
+                                         hp=dict(loss_scaling_factor=128.0))
+    xloss, xpred, xgrads = ON.train_step(spec, state64, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH)
+    assert abs(loss - rloss) <= 3e-3 * abs(rloss), (loss, rloss)
+    assert rel_l2(y_pred, rpred) <= 8e-3
+    top2 = np.sort(rpred, axis=-1)
+    sure = (top2[:, -1] - top2[:, -2]) > 2e-2
+    np.testing.assert_array_equal(y_pred.argmax(-1)[sure], rpred.argmax(-1)[sure])
+    grads = model.get_variables('grad')
+    keys = sorted(k for k in rgrads if k.endswith('weights'))
+    g = np.concatenate([grads[k].ravel() for k in keys])
+    r = np.concatenate([rgrads[k].ravel() for k in keys])
+    e = np.concatenate([xgrads[k].ravel() for k in keys])
+    err_dev, err_emu = rel_l2(g, e), rel_l2(r, e)
+    print('fp16 gradient error vs float64: device {:.4f}, fp16-emulating oracle {:.4f}; cos(device, emu) {:.5f}'.format(err_dev, err_emu, cosine(g, r)))
+    # (the 16-unit width/8 net amplifies storage rounding ~100x: the fp16-emulating oracle itself is 0.17 away from float64;
+    # the device must be no further, and aligned with both)
+    assert err_dev <= 1.5 * err_emu + 0.004, (err_dev, err_emu)
+    assert cosine(g, e) >= 0.98 and cosine(g, r) >= 0.98
+    assert abs(np.linalg.norm(g) / np.linalg.norm(e) - 1.0) <= 0.05
+    got = model.get_variables('data')
+    assert rel_l2(got['block_0/conv_0/bn/mu'], state.stats['block_0/conv_0/bn/mu']) <= 2e-3
+    worst = max((rel_l2(got[k], v), k) for k, v in state.params.items() if k.endswith('weights'))
+    assert worst[0] <= 2e-3, worst                                        # one Nesterov step from identical masters
 
 
 def test_resnet_eval_uses_ema_and_running_stats():
