@@ -178,7 +178,7 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     return b;
 }
 
-extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return 4; }    /* NT: 128x128, 128x64, 64x64, 256x128 (bf16); TN: 4 shapes */
+extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 5; }    /* NT: 128x128, 128x64, 64x64, 256x128 / 8 waves and 128x128 / 8 waves (2-byte types); TN: 4 shapes */
 
 extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
@@ -213,8 +213,10 @@ static void allow_lds(K kernel, int bytes) {
 // and lost 4 %: the kernel boundary costs more than the shorter tail saves.)
 struct NtTile { int bm, bn, nw; };
 // candidate 3 (256x128, 8 waves) is bf16 only: fp32 is MFMA-bound and prefers the smallest tile
-static const NtTile kNtCand[4] = {{128, 128, 4}, {128, 64, 4}, {64, 64, 4}, {256, 128, 8}};
-#define MCN_NT_CANDS 4
+// candidate 4 (128x128 on 8 waves of 32x64): half the accumulators and epilogue registers per wave -> 4 waves per SIMD instead of
+// 2 at the same tile / L2 traffic: for the memory- and epilogue-bound 1x1 layers of the 2-byte types (statistics / residual epilogues)
+static const NtTile kNtCand[5] = {{128, 128, 4}, {128, 64, 4}, {64, 64, 4}, {256, 128, 8}, {128, 128, 8}};
+#define MCN_NT_CANDS 5
 static inline double nt_tile_work(int c, size_t es) {
     static const double w[3] = {128.0 * 128, 128.0 * 64, 64.0 * 64};
     static const double f32[3] = {1.08, 1.03, 1.00}, bf16[3] = {1.00, 1.08, 1.35};
@@ -224,8 +226,9 @@ template <typename T>
 static int pick_nt_tile(int M, int Nn, int hint = 0) {
     hint &= 0xff;
     if (hint >= 1 && hint <= 3) return hint - 1;
-    if (hint == 4 && sizeof(T) == 2 && Nn > 64) return 3;      // 256x128 / 8 waves: bf16 only; otherwise the heuristic below
+    if ((hint == 4 || hint == 5) && sizeof(T) == 2 && Nn > 64) return hint - 1;      // the 8-wave tiles: 2-byte types only; otherwise the heuristic below
     static const int forced = [] { const char* e = getenv("MCN_NT_TILE"); return e ? atoi(e) : -1; }();
+    if (forced == 4 && sizeof(T) == 2 && Nn > 64) return 4;
     const NtTile* cand = kNtCand;
     int best = Nn <= 64 ? 1 : 0;
     double best_cost = -1;
@@ -250,7 +253,7 @@ static int pick_nt_tile(int M, int Nn, int hint = 0) {
 // the tiles of a thin last round run faster than those of a full one, and the split cost 4 % of the step (per-layer +10-38 %).
 struct SkPlan { int body, tail, slices; size_t bytes; };
 // resident workgroups per CU: 160 KB of LDS / (2 buffers x (BM + BN) x 128 B); registers allow at least as many
-static const int kNtSlotsPerCU[MCN_NT_CANDS] = {2, 3, 5, 1};
+static const int kNtSlotsPerCU[MCN_NT_CANDS] = {2, 3, 5, 1, 2};
 #define MCN_SK_MAX_ROUNDS 8          /* more whole rounds than this: the tail is too small a share of the layer to pay */
 #define MCN_SK_MIN_KSTEPS 4          /* K-steps per slice (below: prologue + partial traffic outweigh the MFMAs) */
 static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
@@ -275,7 +278,11 @@ static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
 template <typename T>
 static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mode, bool reduce, hipStream_t st) {
     const NtTile t = kNtCand[tile];
-    const int lds = reduce ? 0 : 2 * (t.bm + t.bn) * 128;
+    // a K loop of one step (K <= 128 bytes: the 64-channel 1x1 layers in bf16) never touches the second LDS buffer: declaring
+    // one lets twice as many workgroups share a CU where registers allow (MCN_NT_LDS1=0 restores the two-buffer launch)
+    static const int lds1 = [] { const char* e = getenv("MCN_NT_LDS1"); return e ? atoi(e) : 1; }();
+    const bool one_step = lds1 && p.sk_mode == 0 && ((p.nchunks + 7) >> 3) <= 1;
+    const int lds = reduce ? 0 : (one_step ? 1 : 2) * (t.bm + t.bn) * 128;
     const dim3 grid(nblocks), block(t.nw * 64);
 #define MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, EPIV)                                   \
     do {                                                                             \
@@ -301,11 +308,12 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
     } while (0)
     // epilogue variant: the accumulate modes have their own instantiation (batched loads), so do the BN statistics
     const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
-    if (t.bm == 256) {
+    if (t.nw == 8) {
         if constexpr (sizeof(T) == 2) {
-            MCN_LAUNCH_NT_MODE(256, 128, 8);
+            if (t.bm == 256) MCN_LAUNCH_NT_MODE(256, 128, 8);
+            else MCN_LAUNCH_NT_MODE(128, 128, 8);
         } else {
-            MCN_FAIL(MCN_E_UNSUPPORTED, "conv: 256x128 tile is bf16 only");
+            MCN_FAIL(MCN_E_UNSUPPORTED, "conv: the 8-wave tiles are for the 2-byte types only");
         }
     } else if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_NT_MODE(128, 128, 4);
     else if (t.bm == 128) MCN_LAUNCH_NT_MODE(128, 64, 4);
@@ -325,6 +333,8 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     const NtTile t = kNtCand[tile];
     p.m_begin = 0;
     p.m_end = p.M;
+    // the epilogue addresses the output through a buffer descriptor: images x full output grid x channel stride
+    p.out_bytes = (unsigned)((size_t)(p.M / (p.OH * p.OW)) * p.OHf * p.OWf * p.ldo * sizeof(T));
     const long W = (long)((p.M + t.bm - 1) / t.bm) * ((p.Nn + t.bn - 1) / t.bn);
     const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
     static const int epi_flags = [] { const char* e = getenv("MCN_NT_EPI_FLAGS"); return e ? atoi(e) : 0; }();

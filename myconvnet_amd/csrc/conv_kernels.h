@@ -51,6 +51,7 @@ struct GemmNTParams {
     const void* add_src;
     const unsigned char* add_mask;
     unsigned in_bytes, wt_bytes;
+    unsigned out_bytes;     // bytes of the whole output tensor (set by launch_nt: buffer range of the epilogue's stores / loads)
     int epi_flags;          // experiments (MCN_NT_EPI_FLAGS): 1 = no lane pairing (8-byte bf16 accesses), 2 = byte-wise mask loads
     int tap[MCN_MAX_TAPS];  // (dy & 0xffff) | (dx << 16) per filter tap: 32-bit so that a wave-uniform tap index is a scalar load
                             // (byte tables are fetched with vector loads whose waits drain the LDS-DMA queue)
@@ -193,100 +194,159 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Epilogue of conv_gemm_nt / conv_nt_sk_reduce: bias, store (or accumulate), optional BN-statistics partials.
 // EPI: 0 = store, 1 = store + BN-statistics partials, 2 = accumulate (p.accumulate 1 / 2) — compile-time so that the plain
 // and statistics instantiations do not carry the registers of the accumulate path's batched loads.
+//
+// Branch-free by construction (round 2; PMC showed the 1x1 layers of the 2-byte types VALU-issue bound in this code: ~870
+// vector instructions per wave and tile, most of them exec-mask branches around single stores / loads, 64-bit address
+// arithmetic and per-element conversions): every store and every epilogue load is a raw BUFFER access whose 32-bit byte
+// offset carries "row past the end" / "column past Nn" in bit 31 (out of range => the store is dropped, the load returns
+// 0), the bias is folded into the accumulators under ONE uniform branch, the statistics run on packed fp32 pairs
+// (v_pk_add_f32 / v_pk_fma_f32), and the pixel of a row is its GEMM row unless the launch scatters a sub-grid (strided dgrad).
 enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// offsets that carry "out of range" in bit 31 are added with saturation (v_add_u32 ... clamp): bad row + bad column must not
+// wrap around to a valid address
+__device__ __forceinline__ unsigned sat_add(unsigned a, unsigned b) { return __builtin_elementwise_add_sat(a, b); }
+
+// rounded storage value(s) of an accumulator quadruple: T x 4 and the same values back in fp32 (what the statistics see)
+template <typename T>
+struct Quad;
+template <>
+struct Quad<float> {
+    typedef f32x4 Bits;                                     // 16 bytes
+    static __device__ __forceinline__ Bits pack(const float (&v)[4]) { return f32x4{v[0], v[1], v[2], v[3]}; }
+    static __device__ __forceinline__ void unpack(const Bits& b, float (&r)[4]) { r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; r[3] = b[3]; }
+};
+template <typename T>
+struct Quad {                                               // bf16 / fp16: 8 bytes
+    typedef u32x2 Bits;
+    typedef T TV4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ Bits pack(const float (&v)[4]) {
+        const TV4 o = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+        return __builtin_bit_cast(u32x2, o);
+    }
+    static __device__ __forceinline__ void unpack(const Bits& b, float (&r)[4]) {
+        const TV4 o = __builtin_bit_cast(TV4, b);
+        r[0] = to_f32(o[0]); r[1] = to_f32(o[1]); r[2] = to_f32(o[2]); r[3] = to_f32(o[3]);
+    }
+};
+
+template <>
+struct Quad<bf16_t> {                                       // bf16 -> fp32 is a 16-bit shift: two integer ops per packed pair
+    typedef u32x2 Bits;
+    typedef bf16_t TV4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ Bits pack(const float (&v)[4]) {
+        const TV4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        return __builtin_bit_cast(u32x2, o);
+    }
+    static __device__ __forceinline__ void unpack(const Bits& b, float (&r)[4]) {
+        r[0] = __builtin_bit_cast(float, b[0] << 16); r[1] = __builtin_bit_cast(float, b[0] & 0xffff0000u);
+        r[2] = __builtin_bit_cast(float, b[1] << 16); r[3] = __builtin_bit_cast(float, b[1] & 0xffff0000u);
+    }
+};
+
 template <typename T, int BM, int BN, bool TAPS, int NW, int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                                             typename MmaNT<T>::Acc (&acc)[BN / 2 / MmaNT<T>::MT][BM / (NW / 2) / MmaNT<T>::MT],
                                             const int m0, const int n0, const int lane, const int wm, const int wn) {
     typedef MmaNT<T> MM;
+    typedef Quad<T> Q;
     constexpr bool STATS = EPI == NT_EPI_STATS, ACC = EPI == NT_EPI_ACC;
     constexpr int WROWS = NW / 2;
     constexpr int WTM = BM / WROWS, WTN = BN / 2;
     constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
+    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 channels per accumulator
+    constexpr int ES = (int)sizeof(T);
+    // 2-byte types / 16x16 accumulators: a lane holds 4 channels = 8 bytes of a pixel, and 8-byte stores run at 2/3 of the rate
+    // of 16-byte ones (4.5 vs 6.4-6.8 TB/s measured for these row shapes).  Lanes l and l+16 hold neighbouring channel groups
+    // of the same pixel: one v_permlane16_swap per dword trades row block 2q+1 of the even 16-lane rows for row block 2q of the
+    // odd ones, after which every lane owns 8 consecutive channels = one 16-byte access (loads of the accumulate path alike).
+    constexpr bool PAIR = ES == 2;
+    static_assert(!PAIR || (MM::MT == 16 && TM % 2 == 0), "lane pairing needs 16x16 accumulators and an even row-block count");
     const int fr = MM::frag_row(lane);
-    // ---- epilogue: lane holds 4 consecutive output channels of one pixel per register group ----
-    // p.stats: the batch-norm statistics of the layer's output ride here — per-lane sums of the STORED (rounded) values
-    // and of their squares over the wave's pixel tiles, folded across the 16 / 32 lanes that share a channel group and
-    // written as one partial row per (M tile, wave row): the separate read of y by the BN statistics pass disappears.
-    T* out = reinterpret_cast<T*>(p.out);
-    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);   // groups of 4 rows per accumulator
-    float s1[STATS ? TN : 1][NG][4], s2[STATS ? TN : 1][NG][4], piv[STATS ? TN : 1][NG][4];
-    constexpr bool do_stats = STATS;             // compile-time: the plain instantiation carries no statistics code
-    if (do_stats) {
+    // first of the 4 consecutive output channels that accumulator group (j, g) holds in this lane
+    auto col = [&](int j, int g) -> int { return n0 + wn * WTN + j * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * g + 4 * (lane >> 5)); };
+
+    // (the bias is not added here: the accumulators START at it — nt_init_acc — so that a biased conv costs no epilogue code)
+
+    // byte offset of each row block's pixel in the output tensor (< 2^31, mfma_path_ok), bit 31 = past the end of the GEMM rows
+    const bool scat = p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf;      // sub-grid of a strided dgrad (uniform)
+    unsigned rowoff[TM];
+    const unsigned rowbytes = (unsigned)(p.ldo * ES);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-                const int n = n0 + wn * WTN + j * MM::MT + nl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[j][0][g * 4 + e];
-                    if (p.bias && n < p.Nn) v += p.bias[n + e];
-                    v = to_f32(from_f32<T>(v));                                  // the value as stored
-                    piv[j][g][e] = __shfl(v, lane & ~(MM::MT - 1));            // pixel row 0 of the wave row
-                    s1[j][g][e] = s2[j][g][e] = 0.f;
-                }
-            }
+    for (int i = 0; i < TM; ++i) {
+        const int mraw = m0 + wm * WTM + i * MM::MT + fr;
+        const unsigned bad = ((unsigned)(p.m_end - 1 - mraw) >> 31) << 31;
+        unsigned pix = bad ? 0u : (unsigned)mraw;
+        if (scat) {
+            const int hw = p.OH * p.OW;
+            const int img = (int)pix / hw, rem = (int)pix - img * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            pix = (unsigned)((img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0));
+        }
+        rowoff[i] = pix * rowbytes | bad;
     }
-    // Accumulate modes: ALL the loads of the epilogue are issued back to back in front of the first store.  (With LDS-DMA
-    // in the kernel hipcc waits vmcnt(0) at the first use of every ordinary load, which also drains the stores in front of
-    // it: loads issued one by one ahead of their stores cost a store + a load round trip each — 32 per 128x128 tile, and
-    // the residual-add dgrads ran at half the HBM rate.)
-    typedef T TV4 __attribute__((ext_vector_type(4)));      // 4 output elements (16 B fp32 / 8 B bf16)
-    constexpr bool CAN_PAIR = MM::MT == 16 && sizeof(T) == 2 && TM % 2 == 0;
-    const bool paired = CAN_PAIR && p.Nn % 8 == 0 && p.ldo % 8 == 0 && !(p.epi_flags & 1);      // see the store loop below
-    TV4 prev[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
+    // column byte offsets (bit 31 = past Nn; Nn is a chunk multiple, so a 4-channel group is in or out as a whole)
+    unsigned coloff[TN][NG];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int n = col(j, g);
+            coloff[j][g] = (unsigned)(n * ES) | (((unsigned)(p.Nn - 1 - n) >> 31) << 31);
+        }
+    const bool oddrow = PAIR && ((lane >> 4) & 1);
+    const unsigned oddmask = oddrow ? ~0u : 0u;
+    const unsigned pairshift = oddrow ? 4u * ES : 0u;         // an odd 16-lane row stores / loads the chunk that starts 4 channels lower
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+
+    // ---- accumulate modes: ALL loads of the epilogue are issued back to back in front of the first store (with LDS-DMA in the
+    // kernel hipcc waits vmcnt(0) at the first use of every ordinary load, which also drains the stores in front of it) ----
+    typename Q::Bits prev[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
     unsigned char mbits[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
     if constexpr (ACC) {
-        constexpr int CEL = (int)(16 / sizeof(T));                     // elements per mask byte
-        constexpr int MB = WTN / CEL;                                  // mask bytes per pixel for this wave's WTN channels: 4, 8 or 16
+        constexpr int CEL = 16 / ES;                                    // elements per mask byte
+        constexpr int MB = WTN / CEL;                                   // mask bytes per pixel for this wave's WTN channels: 4, 8 or 16
         static_assert(MB % 4 == 0, "mask bytes per wave row");
+        const bool masked = p.accumulate == 2;
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(masked ? p.add_src : (const void*)p.out), 0, (int)p.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.add_mask), 0, masked ? (int)(p.out_bytes >> 4) : 0, 0x00020000);
         // one wide mask load per row block (instead of a byte per accumulator) when the wave's channel range is whole
-        const bool wide = p.accumulate == 2 && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)p.add_mask & 15) == 0 && !(p.epi_flags & 2);
-        long pixv[TM];
-        bool mval[TM];
+        const bool wide = masked && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)p.add_mask & 15) == 0 && !(p.epi_flags & 2);
         unsigned mw[TM][MB / 4];
+        const unsigned wcol = (unsigned)((n0 + wn * WTN) * ES) | (((unsigned)(p.Nn - 1 - (n0 + wn * WTN)) >> 31) << 31);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * MM::MT + fr;
-            mval[i] = m < p.m_end;
-            const int mm = mval[i] ? m : 0;
-            const int hw = p.OH * p.OW;
-            const int img = mm / hw, rem = mm - img * hw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            pixv[i] = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
 #pragma unroll
             for (int k = 0; k < MB / 4; ++k) mw[i][k] = 0;
-            if (wide && mval[i] && n0 + wn * WTN < p.Nn) {
-                const unsigned char* mp = p.add_mask + pixv[i] * (p.ldo / CEL) + (n0 + wn * WTN) / CEL;
-                if constexpr (MB == 4) mw[i][0] = *reinterpret_cast<const unsigned*>(mp);
-                else if constexpr (MB == 8) { const u32x2 t = *reinterpret_cast<const u32x2*>(mp); mw[i][0] = t[0]; mw[i][1] = t[1]; }
-                else { const u32x4 t = *reinterpret_cast<const u32x4*>(mp); mw[i][0] = t[0]; mw[i][1] = t[1]; mw[i][2] = t[2]; mw[i][3] = t[3]; }
+            if (wide) {                                                    // uniform
+                const unsigned bo = sat_add(rowoff[i], wcol);                       // byte offset of the wave's first channel of this row (bit 31: invalid)
+                const unsigned mo = ((bo & 0x7fffffffu) >> 4) | (bo & 0x80000000u);
+                if constexpr (MB == 4) mw[i][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsM, (int)mo, 0, 0);
+                else if constexpr (MB == 8) { const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsM, (int)mo, 0, 0); mw[i][0] = t[0]; mw[i][1] = t[1]; }
+                else { const i32x4 t = buf_load16(rsM, mo); mw[i][0] = t[0]; mw[i][1] = t[1]; mw[i][2] = t[2]; mw[i][3] = t[3]; }
             }
         }
-        if (paired) {
-            if constexpr (CAN_PAIR) {
-                // 16-byte loads in the paired layout of the store loop, then the same swap hands every lane its own channels
-                const bool oddrow = (lane >> 4) & 1;
+        if constexpr (PAIR) {
+            // 16-byte loads in the paired layout of the store loop, then the same swap hands every lane its own channels
 #pragma unroll
-                for (int q = 0; q < TM / 2; ++q) {
-                    const long pixs = oddrow ? pixv[2 * q + 1] : pixv[2 * q];
-                    const bool mvs = oddrow ? mval[2 * q + 1] : mval[2 * q];
+            for (int q = 0; q < TM / 2; ++q) {
+                const unsigned srow = rowoff[2 * q] ^ ((rowoff[2 * q] ^ rowoff[2 * q + 1]) & oddmask);   // (a select here compiles to a stack array + indexed load)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = n0 + wn * WTN + j * MM::MT + 4 * (lane >> 4);
-                        const int ns = n - (oddrow ? 4 : 0);
-                        u32x4 w = {0u, 0u, 0u, 0u};
-                        if (mvs && n < p.Nn)
-                            w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.accumulate == 2 ? p.add_src : (const void*)p.out) + pixs * p.ldo + ns);
-                        const auto lo = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
-                        const auto hi = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
-                        prev[2 * q][j][0] = __builtin_bit_cast(TV4, u32x2{lo[0], hi[0]});
-                        prev[2 * q + 1][j][0] = __builtin_bit_cast(TV4, u32x2{lo[1], hi[1]});
-                    }
+                for (int j = 0; j < TN; ++j) {
+                    const i32x4 w = buf_load16(rsS, sat_add(srow, coloff[j][0] - pairshift));
+                    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)w[0], (unsigned)w[2], false, false);
+                    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)w[1], (unsigned)w[3], false, false);
+                    prev[2 * q][j][0] = u32x2{lo[0], hi[0]};
+                    prev[2 * q + 1][j][0] = u32x2{lo[1], hi[1]};
                 }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) prev[i][j][g] = __builtin_bit_cast(typename Q::Bits, buf_load16(rsS, sat_add(rowoff[i], coloff[j][g])));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -294,119 +354,111 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-                    const int n = n0 + wn * WTN + j * MM::MT + nl;
-                    const bool valid = mval[i] && n < p.Nn;
-                    if (!paired) {
-                        prev[i][j][g] = TV4{};
-                        if (valid) prev[i][j][g] = *reinterpret_cast<const TV4*>(reinterpret_cast<const T*>(p.accumulate == 2 ? p.add_src : (const void*)p.out) + pixv[i] * p.ldo + n);
-                    }
-                    if (p.accumulate != 2) {
-                        mbits[i][j][g] = valid ? 0xff : 0;
+                    if (!masked) {
+                        mbits[i][j][g] = 0xff;
                     } else if (wide) {
-                        const int idx = (j * MM::MT + nl) / CEL;          // byte of this accumulator within the wave row's MB bytes
+                        const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+                        const int idx = (j * MM::MT + nl) / CEL;           // byte of this accumulator within the wave row's MB bytes
                         unsigned dw = mw[i][0];
 #pragma unroll
                         for (int k = 1; k < MB / 4; ++k) dw = (idx >> 2) == k ? mw[i][k] : dw;
                         mbits[i][j][g] = (unsigned char)(dw >> ((idx & 3) * 8));
                     } else {
-                        mbits[i][j][g] = valid ? p.add_mask[pixv[i] * (p.ldo / CEL) + n / CEL] : 0;
+                        const unsigned bo = sat_add(rowoff[i], coloff[j][g]);
+                        mbits[i][j][g] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsM, (int)(((bo & 0x7fffffffu) >> 4) | (bo & 0x80000000u)), 0, 0);
                     }
                 }
     }
-    // pixel of accumulator row block i for this lane (false: past the end of the GEMM rows)
-    auto row_pix = [&](int i, long& pix) -> bool {
-        const int mraw = m0 + wm * WTM + i * MM::MT + fr;
-        const bool mvalid = mraw < p.m_end;
-        const int m = mvalid ? mraw : 0;
-        if (TAPS || p.osy != 1 || p.osx != 1 || p.OH != p.OHf || p.OW != p.OWf) {
-            const int hw = p.OH * p.OW;
-            const int img = m / hw, rem = m - img * hw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            pix = ((long)img * p.OHf + (oy * p.osy + p.oy0)) * p.OWf + (ox * p.osx + p.ox0);
-        } else {
-            pix = m;
-        }
-        return mvalid;
-    };
-    // the 4 output values of accumulator (i, j, g) as stored: bias, accumulate, rounding; statistics of the valid ones
-    auto value = [&](int i, int j, int g, int n, bool valid) -> TV4 {
+
+    // ---- BN statistics of the STORED (rounded) values: per-lane sums of (y - pivot) and of its square over the wave's row
+    // blocks, pivot = pixel row 0 of the wave row (keeps the E[y^2] - E[y]^2 cancellation out of fp32) ----
+    float s1[STATS ? TN : 1][NG][4], s2[STATS ? TN : 1][NG][4], piv[STATS ? TN : 1][NG][4];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float v[4], r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][0][g * 4 + e];
+                Q::unpack(Q::pack(v), r);                                     // the values as stored
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    piv[j][g][e] = __shfl(r[e], lane & ~(MM::MT - 1));        // pixel row 0 of the wave row
+                    s1[j][g][e] = s2[j][g][e] = 0.f;
+                }
+            }
+    }
+    const bool full = m0 + BM <= p.m_end;                      // wave-uniform: no row of this tile is past the end
+    // the 4 output values of accumulator (i, j, g) as stored (residual added, rounded) + their statistics
+    auto value = [&](int i, int j, int g, bool rowvalid) -> typename Q::Bits {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e];
-        if (p.bias && valid) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-        }
         if constexpr (ACC) {
-            // accumulate 1: every bit of mbits is set; 2: the residual's ReLU mask, one bit per element
-            const unsigned mb = sizeof(T) == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (n & 4));
+            float pr[4];
+            Q::unpack(prev[i][j][g], pr);
+            // accumulate 1: every bit of mbits is set; 2: the residual's ReLU mask, one bit per element (8 per byte for 2-byte types)
+            const unsigned mb = ES == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (col(j, g) & 4));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? to_f32(prev[i][j][g][e]) : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? pr[e] : 0.f;
         }
-        TV4 o;
+        const typename Q::Bits o = Q::pack(v);
+        if constexpr (STATS) {
+            float r[4];
+            Q::unpack(o, r);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
-        if (do_stats && valid) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = to_f32(o[e]) - piv[j][g][e];
-                s1[j][g][e] += d;
-                s2[j][g][e] = fmaf(d, d, s2[j][g][e]);
+            for (int h = 0; h < 2; ++h) {                                     // packed pairs: v_pk_add_f32 / v_pk_fma_f32
+                f32x2 d = f32x2{r[2 * h], r[2 * h + 1]} - f32x2{piv[j][g][2 * h], piv[j][g][2 * h + 1]};
+                if (!rowvalid) d = f32x2{0.f, 0.f};
+                const f32x2 a = f32x2{s1[j][g][2 * h], s1[j][g][2 * h + 1]} + d;
+                const f32x2 b = __builtin_elementwise_fma(d, d, f32x2{s2[j][g][2 * h], s2[j][g][2 * h + 1]});
+                s1[j][g][2 * h] = a[0]; s1[j][g][2 * h + 1] = a[1];
+                s2[j][g][2 * h] = b[0]; s2[j][g][2 * h + 1] = b[1];
             }
         }
         return o;
     };
-    // bf16 / 16x16 accumulators: a lane holds 4 channels = 8 bytes of a pixel, and 8-byte stores run at 2/3 of the rate of
-    // 16-byte ones (4.5 vs 6.4-6.8 TB/s measured for these row shapes).  Lanes l and l+16 hold neighbouring channel groups
-    // of the same pixel: one v_permlane16_swap per dword trades row block 2q+1 of the even 16-lane rows for row block 2q of
-    // the odd ones, after which every lane owns 8 consecutive channels = one 16-byte store (half as many instructions).
-    if (paired) {
-        if constexpr (CAN_PAIR) {
-            const bool oddrow = (lane >> 4) & 1;
+    auto store_all = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;                         // FULL: every row is valid (no per-row statistics select)
+        if constexpr (PAIR) {
 #pragma unroll
             for (int q = 0; q < TM / 2; ++q) {
-                long pix0, pix1;
-                const bool mv0 = row_pix(2 * q, pix0), mv1 = row_pix(2 * q + 1, pix1);
-                const long pixs = oddrow ? pix1 : pix0;
-                const bool mvs = oddrow ? mv1 : mv0;
+                const unsigned srow = rowoff[2 * q] ^ ((rowoff[2 * q] ^ rowoff[2 * q + 1]) & oddmask);   // (a select here compiles to a stack array + indexed load)
+                const bool v0 = FULL || !(rowoff[2 * q] >> 31), v1 = FULL || !(rowoff[2 * q + 1] >> 31);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * WTN + j * MM::MT + 4 * (lane >> 4);
-                    const bool nv = n < p.Nn;
-                    const u32x2 a = __builtin_bit_cast(u32x2, value(2 * q, j, 0, n, mv0 && nv));
-                    const u32x2 b = __builtin_bit_cast(u32x2, value(2 * q + 1, j, 0, n, mv1 && nv));
+                    const u32x2 a = value(2 * q, j, 0, v0);
+                    const u32x2 b = value(2 * q + 1, j, 0, v1);
                     const auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
                     const auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
                     // even rows: (own, partner) of row block 2q; odd rows: (partner, own) of 2q+1 — lower channels first
-                    const u32x4 w = {lo[0], hi[0], lo[1], hi[1]};
-                    const int ns = n - (oddrow ? 4 : 0);
-                    if (mvs && nv) *reinterpret_cast<u32x4*>(out + pixs * p.ldo + ns) = w;
+                    const i32x4 w = {(int)lo[0], (int)hi[0], (int)lo[1], (int)hi[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsO, (int)sat_add(srow, coloff[j][0] - pairshift), 0, 0);
+                    // (without branches the scheduler would hoist every accumulator read and conversion of the tile in front of
+                    // the first store: +60-110 VGPRs, an occupancy step; one store group at a time keeps the old footprint)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
-    } else {
+        } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            long pix;
-            const bool mvalid = row_pix(i, pix);
-            T* orow = out + pix * p.ldo;
+            for (int i = 0; i < TM; ++i) {
+                const bool rv = FULL || !(rowoff[i] >> 31);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    // 16x16: n = 4*(lane>>4) + e ; 32x32: n = 8*g + 4*(lane>>5) + e
-                    const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-                    const int n = n0 + wn * WTN + j * MM::MT + nl;
-                    const bool valid = mvalid && n < p.Nn;
-                    const TV4 o = value(i, j, g, n, valid);
-                    if (valid) *reinterpret_cast<TV4*>(orow + n) = o;
-                }
+                    for (int g = 0; g < NG; ++g)
+                    {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, value(i, j, g, rv)), rsO, (int)sat_add(rowoff[i], coloff[j][g]), 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
             }
         }
-    }
-    if (do_stats) {
+    };
+    if (!STATS || full) store_all(std::true_type{});
+    else store_all(std::false_type{});
+
+    if constexpr (STATS) {
         // Fold over the MT lanes that hold different pixel rows of the same channels with a halving butterfly: at each
         // step a lane keeps half of its values and receives the partner's copies of that half (V/2 + V/4 + ... shuffles
         // instead of V per step); when one value is left the remaining steps are plain all-reduce steps.  At the end lane
@@ -438,8 +490,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
             for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
                 for (int gg = 0; gg < NG; ++gg) {
-                    const int nl2 = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * gg + 4 * (lane >> 5));
-                    const int n2 = n0 + wn * WTN + jj * MM::MT + nl2;
+                    const int n2 = col(jj, gg);
                     if (n2 < p.Nn)
                         *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 3 + 2) * p.Nn + n2) = f32x4{piv[jj][gg][0], piv[jj][gg][1], piv[jj][gg][2], piv[jj][gg][3]};
                 }
@@ -447,8 +498,38 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     }
 }
 
+// Accumulators start at the bias of their output channels (or at zero): the lane holds 4 consecutive channels per (j, g) for
+// every row block i, so a biased convolution (VGG, the fc layer) costs one uniform branch here and nothing in the epilogue.
+template <typename T, int TN, int TM>
+__device__ __forceinline__ void nt_init_acc(typename MmaNT<T>::Acc (&acc)[TN][TM], const float* bias, int ncol0, int Nn, int lane) {
+    typedef MmaNT<T> MM;
+    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);
+    if (bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int n = ncol0 + j * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * g + 4 * (lane >> 5));
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + min(n, Nn - 4));       // (clamped: columns past Nn are never stored)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][i][g * 4 + e] = bv[e];
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < (int)(sizeof(typename MM::Acc) / 4); ++e) acc[j][i][e] = 0.f;
+    }
+}
+
+// minimum waves per SIMD the register allocator must leave room for: the 8-wave 128x128 tile exists to put two workgroups
+// (4 waves per SIMD) on a CU; everything else takes what it gets
 template <typename T, int BM, int BN, int MODE, int NW = 4, int EPI = NT_EPI_STORE>
-__global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : 1)) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
     constexpr bool TAPS = MODE != NT_LINEAR;
@@ -568,12 +649,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt(const GemmNTParams p) {
         static_for<BR>([&](auto ic) { ldB(ic, (b_off[decltype(ic)::value] + (unsigned)ks * 128u) | oobb); });   // OOB + small stays OOB
     };
     typename MM::Acc acc[TN][TM];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < (int)(sizeof(typename MM::Acc) / 4); ++e) acc[j][i][e] = 0.f;
+    nt_init_acc<T, TN, TM>(acc, sk_slice ? nullptr : p.bias, n0 + wn * WTN, p.Nn, lane);     // (K-slices of a stream-K tail: the reduce pass adds the bias)
 
     const int fr = MM::frag_row(lane), fc = MM::frag_chunk(lane);
     const int fsw = (fr >> 1) & 7;   // tile rows start at multiples of 16 => swizzle key depends on the lane only
@@ -671,12 +747,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_sk_reduce(const GemmNTParams 
     const int L = p.sk_body + (int)blockIdx.x;
     const int m0 = p.m_begin + (L / ntn) * BM, n0 = (L % ntn) * BN;
     typename MM::Acc acc[TN][TM];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < ACCSZ; ++e) acc[j][i][e] = 0.f;
+    nt_init_acc<T, TN, TM>(acc, p.bias, n0 + (wave & 1) * (BN / 2), p.Nn, lane);
     for (int sl = 0; sl < p.sk_slices; ++sl) {
         const float* src = p.partial + (((size_t)blockIdx.x * p.sk_slices + sl) * NREG) * NT + tid;
 #pragma unroll
