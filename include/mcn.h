@@ -336,11 +336,18 @@ int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* works
  * over n contiguous fp32 elements. */
 int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum,
                            float l2, float wd, float ema_decay, float grad_scale, void* stream);
+/* The same update with its per-step scalars read from DEVICE memory, hyper = {lr, wd, ema_decay, grad_scale} (fp32 x 4): the
+ * launch arguments are then identical every step, so the whole step can be captured once in a hipGraph and replayed (the
+ * reference's optimizers.py:590-594 is one session.run per step; here: one graph launch).  use_wd: 0 = no decoupled decay
+ * for this range. */
+int mcn_sgd_nesterov_fused_h(float* w, const float* g, float* accum, float* ema, int64_t n, const float* hyper, float momentum,
+                             float l2, int32_t use_wd, void* stream);
 /* the reference's other decoupled decays, applied after apply_gradients (optimizers.py:163-170; the default
  * w -= wd*w rides in mcn_sgd_nesterov_fused): mode 0: w -= wd*w; 1 (l1_weight_decay): w -= wd*sign(w);
  * 2 (huber_decay_delta): w -= wd*w/sqrt(1 + (w/delta)^2).  n contiguous fp32 elements. */
 typedef enum { MCN_DECAY_L2 = 0, MCN_DECAY_L1 = 1, MCN_DECAY_HUBER = 2 } mcn_decay_mode;
 int mcn_decoupled_decay(float* w, int64_t n, float wd, int32_t mode, float delta, void* stream);
+int mcn_decoupled_decay_h(float* w, int64_t n, const float* hyper /* wd = hyper[1] */, int32_t mode, float delta, void* stream);
 /* replaces tf.clip_by_global_norm(grads, gradient_threshold) (optimizers.py:112-113) over the flat gradient buffer:
  * first g[i] += l2 * w[i] for i < n_l2 (the gradient of the L2 term, which the reference's loss contains and which
  * otherwise rides in mcn_sgd_nesterov_fused — pass l2 = 0 there when clipping), then g *= t / max(||g||_2, t).
@@ -349,6 +356,7 @@ int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int64_t n_l2, f
                             void* workspace, size_t workspace_bytes, void* stream);
 /* shadow <- d*shadow + (1-d)*v (EMA of BN running statistics, convnet.py:1812,1826) */
 int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream);
+int mcn_ema_update_h(float* shadow, const float* v, int64_t n, const float* hyper /* decay = hyper[2] */, void* stream);
 /* chained running-statistics update over `towers` ranks (convnet.py:1899-1909):
  * running <- m*running + (1-m)*batch[k] for k = 0..towers-1; batch:[towers][n] */
 int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* stream);

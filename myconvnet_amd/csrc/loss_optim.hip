@@ -304,7 +304,13 @@ extern "C" int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int6
 template <bool EMA>
 __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ a,
                                                            float* __restrict__ ema, long n, float lr, float mom, float l2, float wd,
-                                                           float d, float gs) {
+                                                           float d, float gs, const float* __restrict__ hy) {
+    if (hy) {                                          // per-step scalars from device memory (the launch is then replayable: hipGraph)
+        lr = hy[0];
+        wd = hy[1] * wd;                               // wd argument = 0 / 1 switch of the decay for this range
+        d = hy[2];
+        gs = hy[3];
+    }
     const long n4 = n / 4;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -339,8 +345,19 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ w
         a[i] = av;
     }
 }
+static int sgd_launch(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum, float l2, float wd, float ema_decay,
+                      float grad_scale, const float* hyper, void* stream);
 extern "C" int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum, float l2,
                                       float wd, float ema_decay, float grad_scale, void* stream) {
+    return sgd_launch(w, g, accum, ema, n, lr, momentum, l2, wd, ema_decay, grad_scale, nullptr, stream);
+}
+extern "C" int mcn_sgd_nesterov_fused_h(float* w, const float* g, float* accum, float* ema, int64_t n, const float* hyper, float momentum, float l2,
+                                        int32_t use_wd, void* stream) {
+    if (!hyper) MCN_FAIL(MCN_E_BADARG, "sgd_nesterov_fused_h: null hyper-parameter buffer");
+    return sgd_launch(w, g, accum, ema, n, 0.f, momentum, l2, use_wd ? 1.f : 0.f, 0.f, 1.f, hyper, stream);
+}
+static int sgd_launch(float* w, const float* g, float* accum, float* ema, int64_t n, float lr, float momentum, float l2, float wd, float ema_decay,
+                      float grad_scale, const float* hyper, void* stream) {
     if (!w || !g || !accum || n < 0) MCN_FAIL(MCN_E_BADARG, "sgd_nesterov_fused: bad argument");
     if (n == 0) return MCN_OK;
     if ((((uintptr_t)w | (uintptr_t)g | (uintptr_t)accum | (uintptr_t)ema) & 15) != 0) MCN_FAIL(MCN_E_BADARG, "sgd_nesterov_fused: buffers must be 16-byte aligned");
@@ -348,8 +365,8 @@ extern "C" int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, fl
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (ema) hipLaunchKernelGGL((sgd_nesterov_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, w, g, accum, ema, (long)n, lr, momentum, l2, wd, ema_decay, grad_scale);
-    else hipLaunchKernelGGL((sgd_nesterov_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, w, g, accum, ema, (long)n, lr, momentum, l2, wd, ema_decay, grad_scale);
+    if (ema) hipLaunchKernelGGL((sgd_nesterov_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, w, g, accum, ema, (long)n, lr, momentum, l2, wd, ema_decay, grad_scale, hyper);
+    else hipLaunchKernelGGL((sgd_nesterov_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, w, g, accum, ema, (long)n, lr, momentum, l2, wd, ema_decay, grad_scale, hyper);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -357,7 +374,8 @@ extern "C" int mcn_sgd_nesterov_fused(float* w, const float* g, float* accum, fl
 // ---- decoupled weight decay variants (optimizers.py:163-170) --------------------------------------------------------
 // MODE 0: w -= wd*w ; 1: w -= wd*sign(w) ; 2 (pseudo-Huber): w -= wd*w / sqrt(1 + (w/delta)^2)
 template <int MODE>
-__global__ __launch_bounds__(256) void decoupled_decay_kernel(float* __restrict__ w, long n, float wd, float delta) {
+__global__ __launch_bounds__(256) void decoupled_decay_kernel(float* __restrict__ w, long n, float wd, float delta, const float* __restrict__ hy) {
+    if (hy) wd = hy[1];
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float v = w[i];
@@ -368,28 +386,43 @@ __global__ __launch_bounds__(256) void decoupled_decay_kernel(float* __restrict_
         w[i] = v - wd * d;
     }
 }
+static int decay_launch(float* w, int64_t n, float wd, int32_t mode, float delta, const float* hyper, void* stream);
 extern "C" int mcn_decoupled_decay(float* w, int64_t n, float wd, int32_t mode, float delta, void* stream) {
+    return decay_launch(w, n, wd, mode, delta, nullptr, stream);
+}
+extern "C" int mcn_decoupled_decay_h(float* w, int64_t n, const float* hyper, int32_t mode, float delta, void* stream) {
+    if (!hyper) MCN_FAIL(MCN_E_BADARG, "decoupled_decay_h: null hyper-parameter buffer");
+    return decay_launch(w, n, 1.f, mode, delta, hyper, stream);
+}
+static int decay_launch(float* w, int64_t n, float wd, int32_t mode, float delta, const float* hyper, void* stream) {
     if (!w || n < 0 || mode < 0 || mode > 2 || (mode == 2 && !(delta > 0.f))) MCN_FAIL(MCN_E_BADARG, "decoupled_decay: bad argument (mode %d, delta %g)", (int)mode, (double)delta);
-    if (n == 0 || wd == 0.f) return MCN_OK;
+    if (n == 0 || (wd == 0.f && !hyper)) return MCN_OK;
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL((decoupled_decay_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta);
-    else if (mode == 1) hipLaunchKernelGGL((decoupled_decay_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta);
-    else hipLaunchKernelGGL((decoupled_decay_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta);
+    if (mode == 0) hipLaunchKernelGGL((decoupled_decay_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta, hyper);
+    else if (mode == 1) hipLaunchKernelGGL((decoupled_decay_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta, hyper);
+    else hipLaunchKernelGGL((decoupled_decay_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, w, (long)n, wd, delta, hyper);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
 
-__global__ void ema_kernel(float* __restrict__ s, const float* __restrict__ v, long n, float d) {
+__global__ void ema_kernel(float* __restrict__ s, const float* __restrict__ v, long n, float d, const float* __restrict__ hy) {
+    if (hy) d = hy[2];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s[i] = d * s[i] + (1.f - d) * v[i];
 }
-extern "C" int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream) {
+static int ema_launch(float* shadow, const float* v, int64_t n, float decay, const float* hyper, void* stream);
+extern "C" int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream) { return ema_launch(shadow, v, n, decay, nullptr, stream); }
+extern "C" int mcn_ema_update_h(float* shadow, const float* v, int64_t n, const float* hyper, void* stream) {
+    if (!hyper) MCN_FAIL(MCN_E_BADARG, "ema_update_h: null hyper-parameter buffer");
+    return ema_launch(shadow, v, n, 0.f, hyper, stream);
+}
+static int ema_launch(float* shadow, const float* v, int64_t n, float decay, const float* hyper, void* stream) {
     if (!shadow || !v || n < 0) MCN_FAIL(MCN_E_BADARG, "ema_update: bad argument");
     if (n == 0) return MCN_OK;
     long blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shadow, v, (long)n, decay);
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shadow, v, (long)n, decay, hyper);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }

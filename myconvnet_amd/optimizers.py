@@ -7,6 +7,7 @@ remaining backward kernels run (dist.py); Nesterov momentum, the L2 term, the EM
 decoupled decay are one fused kernel over the flat parameter buffer; the per-step device->host copy of
 Y_all / pred (optimizers.py:590-594) is optional (`fetch=False`) so the training loop never synchronises.
 """
+import os
 import time
 
 import numpy as np
@@ -40,6 +41,11 @@ class Optimizer(object):
         self.decay_params = kwargs.get('learning_rate_decay_params', (0.94, 2))
         self.update_vars = [v for v in model.store.variables if v.trainable]
         self.optimization_operation = self._optimize_and_update(self._optimizer(**kwargs), **kwargs)
+        # use_graph=True / MCN_GRAPH=1: one hipGraph launch per step (single process).  Off by default: measured on MI355X the
+        # replay is bit-identical but SLOWER than the eager launch lists (bf16 25.04 vs 24.10 ms, fp32 73.4 vs 72.0 ms per step):
+        # the host is ~2x ahead of the GPU anyway, and the replay loses the wgrad / BN-backward overlap of the two eager streams
+        self.use_graph = bool(kwargs.get('use_graph', os.environ.get('MCN_GRAPH', '0') == '1')) and model.device.type == 'cuda'
+        self._graph, self._graph_low, self._eager_steps = None, None, 0
         self._reset()
         self.steps_per_epoch = kwargs.get('steps_per_epoch', None)
         if self.steps_per_epoch is None and train_set is not None:
@@ -98,24 +104,28 @@ class Optimizer(object):
                     runs.append([s1, e1, v.trainable])
         P = Program()
         ema_w = st.ema.data_ptr() if self.use_ema else 0
-        self._sgd_calls, self._decay_calls, self._ema_calls = [], [], []
+        # per-step scalars {lr, wd, ema_decay, grad_scale} live in a 4-float device buffer that the update kernels read, so every
+        # launch of a step has the same arguments every step: the step is replayable as ONE hipGraph (_capture_step)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if m.device.type == 'cuda' else torch.zeros(4, dtype=torch.float32)
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=m.device)
+        hp = self._hyper.data_ptr()
+        separate_decay = self.decay_mode != _ffi.DECAY_L2 and self.weight_decay > 0.0
+        clipping = self.gradient_threshold is not None
         for s1, e1, trainable in runs:
             off = s1 * 4
             if not trainable:
                 if ema_w:
-                    P.add(lib.mcn_ema_update, ema_w + off, st.data.data_ptr() + off, e1 - s1, 0.0)
-                    self._ema_calls.append(P.calls[-1][1])
+                    P.add(lib.mcn_ema_update_h, ema_w + off, st.data.data_ptr() + off, e1 - s1, hp)
                 continue
-            # args: w, g, accum, ema, n, lr, momentum, l2, wd, ema_decay, grad_scale
             reg = s1 < nw
-            P.add(lib.mcn_sgd_nesterov_fused, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
-                  (ema_w + off) if ema_w else 0, e1 - s1, 0.0, self.momentum, self.l2_reg if reg else 0.0, 0.0, 0.0, 1.0)
-            self._sgd_calls.append((P.calls[-1][1], reg))
+            # (with clipping the L2 gradient was folded into g by mcn_clip_by_global_norm: l2 = 0 here)
+            P.add(lib.mcn_sgd_nesterov_fused_h, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
+                  (ema_w + off) if ema_w else 0, e1 - s1, hp, self.momentum, self.l2_reg if (reg and not clipping) else 0.0,
+                  1 if (reg and not separate_decay) else 0)
             # L1 / pseudo-Huber decay of the decayed range (weights, or everything with bias_norm_decay): a pass of its own
             # after the update, as in the reference; the plain w -= wd*w stays fused in the update kernel
-            if reg and self.decay_mode != _ffi.DECAY_L2 and self.weight_decay > 0.0:
-                P.add(lib.mcn_decoupled_decay, st.data.data_ptr() + off, e1 - s1, 0.0, self.decay_mode, float(self.huber_decay_delta or 0.0))
-                self._decay_calls.append(P.calls[-1][1])
+            if reg and separate_decay:
+                P.add(lib.mcn_decoupled_decay_h, st.data.data_ptr() + off, e1 - s1, hp, self.decay_mode, float(self.huber_decay_delta or 0.0))
         # per-tower clipping by global norm (optimizers.py:112-113): folds the L2 gradient into g, then scales
         self._clip = Program()
         if self.gradient_threshold is not None:
@@ -126,7 +136,7 @@ class Optimizer(object):
         # EMA of the BN running statistics (pre-assign value), launched before the forward pass
         self._pre = Program()
         if self.use_ema and m.stats.size > 0:
-            self._pre.add(lib.mcn_ema_update, m.stats.ema.data_ptr(), m.stats.data.data_ptr(), m.stats.size, 0.0)
+            self._pre.add(lib.mcn_ema_update_h, m.stats.ema.data_ptr(), m.stats.data.data_ptr(), m.stats.size, hp)
         # cross-rank running-statistics chain (convnet.py:1899-1909)
         self._post_fwd = Program()
         self.dp = None
@@ -139,40 +149,67 @@ class Optimizer(object):
         return P
 
     def _set_hyper(self):
+        """Per-step scalars -> the device buffer the update kernels read (one 16-byte stream-ordered copy per step)."""
         m = self.model
         lr = self.init_learning_rate * self.curr_multiplier
         d = min(m.moving_average_decay, (1.0 + m.global_step) / (10.0 + m.global_step))     # tf EMA num_updates rule
         wd = self.weight_decay * (self.curr_multiplier if self.weight_decay_scheduling else 1.0)
         gscale = 1.0 / m.world_size                                                          # tower mean, optimizers.py:138
-        for args, reg in self._sgd_calls:
-            args[5] = lr
-            args[9] = d
-            args[10] = gscale
-            args[8] = wd if (reg and not self._decay_calls) else 0.0
-            if self.gradient_threshold is not None:
-                args[7] = 0.0                            # the L2 gradient was folded into g by mcn_clip_by_global_norm
-        for args in self._decay_calls:
-            args[2] = wd
-        for args in self._ema_calls:
-            args[3] = d
-        if len(self._pre):
-            self._pre.calls[0][1][3] = d
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3] = lr, wd, d, gscale
+        self._hyper.copy_(h, non_blocking=True)
         return lr
 
     # ---- one step ---------------------------------------------------------------------------------------------------------------
+    def _step_body(self):
+        """Every launch of one optimisation step on the current stream (single process): replayable as a hipGraph."""
+        m = self.model
+        sp = m.stream_ptr()
+        self._pre.run(sp)
+        m.forward(train=True)
+        m.backward()
+        if len(self._clip) > 0:
+            self._clip.run(sp)
+        self.optimization_operation.run(sp)
+
+    def _capture_step(self):
+        """Capture _step_body once (forward, backward incl. the wgrad side stream's fork / join, clipping, update: ~600 launches in
+        bf16) into a hipGraph through torch's capture API; addresses are static (compile() allocates everything once) and the
+        per-step scalars come from the device buffer, so a step is then ONE graph launch + the 16-byte hyper-parameter copy.
+        Results are bit-identical to the eager launch lists (same kernels, same order, same streams)."""
+        m = self.model
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(device=m.device)
+        cap.wait_stream(torch.cuda.current_stream(m.device))
+        with torch.cuda.graph(g, stream=cap):
+            self._step_body()
+        torch.cuda.current_stream(m.device).wait_stream(cap)
+        self._graph = g
+        self._graph_low = m._train_low                   # a re-lowering (compile, autotune) invalidates the capture
+
     def _step(self, handles=None, merged=None, writer=None, summary=False, log_trace=False, fetch=True):
         """reference optimizers.py:565-606: one optimisation step on the batch currently in the model's input buffers.
         Returns (loss, Y_true, Y_pred) as numpy when fetch=True (the reference's behaviour), else device tensors
         without synchronising."""
         m = self.model
         self._set_hyper()
-        sp = m.stream_ptr()
-        self._pre.run(sp)
         if m._random_nodes:
             m.sample_random_masks()
-        m.forward(train=True)
-        clip = len(self._clip) > 0
-        if self.dp is not None:
+        if self.dp is None and self.use_graph:
+            if self._graph is not None and self._graph_low is not m._train_low:
+                self._graph = None
+            if self._graph is None and self._eager_steps >= 2:          # two eager steps first (lazy event / scratch creation)
+                self._capture_step()
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._step_body()
+                self._eager_steps += 1
+        elif self.dp is not None:
+            sp = m.stream_ptr()
+            self._pre.run(sp)
+            m.forward(train=True)
+            clip = len(self._clip) > 0
             self.dp.gather_bn_stats()
             self._post_fwd.run(sp)
             if clip:                                     # towers clip their own gradient before the mean
@@ -182,11 +219,9 @@ class Optimizer(object):
             else:
                 m.backward(self.dp.hooks())
                 self.dp.finish()
+            self.optimization_operation.run(sp)
         else:
-            m.backward()
-            if clip:
-                self._clip.run(sp)
-        self.optimization_operation.run(sp)
+            self._step_body()
         m.global_step += 1
         if fetch:
             loss = self._mean_loss()

@@ -135,3 +135,40 @@ def test_loss_scaling_keeps_injected_variables_and_changes_nothing(dtype):
         assert abs(l128 - rloss) <= 1e-4 * abs(rloss)
         worst = max((rel_l2(g128[k], rgrads[k]), k) for k in rgrads)
         assert worst[0] <= 1e-3, worst
+
+
+@pytest.mark.parametrize('kind', ['resnet_fp32', 'resnet_bf16', 'effnet_bf16'])
+def test_graph_replay_is_bit_identical_to_eager_launch_lists(kind):
+    """One hipGraph launch per step (Optimizer._capture_step: forward, backward with the wgrad side stream, update; per-step
+    scalars from the device hyper-parameter buffer) against the eager launch lists: 6 steps with a moving learning rate, EMA
+    decay and — EfficientNet — fresh stochastic-depth / dropout masks every step; losses and every variable bit for bit."""
+    import myconvnet_amd as M
+    import torch
+    res = {}
+    for graph in (False, True):
+        if kind.startswith('resnet'):
+            model, spec, params, stats = make_resnet(50, 'float32' if kind.endswith('fp32') else 'bfloat16', True)
+        else:
+            from test_gpu_efficientnet import make_effnet
+            model, spec, params, stats = make_effnet('bfloat16', True, initial_drop_rate=0.1, final_drop_rate=0.3, dropout_rate=0.2)
+        model._mask_rng = np.random.default_rng(4242)
+        opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=4, num_epochs=3, learning_warmup_epochs=1.0,
+                                  learning_rate_decay_method='cosine', learning_rate_decay_params=(0,), base_weight_decay=0.01, use_graph=graph)
+        rng = np.random.default_rng(321)
+        losses = []
+        for step in range(6):
+            x = rng.random((8, 64, 64, 3)).astype(np.float32)
+            y = rng.integers(0, 10, 8).astype(np.float32)
+            model.feed(x, y)
+            opt._update_learning_rate()
+            loss, _, pred = opt._step(None)
+            opt.curr_step += 1
+            losses.append(loss)
+        assert (opt._graph is not None) == graph                          # steps 3-6 were graph replays
+        torch.cuda.synchronize()
+        res[graph] = (losses, model.get_variables('data'), model.get_variables('ema'), pred)
+    assert res[False][0] == res[True][0]
+    for which in (1, 2):
+        for k, v in res[False][which].items():
+            np.testing.assert_array_equal(v, res[True][which][k], err_msg=k)
+    np.testing.assert_array_equal(res[False][3], res[True][3])
