@@ -794,19 +794,23 @@ __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f3
 // bf16 pixel-major tile: row stride RS bytes, 32-byte granule g of pixel row p stored at granule g ^ key(p)
 __device__ __forceinline__ int tn_key(int p) { return (p & 3) | (((p >> 3) & 1) << 2); }
 
-template <typename T, int BR, int BN, bool LINEAR>
-__global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
+// NW waves per workgroup: 4 = 2x2 waves; 8 = 4x2 waves on the same tile (wave tile BR/4 x BN/2): the 128x128 tile needs 64 KB of LDS,
+// i.e. two workgroups per CU — with 4 waves each a SIMD holds 2 waves and its MFMA pipe idles whenever both sit at the
+// barrier / DMA wait (fp32: 69 % busy by SQ_VALU_MFMA_BUSY_CYCLES); 8 waves put 4 on every SIMD at the same tile traffic.
+template <typename T, int BR, int BN, bool LINEAR, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
     typedef TNCfg<T> CF;
     constexpr int CE = VecTraits<T>::CE;
     constexpr int KP = CF::KP;
     constexpr int XRS = BR * (int)sizeof(T);           // X tile row stride (bytes): 256 / 512
     constexpr int DRS = BN * (int)sizeof(T);
     constexpr int XCPR = BR / CE, DCPR = BN / CE;      // chunks per pixel row
-    constexpr int XPR = 256 / XCPR, DPR = 256 / DCPR;  // pixel rows per staging pass
+    constexpr int NT = NW * 64;                        // threads
+    constexpr int XPR = NT / XCPR, DPR = NT / DCPR;    // pixel rows per staging pass
     constexpr int XN = KP / XPR, DN = KP / DPR;        // chunks per thread
     constexpr int XBYTES = KP * XRS, DBYTES = KP * DRS;
     constexpr int TILE_BYTES = XBYTES + DBYTES;
-    constexpr int WTR = BR / 2, WTN = BN / 2;
+    constexpr int WTR = BR / (NW / 2), WTN = BN / 2;
     constexpr int TR = WTR / CF::MT, TNn = WTN / CF::MT;
     constexpr int DGM = (DRS / 32) - 1;                // granule masks of the D / X tiles
     constexpr int XGM = (XRS / 32) - 1;
@@ -860,7 +864,8 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
     const bool dcol_ok = dn < p.Nn;
 
     const unsigned xoob = xcol_ok ? 0u : MCN_OOB, doob = dcol_ok ? 0u : MCN_OOB;       // loop-invariant column masks
-    static_assert(XPR * XRS == 4096 && DPR * DRS == 4096, "one staging pass of the workgroup = 4 KiB of LDS");
+    static_assert(XPR * XRS == NT * 16 && DPR * DRS == NT * 16, "one staging pass of the workgroup = 16 bytes per thread");
+    static_assert(XN >= 1 && DN >= 1 && WTR % CF::MT == 0, "tile too small for this many waves");
     __attribute__((address_space(3))) char* const wbase =
         (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
     auto issue = [&](int ks, auto bufc) {
@@ -884,13 +889,13 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(const GemmTNParams p) {
                 if (py[i] >= p.OH) { py[i] -= p.OH; pimg[i] += 1; }
                 pimg[i] += dKi;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * 4096)), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * (NT * 16))), 16, (int)off, 0, 0, 0);
         });
         static_for<DN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + dpr + DPR * i;
             const unsigned off = (((unsigned)m * (unsigned)p.ldy + (unsigned)dn) * (unsigned)sizeof(T)) | doob | (((unsigned)(p.M - 1 - m) >> 31) << 31);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + XBYTES + i * 4096)), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + XBYTES + i * (NT * 16))), 16, (int)off, 0, 0, 0);
         });
     };
     constexpr int ACCN = CF::MT == 16 ? 4 : 16;

@@ -31,9 +31,10 @@ class Lowering(object):
         self.prepack = Program()       # one launch: cast / re-pack every conv weight from its fp32 master (or EMA shadow)
         self.ws = None
         self.keep = []                 # objects that must outlive the programs (ctypes structs, scratch)
-        # BN statistics in the conv epilogue: on for bf16 (+2-3 % end to end); fp32's 1x1 convs are output-bound and the
-        # epilogue costs them what the skipped statistics pass saves, so fp32 keeps the separate pass unless asked
-        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', _env_flag('MCN_FUSE_BN_STATS', graph.dtype != 'float32')))
+        # BN statistics in the conv epilogue: +2-3 % end to end for the 2-byte types; in fp32 the round-1 epilogue cost the
+        # output-bound 1x1 convs what the skipped statistics pass saved, with the branch-free packed-math epilogue of round 2 it
+        # nets +0.7 % (71.2 vs 71.8 ms per step, two A/B pairs on one box) and is on for every dtype
+        self.fuse_bn_stats = bool(model._parameters.get('fuse_bn_stats', _env_flag('MCN_FUSE_BN_STATS', True)))
         # (+1 % in bf16, +0.6 % in fp32 since the accumulate epilogue issues its loads in one batch)
         self.defer_dskip = bool(model._parameters.get('defer_dskip', _env_flag('MCN_DEFER_DSKIP', True)))
         self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
