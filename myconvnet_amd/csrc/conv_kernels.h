@@ -70,6 +70,7 @@ struct GemmTNParams {
     int Nn, ldy;
     int nsteps, steps_per_split;
     unsigned x_bytes, dy_bytes;
+    int dbg;                // DEBUG probes (MCN_TN_DBG): 1 = X staged for the first K-step only, 2 = DY likewise (wrong results, timing only)
     signed char tdy[MCN_MAX_TAPS];
     signed char tdx[MCN_MAX_TAPS];
 };
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : 1)) void conv_
             const int tw = p.tap[tap];
             const int dy = (short)(tw & 0xffff), dx = tw >> 16;
             const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + cb * 128);
+            if (!((p.epi_flags & 8) && tap != 0))      // DEBUG probe (MCN_NT_EPI_FLAGS=8): A staged for the first tap only — wrong results, timing only
             static_for<AR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
@@ -646,6 +648,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : 1)) void conv_
             });
         }
         const unsigned oobb = MODE == NT_UNIFORM ? 0u : ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
+        if (!((p.epi_flags & 16) && ks % 9 != 0))      // DEBUG probe (MCN_NT_EPI_FLAGS=16): B staged every 9th K-step only
         static_for<BR>([&](auto ic) { ldB(ic, (b_off[decltype(ic)::value] + (unsigned)ks * 128u) | oobb); });   // OOB + small stays OOB
     };
     typename MM::Acc acc[TN][TM];
@@ -870,6 +873,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
         (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
     auto issue = [&](int ks, auto bufc) {
         constexpr int B = decltype(bufc)::value;
+        if (!((p.dbg & 1) && ks != ks0))
         static_for<XN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + xpr + XPR * i;
@@ -891,6 +895,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * (NT * 16))), 16, (int)off, 0, 0, 0);
         });
+        if (!((p.dbg & 2) && ks != ks0))
         static_for<DN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + dpr + DPR * i;
