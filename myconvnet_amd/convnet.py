@@ -354,10 +354,7 @@ class ConvNet(object):
                 a['saved'] = dict(mean=torch.zeros(c, dtype=torch.float32, device=dev), invstd=torch.zeros(c, dtype=torch.float32, device=dev),
                                   bmean=self.batch_stats[mu.offset:mu.offset + c], bvar=self.batch_stats[sg.offset:sg.offset + c])
             elif n.op == 'mulmask':
-                x = n.inputs[0]
-                ce = 4 if x.dtype == 'float32' else 8
-                cols = ce if n.attrs['kind'] == 'sample' else x.shape[-1]
-                n.attrs['mask'] = torch.ones((x.shape[0], cols), dtype=TORCH_DT[x.dtype], device=dev)
+                pass                                       # one flat buffer for all masks, below
             elif n.op == 'loss':
                 a = n.attrs
                 a['pred'] = self.pred
@@ -367,6 +364,7 @@ class ConvNet(object):
                 a['class_w'] = None if self._loss_weights is None else torch.tensor(np.asarray(self._loss_weights, dtype=np.float32), device=dev)
                 self.loss_buf = a['loss']
                 self.valid_coef = a['coef']
+        self._allocate_masks()
         g.allocate(training=True)
 
     def initialize_variables(self, seed=None):
@@ -712,27 +710,63 @@ class ConvNet(object):
         self._random_nodes.append(nd)
         return y
 
+    def _allocate_masks(self):
+        """All dropout / stochastic-depth masks of the model live in ONE device buffer (views per node) with two pinned host
+        staging buffers: a step uploads them with a single asynchronous copy instead of one pageable, host-blocking copy per
+        node (EfficientNet-B0: 17 per step, which kept the host from running ahead of the GPU)."""
+        dev = self.device
+        if not self._random_nodes:
+            return
+        tdt = TORCH_DT[self._random_nodes[0].inputs[0].dtype]
+        offs, total = [], 0
+        for nd in self._random_nodes:
+            x = nd.inputs[0]
+            ce = 4 if x.dtype == 'float32' else 8
+            cols = ce if nd.attrs['kind'] == 'sample' else x.shape[-1]
+            offs.append((total, x.shape[0], cols))
+            total += (x.shape[0] * cols + 7) // 8 * 8                     # 16-byte aligned views
+        self._mask_dev = torch.ones(total, dtype=tdt, device=dev)
+        pin = dev.type == 'cuda'
+        self._mask_host = [torch.ones(total, dtype=tdt).pin_memory() if pin else torch.ones(total, dtype=tdt) for _ in range(2)]
+        self._mask_events = [None, None]
+        self._mask_turn = 0
+        for nd, (o, rows, cols) in zip(self._random_nodes, offs):
+            nd.attrs['mask'] = self._mask_dev[o:o + rows * cols].view(rows, cols)
+            nd.attrs['mask_off'] = o
+
     def sample_random_masks(self, masks=None):
         """Draw the dropout / stochastic-depth masks of the next training step (tf.random.uniform at convnet.py:2507,
-        tf.nn.dropout) and upload them.  `masks` ({node scope: array}) overrides the draw (parity tests feed the
-        oracle's masks)."""
+        tf.nn.dropout) and upload them (one stream-ordered copy from a pinned buffer).  `masks` ({node scope: array})
+        overrides the draw (parity tests feed the oracle's masks)."""
         if masks is None:
             masks = getattr(self, 'fixed_random_masks', None)      # tests pin the draw
+        if not self._random_nodes or getattr(self, '_mask_dev', None) is None:
+            return                                                  # not compiled yet
+        turn = self._mask_turn
+        self._mask_turn ^= 1
+        ev = self._mask_events[turn]
+        if ev is not None:
+            ev.synchronize()                                        # the copy that last read this staging buffer (two steps ago)
+        host = self._mask_host[turn]
         for nd in self._random_nodes:
             x = nd.inputs[0]
             rate = nd.attrs['rate']
+            dev = nd.attrs['mask']
             if masks is not None and nd.scope in masks:
                 keep = np.asarray(masks[nd.scope], dtype=np.float32)
             elif nd.attrs['kind'] == 'sample':
                 keep = (self._mask_rng.random(x.shape[0]) >= rate).astype(np.float32) / (1.0 - rate)
             else:
                 keep = (self._mask_rng.random((x.shape[0], x.shape[-1])) >= rate).astype(np.float32) / (1.0 - rate)
-            dev = nd.attrs.get('mask')
-            if dev is None:
-                continue                                               # not compiled yet
             if nd.attrs['kind'] == 'sample':
                 keep = np.repeat(keep.reshape(-1, 1), dev.shape[1], axis=1)
-            dev.copy_(torch.from_numpy(np.ascontiguousarray(keep)).to(dev.dtype))
+            o = nd.attrs['mask_off']
+            host[o:o + dev.numel()].copy_(torch.from_numpy(np.ascontiguousarray(keep).reshape(-1)))
+        self._mask_dev.copy_(host, non_blocking=True)
+        if self.device.type == 'cuda':
+            if ev is None:
+                ev = self._mask_events[turn] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
 
     def dropout(self, x, rate):
         """Stand-in for tf.nn.dropout at models/resnet_v1_5.py:75 / models/efficientnet.py:121 (on the pooled [N,C]
