@@ -12,9 +12,9 @@
 //      both operands are pixel-major in memory, i.e. the reduction index is the slow one; bf16
 //      fragments come from LDS through ds_read_b64_tr_b16, fp32 through conflict-free b32 reads.
 //
-// conv_gemm_nt stages its tiles with LDS-DMA loads (buffer_load_dwordx4 ... lds) into XOR-swizzled, double-buffered LDS
-// images (the DMA of K-step ks+1 flies under the MFMAs of step ks; one barrier per K-step); conv_gemm_tn stages through
-// registers.  bf16 uses v_mfma_f32_16x16x32_bf16,
+// Both kernels stage their tiles with LDS-DMA loads (buffer_load_dwordx4 ... lds) into XOR-swizzled, double-buffered LDS
+// images (the DMA of K-step ks+1 flies under the MFMAs of step ks; one barrier per K-step; the swizzle sits on the SOURCE
+// address because a wave-instruction writes LDS in lane order).  bf16 / fp16 use v_mfma_f32_16x16x32_{bf16,f16},
 // fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32; no TF32 on gfx950).  Operand order is
 // (weights, activations) so that each lane ends with 4 consecutive output channels of one pixel
 // => 8/16-byte epilogue stores.

@@ -10,14 +10,14 @@ O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for dt in fp32 bf16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$dt -o s -- python3 $R/bench.py --steps 10 --warmup 3 --dtype $dt --no-secondary > $O/bench_$dt.json 2> $O/bench_$dt.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_$dt -o s -- python3 $R/bench.py --steps 10 --warmup 3 --dtype $dt --no-secondary --no-cpu-baseline --no-overlap > $O/serial_$dt.json 2> $O/serial_$dt.err
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$dt -o s -- python3 $R/bench.py --steps 10 --warmup 3 --dtype $dt --no-secondary > $O/bench_$dt.json 2> $O/bench_$dt.err
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_$dt -o s -- python3 $R/bench.py --steps 10 --warmup 3 --dtype $dt --no-secondary --no-cpu-baseline --no-overlap > $O/serial_$dt.json 2> $O/serial_$dt.err
   echo "stats $dt done"
 done
 for dt in fp32 bf16; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_$dt -o p -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $dt --no-secondary --no-cpu-baseline > $O/pmc_${c}_$dt.json 2> $O/pmc_${c}_$dt.err
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_$dt -o p -- python3 $R/bench.py --steps 1 --warmup 1 --dtype $dt --no-secondary --no-cpu-baseline > $O/pmc_${c}_$dt.json 2> $O/pmc_${c}_$dt.err
     echo "pmc $c $dt done"
   done
 done
-cd $R && python3 profiles/summarize.py $O
+cd $R && python3 profiles/summarize.py $O ${ROUND:-round2}

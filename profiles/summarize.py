@@ -1,6 +1,6 @@
 """Turn the raw rocprofv3 output of profiles/collect.sh into the small committed summaries:
-  round1_<dtype>_b256_kernel_stats.csv   rocprofv3's own per-kernel --stats table
-  round1_<dtype>_b256_bench.json         the JSON line bench.py printed under the profiler
+  <round>_<dtype>_b256_kernel_stats.csv   rocprofv3's own per-kernel --stats table
+  <round>_<dtype>_b256_bench.json         the JSON line bench.py printed under the profiler
   pmc_traffic_<dtype>.json               HBM bytes per launch per kernel = (2*FETCH_SIZE + WRITE_SIZE) * 1024
 (FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide
 coalesced reads, so it is doubled — MI355X_MICROARCH.md, "HBM".)"""
@@ -64,13 +64,13 @@ def counter_rows(d):
     return acc
 
 
-def main(root):
+def main(root, rnd='round2'):
     here = os.path.dirname(os.path.abspath(__file__))
     for dt in ('fp32', 'bf16'):
         for src, tag in (('stats_', ''), ('serial_', 'serial_')):
             st = glob.glob(os.path.join(root, src + dt, '**', '*kernel_stats.csv'), recursive=True)
             if st:
-                with open(st[0]) as fh, open(os.path.join(here, 'round1_%s_b256_%skernel_stats.csv' % (dt, tag)), 'w') as out:
+                with open(st[0]) as fh, open(os.path.join(here, '%s_%s_b256_%skernel_stats.csv' % (rnd, dt, tag)), 'w') as out:
                     rd = csv.reader(fh)
                     wr = csv.writer(out, quoting=csv.QUOTE_MINIMAL)
                     for i, row in enumerate(rd):
@@ -80,7 +80,7 @@ def main(root):
         for src, tag in (('bench_', ''), ('serial_', 'serial_')):
             bj = os.path.join(root, '%s%s.json' % (src, dt))
             if os.path.exists(bj) and os.path.getsize(bj):
-                shutil.copy(bj, os.path.join(here, 'round1_%s_b256_%sbench.json' % (dt, tag)))
+                shutil.copy(bj, os.path.join(here, '%s_%s_b256_%sbench.json' % (rnd, dt, tag)))
         fe = counter_rows(os.path.join(root, 'pmc_FETCH_SIZE_' + dt))
         wr = counter_rows(os.path.join(root, 'pmc_WRITE_SIZE_' + dt))
         if not fe or not wr:
@@ -105,4 +105,4 @@ def main(root):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof', sys.argv[2] if len(sys.argv) > 2 else 'round2')
