@@ -121,23 +121,43 @@ def load(path=LIB_PATH):
     return lib
 
 
-def _check_fresh(lib):
-    """Refuse a binary built from other sources than the tree it is imported from (editing csrc/ or include/mcn.h and
-    running tests / bench without rebuilding used to run the stale library silently).  MCN_SKIP_BUILD_CHECK=1 overrides."""
-    if os.environ.get('MCN_SKIP_BUILD_CHECK') == '1':
-        return
+def _build_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location('_mcn_build', os.path.join(_HERE, 'build.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    have, want = lib.mcn_build_id().decode(), mod.source_digest()
-    if have != want:
-        raise ImportError('libmcn_hip.so is stale: built from sources {}..., the tree has {}... — rebuild with '
-                          '`python myconvnet_amd/build.py`'.format(have[:12], want[:12]))
+    return mod
 
 
+def _ensure_fresh():
+    """Before loading: the library must have been built from the sources of THIS tree (editing csrc/ or include/mcn.h and
+    running tests / bench without rebuilding used to run the stale binary silently).  build.py records the source digest
+    next to the library; on a mismatch (or a missing library) the library is rebuilt when hipcc is there, else the import
+    fails with the build command.  MCN_SKIP_BUILD_CHECK=1 skips the check, MCN_NO_AUTOBUILD=1 turns the rebuild into an error."""
+    if os.environ.get('MCN_SKIP_BUILD_CHECK') == '1':
+        return None
+    mod = _build_module()
+    want = mod.source_digest()
+    have = None
+    try:
+        with open(LIB_PATH + '.id') as f:
+            have = f.read().strip()
+    except OSError:
+        pass
+    if have == want and os.path.exists(LIB_PATH):
+        return want
+    if os.environ.get('MCN_NO_AUTOBUILD') == '1' or not os.path.exists(mod.HIPCC):
+        raise ImportError('libmcn_hip.so is {}: built from sources {}, the tree has {}... — rebuild with '
+                          '`python myconvnet_amd/build.py`'.format('stale' if have else 'missing', (have or 'none')[:12], want[:12]))
+    mod.build(verbose=False)
+    return want
+
+
+_want = _ensure_fresh()
 lib = load()
-_check_fresh(lib)
+if _want is not None and lib.mcn_build_id().decode() != _want:
+    raise ImportError('libmcn_hip.so reports build id {}..., expected {}... — rebuild with `python myconvnet_amd/build.py --force`'
+                      .format(lib.mcn_build_id().decode()[:12], _want[:12]))
 
 
 def last_error():

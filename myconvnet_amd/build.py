@@ -73,6 +73,8 @@ def build(force=False, verbose=True):
         cmd, rc, out = run(cmd)
         if rc != 0:
             raise RuntimeError('link failed: {}\n{}'.format(' '.join(cmd), out))
+    with open(LIB + '.id', 'w') as fh:                   # what _ffi.py compares with the tree before loading the library
+        fh.write(digest + '\n')
     return LIB
 
 
