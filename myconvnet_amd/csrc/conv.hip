@@ -276,6 +276,47 @@ static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
     return sp;
 }
 
+// conv_gemm_nt_win (input window with halo kept in LDS across the taps): stride-1 tap convolutions on the input's own grid whose
+// window (BM + span rows of 128 bytes, span = (KH-1)*DH*IW + (KW-1)*DW pixels) plus two B buffers stay within 64 KB and 1.6x the
+// LDS of the two-buffer kernel (occupancy: fp32 64x64 keeps 4-5 workgroups per CU up to 56-wide maps).
+// Measured per layer (B = 256): fp32 7x7 492 -> 460 us, 14x14 504 -> 468, 28x28 510 -> 482, 56x56 518 -> 504 (the staging probe's
+// bound was -8 %).  The 2-byte types do NOT gain (bf16 14x14 69.9 -> 71.5 us, 56x56 91 -> 103): their 16-row fragment reads hit
+// the window at odd row offsets, where the (row >> 1) XOR swizzle is 2-way bank-conflicted for the 16x16x32 operand map, and the
+// one exposed window load per channel chunk is a larger share of their short K-steps — fp32 only by default.
+// MCN_NT_WINDOW: 0 = off, 1 = fp32 (default), 2 = every dtype.
+#define NT_WINDOW 3
+static int nt_window_level() {
+    static const int v = [] { const char* e = getenv("MCN_NT_WINDOW"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static bool nt_window_enabled(size_t es) { return nt_window_level() >= (es == 4 ? 1 : 2); }
+static int nt_window_lds(int span, const NtTile& t) {           // 0 = not eligible
+    const int P = t.bm + span, rpp = t.nw * 8;
+    const int wrows8 = (P + 8) & ~7;
+    if (t.nw != 4 || wrows8 > 16 * rpp) return 0;
+    const int lds = wrows8 * 128 + 2 * t.bn * 128;
+    if (lds > 64 * 1024 || lds * 10 > 2 * (t.bm + t.bn) * 128 * 16) return 0;
+    return lds;
+}
+// span of the tap offsets in pixels, or -1 when the geometry does not qualify (same-grid, stride 1, 2..32 taps, whole K-steps per tap)
+static int nt_window_span(size_t es, int ntaps, int cpt, int sy, int sx, bool same_grid, const int* tap, int IW, int* dmin_out) {
+    if (!nt_window_enabled(es) || ntaps < 2 || ntaps > 32 || sy != 1 || sx != 1 || !same_grid || cpt % 8) return -1;
+    int dmin = 0x7fffffff, dmax = -0x7fffffff;
+    for (int t = 0; t < ntaps; ++t) {
+        const int d = (int)(short)(tap[t] & 0xffff) * IW + (tap[t] >> 16);
+        if (d < dmin) dmin = d;
+        if (d > dmax) dmax = d;
+    }
+    if (dmin_out) *dmin_out = dmin;
+    return dmax - dmin;
+}
+
+// the same decision from the conv geometry alone (introspection: kernel names for profiling tables)
+static bool nt_window_geom(const Geo& g, size_t es, int cpt, const NtTile& t) {
+    if (!nt_window_enabled(es) || g.KH * g.KW < 2 || g.KH * g.KW > 32 || g.SH != 1 || g.SW != 1 || g.OH != g.H || g.OW != g.W || cpt % 8) return false;
+    return nt_window_lds((g.KH - 1) * g.DH * g.W + (g.KW - 1) * g.DW, t) != 0;
+}
+
 template <typename T>
 static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mode, bool reduce, hipStream_t st) {
     const NtTile t = kNtCand[tile];
@@ -303,12 +344,35 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
             if (epi == NT_EPI_STATS) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STATS>), grid, block, 0, st, p);    \
             else if (epi == NT_EPI_ACC) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_ACC>), grid, block, 0, st, p);   \
             else hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STORE>), grid, block, 0, st, p);                        \
-        } else if (mode == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_LINEAR);            \
-        else if (mode == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_UNIFORM);            \
+        } else if (mode_nt == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_LINEAR);         \
+        else if (mode_nt == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_UNIFORM);         \
         else MCN_LAUNCH_NT(BMV, BNV, NWV, NT_GENERIC);                                    \
     } while (0)
     // epilogue variant: the accumulate modes have their own instantiation (batched loads), so do the BN statistics
     const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
+    if (mode == NT_WINDOW && !reduce) {
+        const int wlds = nt_window_lds(p.win_rows - t.bm, t);
+#define MCN_LAUNCH_WIN_E(BMV, BNV, EPIV)                                                                  \
+    do {                                                                                                  \
+        static bool once = (allow_lds(conv_gemm_nt_win<T, BMV, BNV, 4, EPIV>, 64 * 1024), true);          \
+        (void)once;                                                                                       \
+        hipLaunchKernelGGL((conv_gemm_nt_win<T, BMV, BNV, 4, EPIV>), grid, block, wlds, st, p);           \
+    } while (0)
+#define MCN_LAUNCH_WIN(BMV, BNV)                                                                          \
+    do {                                                                                                  \
+        if (epi == NT_EPI_STATS) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_STATS);                                \
+        else if (epi == NT_EPI_ACC) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_ACC);                               \
+        else MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_STORE);                                                    \
+    } while (0)
+        if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_WIN(128, 128);
+        else if (t.bm == 128) MCN_LAUNCH_WIN(128, 64);
+        else MCN_LAUNCH_WIN(64, 64);
+#undef MCN_LAUNCH_WIN
+#undef MCN_LAUNCH_WIN_E
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
+    const int mode_nt = mode == NT_WINDOW ? NT_UNIFORM : mode;          // (the stream-K reduce pass of a window launch: epilogue only)
     if (t.nw == 8) {
         if constexpr (sizeof(T) == 2) {
             if (t.bm == 256) MCN_LAUNCH_NT_MODE(256, 128, 8);
@@ -337,7 +401,17 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     // the epilogue addresses the output through a buffer descriptor: images x full output grid x channel stride
     p.out_bytes = (unsigned)((size_t)(p.M / (p.OH * p.OW)) * p.OHf * p.OWf * p.ldo * sizeof(T));
     const long W = (long)((p.M + t.bm - 1) / t.bm) * ((p.Nn + t.bn - 1) / t.bn);
-    const int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
+    int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
+    if (mode == NT_UNIFORM) {
+        const bool same_grid = p.OH == p.IH && p.OW == p.IW && p.osy == 1 && p.osx == 1 && p.OHf == p.OH && p.OWf == p.OW;
+        int dmin = 0;
+        const int span = nt_window_span(sizeof(T), p.ntaps, p.cpt, p.sy, p.sx, same_grid, p.tap, p.IW, &dmin);
+        if (span >= 0 && nt_window_lds(span, t)) {
+            mode = NT_WINDOW;
+            p.win_dmin = dmin;
+            p.win_rows = t.bm + span;
+        }
+    }
     static const int epi_flags = [] { const char* e = getenv("MCN_NT_EPI_FLAGS"); return e ? atoi(e) : 0; }();
     p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
@@ -919,7 +993,8 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
+        if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return 1;
     }
     if (op == MCN_CONV_DGRAD) {
@@ -944,7 +1019,8 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
+        if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return ncls;
     }
     if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_co(g)); return 1; }
@@ -994,7 +1070,9 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
             const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
             const bool lin = nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
             const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-            const int w = snprintf(buf + used, buflen - used, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, mode, kNtCand[t].nw, nt);
+            const int w = (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, kNtCand[t]))
+                              ? snprintf(buf + used, buflen - used, "conv_gemm_nt_win<%s, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, kNtCand[t].nw, nt)
+                              : snprintf(buf + used, buflen - used, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, mode, kNtCand[t].nw, nt);
             if (w < 0 || (size_t)w >= buflen - used) MCN_FAIL(MCN_E_BADARG, "launch_list: buffer too small");
             used += (size_t)w;
             nl++;

@@ -51,6 +51,7 @@ struct GemmNTParams {
     const void* add_src;
     const unsigned char* add_mask;
     unsigned in_bytes, wt_bytes;
+    int win_dmin, win_rows; // conv_gemm_nt_win: smallest tap offset in pixels (dy*IW + dx) and the rows of the input window BM + (dmax - dmin)
     unsigned out_bytes;     // bytes of the whole output tensor (set by launch_nt: buffer range of the epilogue's stores / loads)
     int epi_flags;          // experiments (MCN_NT_EPI_FLAGS): 1 = no lane pairing (8-byte bf16 accesses), 2 = byte-wise mask loads
     int tap[MCN_MAX_TAPS];  // (dy & 0xffff) | (dx << 16) per filter tap: 32-bit so that a wave-uniform tap index is a scalar load
@@ -761,6 +762,199 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_sk_reduce(const GemmNTParams 
                 for (int e = 0; e < ACCSZ; ++e) acc[j][i][e] += src[(size_t)((j * TM + i) * ACCSZ + e) * NT];
     }
     nt_epilogue<T, BM, BN, true, NW, EPI>(p, acc, m0, n0, lane, wave >> 1, wave & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_nt_win: conv_gemm_nt for stride-1 tap convolutions whose output grid is the input grid (3x3 SAME forward, its dgrad,
+// dilated 3x3) with the INPUT WINDOW of the tile kept in LDS across the taps.
+//
+// GEMM row m is output pixel m of the flattened (image, y, x) grid and tap t reads input pixel m + doff_t, doff_t = dy_t*IW +
+// dx_t: all taps of a BM-row tile read the contiguous pixel range [m0 + dmin, m0 + BM + dmax) — the window, P = BM + dmax - dmin
+// rows.  conv_gemm_nt stages a fresh BM-row A tile per K-step (the nine taps re-read the same rows with their halo through L2:
+// PMC 2.3x the algorithmic bytes, and the staging probes put 8 % (fp32) / 20 % (bf16) of the kernel on exactly that); here the
+// K loop runs channel chunk OUTER, tap INNER: the window of one 128-byte channel chunk is staged once (P rows instead of
+// 9 x BM) and the nine K-steps read their A fragments from it at row offset doff_t - dmin.  A tap that leaves the image for a
+// given output pixel must contribute zero although its window row holds a real neighbour (previous image row / image): the
+// lane's fragment address is redirected to a row of zeros — rows >= P of the window allocation are staged out of range, i.e.
+// zero-filled by every window load.  One window buffer, two B buffers: at a chunk boundary the next window is issued after the
+// barrier that retires the last tap's reads (one exposed DMA latency per ntaps K-steps, covered by the other workgroups of
+// the CU).  Everything else (tile -> workgroup map, stream-K slices, epilogue) is conv_gemm_nt's.
+// ------------------------------------------------------------------------------------------------
+#define MCN_WIN_MAXPASS 16
+template <typename T, int BM, int BN, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_nt_win(const GemmNTParams p) {
+    typedef MmaNT<T> MM;
+    constexpr int NT = NW * 64, RPP = NT / 8, WROWS = NW / 2;
+    constexpr int BR = BN / RPP;
+    constexpr int WTM = BM / WROWS, WTN = BN / 2;
+    constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int ntm = (p.m_end - p.m_begin + BM - 1) / BM;
+    const int sk_rel = (int)blockIdx.x - p.sk_body;
+    const bool sk_slice = p.sk_mode == 1 && sk_rel >= 0;
+    const int L = sk_slice ? p.sk_body + sk_rel / p.sk_slices : xcd_remap(blockIdx.x, p.sk_mode == 1 ? p.sk_body : ntm * ntn);
+    const int m0 = p.m_begin + (L / ntn) * BM, n0 = (L % ntn) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
+
+    // LDS: [window: wrows8 rows x 128 B (rows >= P are zero)] [B buffer 0] [B buffer 1]
+    const int P = p.win_rows;
+    const int wrows8 = (P + 8) & ~7;                   // at least one zero row behind the window
+    const int WB = wrows8 * 128;
+    const int ZOFF = P * 128;
+    const int crow = tid >> 3;
+    const int cid = (tid & 7) ^ ((crow >> 1) & 7);     // chunk this thread fetches (source-side swizzle; RPP % 16 == 0: the key is pass-invariant)
+    const int pix_bytes = p.Cs * (int)sizeof(T);
+    const int ntaps = p.ntaps, kpt = p.cpt >> 3;
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + crow + RPP * i;
+        b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u + (unsigned)cid * 16u : MCN_OOB;
+    }
+    __attribute__((address_space(3))) char* const wbaseA =
+        (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
+    __attribute__((address_space(3))) char* const wbaseB =
+        (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024 + WB);
+    const int wrow0 = __builtin_amdgcn_readfirstlane(wave * 8);          // first window row this wave stages in pass 0
+    // window of channel chunk cb: pass ps stages rows [ps*RPP, ps*RPP + RPP); waves whose rows lie behind the allocation skip
+    auto issue_window = [&](int cb) {
+        static_for<MCN_WIN_MAXPASS>([&](auto pc) {
+            constexpr int ps = decltype(pc)::value;
+            if (ps * RPP + wrow0 < wrows8) {                              // wave-uniform
+                const int j = ps * RPP + crow;
+                const int q = m0 + p.win_dmin + j;                        // input pixel of window row j
+                const unsigned bad = (unsigned)q | (unsigned)(p.M - 1 - q) | (unsigned)(P - 1 - j);      // sign bits: outside the tensor / behind the window
+                const unsigned off = ((unsigned)q * (unsigned)pix_bytes + (unsigned)(cb * 128 + cid * 16)) | ((bad >> 31) << 31);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbaseA + ps * RPP * 128), 16, (int)off, 0, 0, 0);
+            }
+        });
+    };
+    auto issue_b = [&](int cb, int t, auto setc) {
+        constexpr int S = decltype(setc)::value;
+        const unsigned koff = (unsigned)(t * kpt + cb) * 128u;
+        static_for<BR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(wbaseB + (S * BN * 128 + i * RPP * 128)), 16,
+                                                     (int)(b_off[i] + koff), 0, 0, 0);                          // (OOB + small stays OOB)
+        });
+    };
+
+    // per fragment row block: window row of the output pixel itself and the taps that stay inside the image (bit t)
+    const int fr = MM::frag_row(lane), fc = MM::frag_chunk(lane);
+    int rloc[TM];
+    unsigned vm[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        rloc[i] = wm * WTM + i * MM::MT + fr - p.win_dmin;
+        const int m = m0 + wm * WTM + i * MM::MT + fr;
+        unsigned bits = 0;
+        if (m < p.m_end) {
+            const int hw = p.OH * p.OW;
+            const int rem = m - (m / hw) * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            for (int t = 0; t < ntaps; ++t) {
+                const int tw = p.tap[t];
+                const int dy = (short)(tw & 0xffff), dx = tw >> 16;
+                bits |= (((unsigned)(oy + dy) < (unsigned)p.IH && (unsigned)(ox + dx) < (unsigned)p.IW) ? 1u : 0u) << t;
+            }
+        }
+        vm[i] = bits;
+    }
+
+    typename MM::Acc acc[TN][TM];
+    nt_init_acc<T, TN, TM>(acc, sk_slice ? nullptr : p.bias, n0 + wn * WTN, p.Nn, lane);
+
+    const int fsw = (fr >> 1) & 7;
+    const int b_rd = (wn * WTN + fr) * 128;
+    static_assert(MM::SLABS % 2 == 0, "slab skew needs an even slab count");
+    typename MM::Frag xa[2][TM], wb[2][TN];
+    int abase[TM], akey[TM];                             // per K-step: byte base and swizzle key of each row block's window row (-1: zero row)
+    auto load_frags = [&](int set, int sl, const char* bbase) {
+        const int ch = sl * MM::CPS + fc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int a = akey[i] < 0 ? ZOFF + (ch << 4) : abase[i] + ((ch ^ akey[i]) << 4);
+            xa[set][i] = *reinterpret_cast<const typename MM::Frag*>(smem + a);
+        }
+        const int coff = ((ch ^ fsw) << 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[set][j] = *reinterpret_cast<const typename MM::Frag*>(bbase + b_rd + j * MM::MT * 128 + coff);
+    };
+    auto mma_set = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[set][j], xa[set][i]);
+    };
+    auto compute = [&](int t, const char* bbase) {
+        const int tw = p.tap[t];
+        const int sh = (short)(tw & 0xffff) * p.IW + (tw >> 16);          // (scalar)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int wr = rloc[i] + sh;
+            abase[i] = wr << 7;
+            akey[i] = ((vm[i] >> t) & 1u) ? ((wr >> 1) & 7) : -1;
+        }
+        load_frags(0, 0, bbase);
+#pragma unroll
+        for (int s = 0; s < MM::SLABS; ++s) {
+            if (s + 1 < MM::SLABS) load_frags((s + 1) & 1, s + 1, bbase);
+            mma_set(s & 1);
+        }
+    };
+
+    const int nk_all = ntaps * kpt;
+    int ks0 = 0, nk = nk_all;
+    if (sk_slice) {
+        const int per = (nk_all + p.sk_slices - 1) / p.sk_slices, sl = sk_rel % p.sk_slices;
+        ks0 = sl * per;
+        nk = min(nk_all, ks0 + per);
+    }
+    constexpr int ACCSZ = (int)(sizeof(typename MM::Acc) / 4);
+    constexpr int NREG = TN * TM * ACCSZ;
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    if (ks0 < nk) {
+        int cb = ks0 / ntaps, t = ks0 - cb * ntaps;      // (a stream-K slice may start in the middle of a channel chunk)
+        bool need_win = true;
+        auto step = [&](int s, auto cur, auto nxt) {
+            if (need_win) {
+                if (s > ks0) __syncthreads();            // every wave has finished reading the previous chunk's window
+                issue_window(cb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int t2 = t + 1, cb2 = cb;
+            if (t2 == ntaps) { t2 = 0; cb2 = cb + 1; }
+            if (s + 1 < nk) issue_b(cb2, t2, nxt);
+            compute(t, smem + WB + decltype(cur)::value * (BN * 128));
+            need_win = t2 == 0;
+            t = t2;
+            cb = cb2;
+        };
+        issue_b(cb, t, S0{});
+        for (int s = ks0; s < nk; s += 2) {
+            step(s, S0{}, S1{});
+            if (s + 1 < nk) step(s + 1, S1{}, S0{});
+        }
+    }
+    if (sk_slice) {
+        float* dst = p.partial + ((size_t)sk_rel * NREG) * NT + tid;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < ACCSZ; ++e) dst[(size_t)((j * TM + i) * ACCSZ + e) * NT] = acc[j][i][e];
+        return;
+    }
+    nt_epilogue<T, BM, BN, true, NW, EPI>(p, acc, m0, n0, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------

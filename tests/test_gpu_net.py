@@ -154,8 +154,14 @@ def test_resnet_frozen_blocks_and_frozen_batch_norm(freeze, dtype):
             flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in sorted(rgrads)])
             assert cosine(flat(grads), flat(rgrads)) >= 0.98
         else:
+            # step 0 differs from the float64 oracle by rounding alone (measured <= 2e-6 per tensor).  After one lr = 0.1 update
+            # a pre-activation within fp32 rounding of zero may fall on the other side of the ReLU than in float64: ONE such
+            # element moves a 16-channel beta gradient by 3e-3 (seen: 15 channels at 2e-8, one at 1.4e-4), so the per-tensor
+            # bound of the second step allows for single flips and the whole gradient keeps the tight one.
             worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
-            assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+            assert worst[0] <= (1e-5 if step == 0 else 1e-2), 'step {}: worst gradient {}'.format(step, worst)
+            flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in sorted(rgrads)])
+            assert rel_l2(flat(grads), flat(rgrads)) <= 1e-3
         got, ema = model.get_variables('data'), model.get_variables('ema')
         tol = 2e-2 if bf else 1e-4
         worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
