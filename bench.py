@@ -128,6 +128,14 @@ def timed(opt, steps, warmup, world, autotune=False):
 
 
 # ---- per-kernel timing (instrumented pass) ---------------------------------------------------------------------
+def _not_persistent(sym):
+    """conv_gemm_nt_pers<T, BM, BN, NW, E> -> the conv_gemm_nt symbol of the same tile (mcn_conv2d_kernel_name answers from the
+    geometry alone; launches with a bias, and fp32 launches with the accumulate epilogue, stay on conv_gemm_nt)."""
+    import re
+    m = re.match(r'conv_gemm_nt_pers<(.+), (\d+), (\d+), (\d+), (\d+)>$', sym)
+    return 'conv_gemm_nt<{}, {}, {}, 0, {}, {}>'.format(*m.groups()) if m else sym
+
+
 def instrumented_pass(model, dtype, reps=3, layers=False):
     """Time every C-ABI launch of forward+backward with HIP events on the launch stream (torch's current stream IS the
     launch stream).  Conv calls are keyed by the exact kernel symbol rocprofv3 reports (mcn_conv2d_kernel_name); a call
@@ -178,6 +186,8 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 op = _ffi.CONV_FWD if name == 'mcn_fc_fwd' else (_ffi.CONV_DGRAD if a[3] else _ffi.CONV_WGRAD)
                 nl = lib.mcn_conv2d_kernel_name(op, ctypes.byref(gm), mdt, buf, 128)
                 key = buf.value.decode()
+                if name == 'mcn_fc_fwd':                                   # biased: not the persistent kernel
+                    key = _not_persistent(key)
                 flop = 2.0 * B_ * In_ * Out_
                 es = 4 if dtype == 'fp32' else 2
                 byt = es * B_ * (In_ + Out_) + (4 if op == _ffi.CONV_WGRAD else es) * In_ * Out_
@@ -197,6 +207,9 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 elif (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
                     epi = ', 2>'                                           # ... with the accumulate epilogue
                 launches = [(k.replace(', 0>', epi) if epi else k, int(t)) for k, t in launches]
+                if (epi == ', 2>' and dtype == 'fp32') or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
+                    # fp32 keeps conv_gemm_nt for the accumulate epilogue; by default only the statistics forward is persistent
+                    launches = [(_not_persistent(k), t) for k, t in launches]
                 key = max(launches, key=lambda kt: kt[1])[0]               # (per-layer table: the launch with the most taps)
                 es = 4 if dtype == 'fp32' else 2
                 # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)

@@ -390,6 +390,63 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
     return MCN_OK;
 }
 
+// conv_gemm_nt_pers (persistent workgroups with the next tile's first K-step prefetched under the epilogue): the 1x1 /
+// stride-1 launches without bias on the 4-wave tiles that run unsplit.  MCN_NT_PERS: 0 = off, 1 = forward with statistics (default), 2 = all.
+// Measured per layer (B = 256, us): bf16 128x128 56x56 64->256 fwd+stats 151 -> 127, 28x28 128->512 94 -> 84, 7x7 512->2048 45 -> 37,
+// dgrad+residual 14x14 72 -> 67, 7x7 56 -> 51; the 128x64 tile (Nn = 64 layers) loses 1-10 %, the 8-wave tile loses on the
+// statistics epilogue (its VALU work doubles per pixel row); fp32 64x64 gains 2-9 % with the store / statistics epilogues and
+// loses 2-12 % with the accumulate one (its loads wait behind the prefetch).
+// In the training step only the forward launches (statistics epilogue) use it: the backward's dgrad launches share the chip with
+// the wgrad GEMMs of the side stream, and workgroups with a fixed tile list cannot rebalance around them — with every eligible
+// launch persistent the bf16 step was 0.16 ms SLOWER although its kernels summed to 0.35 ms less (MCN_NT_PERS=2: all of them).
+static bool nt_pers_tile(const NtTile& t, size_t es, int epi) {
+    static const int level = [] { const char* e = getenv("MCN_NT_PERS"); return e ? atoi(e) : 1; }();
+    if (level <= 0 || t.nw != 4 || (level == 1 && epi != NT_EPI_STATS)) return false;
+    return es == 4 ? (t.bm == 64 && epi != NT_EPI_ACC) : (t.bm == 128 && t.bn == 128);
+}
+// introspection twin of launch_nt's decision (assumes the caller hands over the stream-K workspace, as the executor does)
+static bool nt_pers_geom(int tile, long M, int Nn, int nchunks, size_t es, int tile_hint, int epi = NT_EPI_STORE) {
+    const NtTile t = kNtCand[tile];
+    if (!nt_pers_tile(t, es, epi)) return false;
+    const long W = ((M + t.bm - 1) / t.bm) * ((Nn + t.bn - 1) / t.bn);
+    return (tile_hint & MCN_TILE_NOSPLIT) || sk_plan(tile, W, (nchunks + 7) >> 3, es).slices < 2;
+}
+template <typename K>
+static int pers_slots(K kernel, int threads, int lds) {
+    allow_lds(kernel, lds);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), threads, (size_t)lds) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    return n;
+}
+template <typename T>
+static int launch_nt_pers(const GemmNTParams& p, int tile, long W, hipStream_t st) {
+    const NtTile t = kNtCand[tile];
+    const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
+    const int lds = 2 * (t.bm + t.bn) * 128;
+#define MCN_LAUNCH_PERS_E(BMV, BNV, NWV, EPIV)                                                                  \
+    do {                                                                                                        \
+        static const int slots = pers_slots(conv_gemm_nt_pers<T, BMV, BNV, NWV, EPIV>, NWV * 64, 2 * (BMV + BNV) * 128); \
+        const long cap = (long)slots * MCN_NUM_CU;                                                              \
+        hipLaunchKernelGGL((conv_gemm_nt_pers<T, BMV, BNV, NWV, EPIV>), dim3((unsigned)(W < cap ? W : cap)), dim3(NWV * 64), lds, st, p); \
+    } while (0)
+#define MCN_LAUNCH_PERS(BMV, BNV, NWV)                                                   \
+    do {                                                                                 \
+        if (epi == NT_EPI_STATS) MCN_LAUNCH_PERS_E(BMV, BNV, NWV, NT_EPI_STATS);         \
+        else if (epi == NT_EPI_ACC) MCN_LAUNCH_PERS_E(BMV, BNV, NWV, NT_EPI_ACC);        \
+        else MCN_LAUNCH_PERS_E(BMV, BNV, NWV, NT_EPI_STORE);                             \
+    } while (0)
+    if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_PERS(128, 128, 4);
+    else if (t.bm == 64 && t.bn == 64) MCN_LAUNCH_PERS(64, 64, 4);
+    else MCN_FAIL(MCN_E_UNSUPPORTED, "conv: no persistent instantiation for this tile");
+#undef MCN_LAUNCH_PERS
+#undef MCN_LAUNCH_PERS_E
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
 // sk_ws: scratch for the stream-K partials (may be null / too small: the conv then runs unsplit)
 template <typename T>
 static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
@@ -415,7 +472,11 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     static const int epi_flags = [] { const char* e = getenv("MCN_NT_EPI_FLAGS"); return e ? atoi(e) : 0; }();
     p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
-    if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
+    if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) {
+        if (mode == NT_LINEAR && !p.bias && nt_pers_tile(t, sizeof(T), p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE)))
+            return launch_nt_pers<T>(p, tile, W, st);
+        return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
+    }
     p.sk_mode = 1;
     p.sk_body = sp.body;
     p.sk_slices = sp.slices;
@@ -994,6 +1055,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
         if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cout, cpt, mcn_dtype_size(dtype), g.tile, NT_EPI_STATS)) snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);   /* (answers for mcn_conv2d_fwd_bnstats; a biased launch, and by default a forward without statistics: conv_gemm_nt) */
         else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return 1;
     }
@@ -1020,6 +1082,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
         if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cin, nt0 * cpt, mcn_dtype_size(dtype), g.tile)) snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
         else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return ncls;
     }
@@ -1072,6 +1135,8 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
             const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
             const int w = (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, kNtCand[t]))
                               ? snprintf(buf + used, buflen - used, "conv_gemm_nt_win<%s, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, kNtCand[t].nw, nt)
+                          : (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cin, nt * cpt, mcn_dtype_size(dtype), g.tile))
+                              ? snprintf(buf + used, buflen - used, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, kNtCand[t].nw, nt)
                               : snprintf(buf + used, buflen - used, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, mode, kNtCand[t].nw, nt);
             if (w < 0 || (size_t)w >= buflen - used) MCN_FAIL(MCN_E_BADARG, "launch_list: buffer too small");
             used += (size_t)w;

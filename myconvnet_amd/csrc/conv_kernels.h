@@ -264,6 +264,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     // odd ones, after which every lane owns 8 consecutive channels = one 16-byte access (loads of the accumulate path alike).
     constexpr bool PAIR = ES == 2;
     static_assert(!PAIR || (MM::MT == 16 && TM % 2 == 0), "lane pairing needs 16x16 accumulators and an even row-block count");
+    if (p.epi_flags & 32) return;                              // DEBUG probe (MCN_NT_EPI_FLAGS=32): no epilogue at all — timing only
     const int fr = MM::frag_row(lane);
     // first of the 4 consecutive output channels that accumulator group (j, g) holds in this lane
     auto col = [&](int j, int g) -> int { return n0 + wn * WTN + j * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * g + 4 * (lane >> 5)); };
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : 1)) void conv_
             // K tail as arithmetic (bit 31 = out of range), not as a select: hipcc turned `kv ? off : OOB` into two DMA
             // instructions under complementary exec masks behind a branch — 12 DMAs and 11 branches per K-step instead of 8 and 0
             const unsigned oob = ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
+            if (!((p.epi_flags & 8) && ks != 0))
             static_for<AR>([&](auto ic) { ldA(ic, (a_off[decltype(ic)::value] + (unsigned)ks * 128u) | oob); });
         } else {
             const int j = ks * 8 + cid;
@@ -762,6 +764,157 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_sk_reduce(const GemmNTParams 
                 for (int e = 0; e < ACCSZ; ++e) acc[j][i][e] += src[(size_t)((j * TM + i) * ACCSZ + e) * NT];
     }
     nt_epilogue<T, BM, BN, true, NW, EPI>(p, acc, m0, n0, lane, wave >> 1, wave & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_nt_pers: the NT_LINEAR conv_gemm_nt (1x1 / stride 1: A is a plain [M][Cs] matrix) as a PERSISTENT kernel.
+//
+// Probes on the 1x1 layers of ResNet-50 (round 2, bf16, B = 256: `MCN_NT_EPI_FLAGS=32` = no epilogue, `=24` = operands staged
+// for the first K-step only) showed that their time is the SUM of the K loop and the epilogue, not the larger of the two:
+// 56x56 64 -> 256 forward 157 us = 47 (loads + MFMA) + 110 (stores + statistics), 28x28 128 -> 512 95 = 30 + 65, 14x14 1024 -> 256
+// dgrad + residual 73 = 24 + 49 — a workgroup loads, multiplies, stores and retires, and the next one on that slot starts with an
+// address prologue and a full DMA round trip before its first MFMA, while HBM idles through every K loop and the MFMAs through
+// every epilogue.  Here a workgroup walks tiles v = blockIdx.x, + gridDim.x, ... (grid = resident slots; xcd_remap keeps an
+// XCD on a contiguous tile range) and issues the first K-step of tile i+1 into the free LDS buffer right after the barrier
+// of the LAST K-step of tile i: that DMA flies under the last MFMAs and the whole epilogue of tile i.
+//   * vmcnt counts loads, stores and LDS-DMAs together, in issue order: the first wait of tile i+1 is `vmcnt(NSTORE)`,
+//     NSTORE = the store instructions the epilogue always issues — the prefetched DMAs are older than those and have landed,
+//     the stores themselves stay in flight.  (Statistics partials are extra, conditional stores: they only make the wait more
+//     conservative.)  Raw s_barrier: a __syncthreads() fence would drain the counter.
+//   * the two LDS buffers alternate over the flattened (tile, K-step) sequence; buffer indices are compile-time constants
+//     (DMA aliasing, see conv_gemm_nt), so the tile body exists for both starting parities and a K loop with an odd number
+//     of steps alternates between them.
+// Not for: a bias (its load would wait vmcnt(0) behind the previous tile's stores), stream-K launches.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2 : (BM == 128 ? 3 : 4)))) void conv_gemm_nt_pers(const GemmNTParams p) {
+    typedef MmaNT<T> MM;
+    constexpr int NT = NW * 64, RPP = NT / 8, WROWS = NW / 2;
+    constexpr int AR = BM / RPP, BR = BN / RPP;
+    constexpr int WTM = BM / WROWS, WTN = BN / 2;
+    constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);
+    constexpr int NSTORE = sizeof(T) == 2 ? (TM / 2) * TN : TM * TN * NG;      // nt_epilogue's unconditional stores per wave
+    static_assert(NSTORE >= 1 && NSTORE < 48, "vmcnt immediate");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int total = ((p.m_end - p.m_begin + BM - 1) / BM) * ntn;
+    const int nk = (p.nchunks + 7) >> 3;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
+    const int crow = tid >> 3;
+    const int cid = (tid & 7) ^ ((crow >> 1) & 7);
+    const unsigned rowb = (unsigned)p.Cs * (unsigned)sizeof(T);
+
+    int v = blockIdx.x, m0 = 0, n0 = 0;                // (grid <= total)
+    unsigned a_off[AR], b_off[BR];
+    auto set_tile = [&](int vv) {
+        const int L = xcd_remap(vv, total);
+        m0 = p.m_begin + (L / ntn) * BM;
+        n0 = (L % ntn) * BN;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = m0 + crow + RPP * i;
+            a_off[i] = ((unsigned)m * rowb + (unsigned)cid * 16u) | (((unsigned)(p.m_end - 1 - m) >> 31) << 31);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + crow + RPP * i;
+            b_off[i] = ((unsigned)n * (unsigned)p.nchunks * 16u + (unsigned)cid * 16u) | (((unsigned)(p.Nn - 1 - n) >> 31) << 31);
+        }
+    };
+    __attribute__((address_space(3))) char* const wbase =
+        (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto issue = [&](int ks, auto setc) {
+        constexpr int S = decltype(setc)::value;
+        const unsigned oob = ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;      // K tail (bit 31 = out of range: zero fill)
+        static_for<AR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbase + (S * TILE_BYTES + i * RPP * 128)), 16,
+                                                     (int)((a_off[i] + (unsigned)ks * 128u) | oob), 0, 0, 0);
+        });
+        static_for<BR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(wbase + (S * TILE_BYTES + BM * 128 + i * RPP * 128)), 16,
+                                                     (int)((b_off[i] + (unsigned)ks * 128u) | oob), 0, 0, 0);
+        });
+    };
+
+    const int fr = MM::frag_row(lane), fc = MM::frag_chunk(lane);
+    const int fsw = (fr >> 1) & 7;
+    const int a_rd = (wm * WTM + fr) * 128;
+    const int b_rd = BM * 128 + (wn * WTN + fr) * 128;
+    static_assert(MM::SLABS % 2 == 0, "slab skew needs an even slab count");
+
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    bool first = true;
+    // one tile whose first K-step sits (or is on its way) in buffer P; returns true after the workgroup's last tile
+    auto body = [&](auto parc) -> bool {
+        constexpr int P = decltype(parc)::value;
+        typedef std::integral_constant<int, P> C0;
+        typedef std::integral_constant<int, P ^ 1> C1;
+        typename MM::Acc acc[TN][TM];
+        nt_init_acc<T, TN, TM>(acc, nullptr, 0, p.Nn, lane);
+        typename MM::Frag xa[2][TM], wb[2][TN];
+        auto load_frags = [&](int set, int sl, const char* base) {
+            const int coff = (((sl * MM::CPS + fc) ^ fsw) << 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[set][i] = *reinterpret_cast<const typename MM::Frag*>(base + a_rd + i * MM::MT * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[set][j] = *reinterpret_cast<const typename MM::Frag*>(base + b_rd + j * MM::MT * 128 + coff);
+        };
+        auto compute = [&](const char* base) {
+            load_frags(0, 0, base);
+#pragma unroll
+            for (int s = 0; s < MM::SLABS; ++s) {
+                if (s + 1 < MM::SLABS) load_frags((s + 1) & 1, s + 1, base);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[s & 1][j], xa[s & 1][i]);
+            }
+        };
+        const int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);   // this tile (set_tile moves m0 / n0 on to the next one inside the K loop)
+        const int vnext = v + (int)gridDim.x;
+        const bool more = vnext < total;
+        auto gstep = [&](int ks, auto cur, auto nxt) {
+            if (ks == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");      // the previous tile's stores stay in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ks + 1 < nk) issue(ks + 1, nxt);
+            else if (more) {
+                set_tile(vnext);
+                issue(0, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            compute(smem + decltype(cur)::value * TILE_BYTES);
+        };
+        for (int ks = 0; ks < nk; ks += 2) {
+            gstep(ks, C0{}, C1{});
+            if (ks + 1 < nk) gstep(ks + 1, C1{}, C0{});
+        }
+        __builtin_amdgcn_sched_barrier(0);              // the prefetch stays in front of the epilogue's stores
+        nt_epilogue<T, BM, BN, false, NW, EPI>(p, acc, em0, en0, lane, wm, wn);
+        __builtin_amdgcn_sched_barrier(0);
+        first = false;
+        v = vnext;
+        if (more) set_tile(v);                          // (recomputed: the operand offsets are not kept alive across the epilogue)
+        return !more;
+    };
+    set_tile(v);
+    issue(0, S0{});
+    for (;;) {
+        if (body(S0{})) break;
+        if (nk & 1) {
+            if (body(S1{})) break;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,7 +60,7 @@ def test_argument_validation_without_gpu():
     lbuf = ctypes.create_string_buffer(512)
     assert lib.mcn_conv2d_launch_list(_ffi.CONV_DGRAD, ctypes.byref(g2), _ffi.F32, lbuf, 512) == 4
     lines = lbuf.value.decode().splitlines()
-    assert len(lines) == 4 and sorted(int(ln.rsplit(':', 1)[1]) for ln in lines) == [1, 2, 2, 4] and all(ln.startswith('conv_gemm_nt<float') for ln in lines)
+    assert len(lines) == 4 and sorted(int(ln.rsplit(':', 1)[1]) for ln in lines) == [1, 2, 2, 4] and all(ln.startswith(('conv_gemm_nt<float', 'conv_gemm_nt_pers<float')) for ln in lines)
     assert lib.mcn_conv2d_launch_list(_ffi.CONV_FWD, ctypes.byref(g2), _ffi.F32, lbuf, 512) == 1 and lbuf.value.decode().endswith(':9\n')
     assert lib.mcn_conv2d_launch_list(_ffi.CONV_FWD, ctypes.byref(g2), _ffi.F32, lbuf, 8) == _ffi.E_BADARG
     # stream-K plan: small layers run unsplit; MCN_TILE_NOSPLIT turns the split off for a layer that has one
