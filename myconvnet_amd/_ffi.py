@@ -11,7 +11,8 @@ import torch  # noqa: F401  MUST precede loading libmcn_hip.so: both then share 
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmcn_hip.so')
+# MCN_LIB_PATH: load another build of the library (A/B runs of compile-time variants; no freshness check then)
+LIB_PATH = os.environ.get('MCN_LIB_PATH') or os.path.join(_HERE, 'libmcn_hip.so')
 
 F32, BF16, F16 = 0, 1, 2
 NHWC, NCHW = 0, 1
@@ -134,7 +135,7 @@ def _ensure_fresh():
     running tests / bench without rebuilding used to run the stale binary silently).  build.py records the source digest
     next to the library; on a mismatch (or a missing library) the library is rebuilt when hipcc is there, else the import
     fails with the build command.  MCN_SKIP_BUILD_CHECK=1 skips the check, MCN_NO_AUTOBUILD=1 turns the rebuild into an error."""
-    if os.environ.get('MCN_SKIP_BUILD_CHECK') == '1':
+    if os.environ.get('MCN_SKIP_BUILD_CHECK') == '1' or os.environ.get('MCN_LIB_PATH'):
         return None
     mod = _build_module()
     want = mod.source_digest()

@@ -135,6 +135,20 @@ __device__ __forceinline__ int nt_lds_off(int r, int c) { return r * 128 + ((c ^
 
 // Halving butterfly over lanes (see the statistics epilogue of conv_gemm_nt): C values left, partner offset O.  All array
 // indices are compile-time constants (a run-time count makes the compiler index the register arrays with select chains).
+// The exchanges are DPP moves inside the 16-lane rows and v_permlane16_swap across them — no LDS traffic (the ds_bpermute
+// that __shfl_xor compiles to cost 46 LDS round trips per tile in four dependent levels, queued behind the other workgroup's
+// fragment reads).  A step only has to pair every lane with one whose bit O differs and that kept the same values so far:
+// offset 8 = rotate the row by 8, offset 4 = mirror the half row (partner lane ^ 7), offsets 2 / 1 = quad permutes.
+template <int O>
+__device__ __forceinline__ float lane_partner(float x) {
+    static_assert(O == 8 || O == 4 || O == 2 || O == 1, "DPP partner inside a 16-lane row");
+    constexpr int ctrl = O == 8 ? 0x128 /* row_ror:8 */ : (O == 4 ? 0x141 /* row_half_mirror */ : (O == 2 ? 0x4E /* quad_perm:[2,3,0,1] */ : 0xB1 /* [1,0,3,2] */));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false));
+}
+// lane 0 of every 16-lane row to the whole row
+__device__ __forceinline__ float row_first(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x150 /* row_newbcast:0 */, 0xf, 0xf, false));
+}
 template <int C, int O>
 struct LaneFold {
     static __device__ __forceinline__ void run(float* a, float* b, int lane, int& base, bool& writer) {
@@ -143,16 +157,31 @@ struct LaneFold {
             constexpr int H = C / 2;
 #pragma unroll
             for (int t = 0; t < H; ++t) {
-                const float sa = hi ? a[t] : a[t + H], sb = hi ? b[t] : b[t + H];
-                const float ka = hi ? a[t + H] : a[t], kb = hi ? b[t + H] : b[t];
-                a[t] = ka + __shfl_xor(sa, O);
-                b[t] = kb + __shfl_xor(sb, O);
+                if constexpr (O == 16) {
+                    // rows 1 / 3 of the first operand trade places with rows 0 / 2 of the second: every lane then holds its own kept
+                    // value in one result and the partner's copy of it in the other — no selects
+                    // (as inline asm: hipcc 7.2 compiled `r = permlane16_swap(x, y); r[0] + r[1]` to `v_add_f32 x, x, x`)
+                    float x0 = a[t], x1 = a[t + H], y0 = b[t], y1 = b[t + H];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+                    a[t] = x0 + x1;
+                    b[t] = y0 + y1;
+                } else {
+                    const float sa = hi ? a[t] : a[t + H], sb = hi ? b[t] : b[t + H];
+                    const float ka = hi ? a[t + H] : a[t], kb = hi ? b[t + H] : b[t];
+                    a[t] = ka + lane_partner<O>(sa);
+                    b[t] = kb + lane_partner<O>(sb);
+                }
             }
             base += hi ? H : 0;
             LaneFold<H, O / 2>::run(a, b, lane, base, writer);
         } else {
-            a[0] += __shfl_xor(a[0], O);
-            b[0] += __shfl_xor(b[0], O);
+            if constexpr (O == 16) {
+                a[0] += __shfl_xor(a[0], O);
+                b[0] += __shfl_xor(b[0], O);
+            } else {
+                a[0] += lane_partner<O>(a[0]);
+                b[0] += lane_partner<O>(b[0]);
+            }
             writer = writer && !hi;
             LaneFold<1, O / 2>::run(a, b, lane, base, writer);
         }
@@ -387,7 +416,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                 Q::unpack(Q::pack(v), r);                                     // the values as stored
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    piv[j][g][e] = __shfl(r[e], lane & ~(MM::MT - 1));        // pixel row 0 of the wave row
+                    piv[j][g][e] = MM::MT == 16 ? row_first(r[e]) : __shfl(r[e], lane & ~(MM::MT - 1));        // pixel row 0 of the wave row
                     s1[j][g][e] = s2[j][g][e] = 0.f;
                 }
             }
