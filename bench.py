@@ -193,6 +193,16 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 byt = es * B_ * (In_ + Out_) + (4 if op == _ffi.CONV_WGRAD else es) * In_ * Out_
             elif name not in ops:
                 key, flop, nl, byt = name, 0.0, 1, 0.0
+                if layers and name.startswith('mcn_dwconv2d_'):           # depthwise rows of the per-layer table (HBM-bound: GB/s is the figure)
+                    gm = [x for x in a if hasattr(x, '_obj')][0]._obj
+                    oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
+                    ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
+                    es = 4 if dtype == 'fp32' else 2
+                    dflop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin
+                    dbyt = es * gm.N * gm.Cin * (gm.H * gm.W + oh * ow)   # x and y (fwd), dy and dx (dgrad), x and dy (wgrad) once each
+                    r = rows.setdefault(('dw_' + name[13:], gm.H, gm.Cin, gm.Cin, gm.KH, gm.SH, name), [0, 0.0, dflop, dbyt])
+                    r[0] += 1
+                    r[1] += ms
             else:
                 gm = [x for x in a if hasattr(x, '_obj')][0]._obj          # ctypes.byref(geom)
                 oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
