@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void dw_band_kernel(const T* __restrict__ x, c
                 int cr = d_r;
                 if (col >= p.BW) { col -= p.BW; cr++; }
                 row += cr;
+                __builtin_amdgcn_sched_barrier(0);            // (one pass at a time: hoisting the index chains of all passes costs 100+ VGPRs)
             }
         });
     }
@@ -723,6 +724,165 @@ __global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const T* __restrict_
     }
 }
 
+// ---- wgrad, LDS-band form ------------------------------------------------------------------------------------------------
+// The band kernel's staging (dw_band_kernel) for the weight gradient: a workgroup walks tiles t = blockIdx.y, + gridDim.y, ...
+// of the (image, row block, strip block) grid; per tile it stages the x band AND the dy tile in LDS by LDS-DMA (out-of-range
+// dy pixels arrive as zeros and add nothing, so the loops carry no bounds tests), then thread (chunk, filter row ky, strip
+// lane) adds S dy pixels x K taps of row ky into its K x CE accumulators, which live in registers across all tiles.  One
+// partial slab [K*K][C] per blockIdx.y at the end (folded over the strip lanes through LDS), summed by dw_wgrad_reduce_kernel.
+struct DwWBandParams {
+    DwBandParams b;                // x band geometry (H, W = x; OH, OW = dy)
+    int DW_;                       // dy tile width in pixels (TNS * S)
+    int npass_y;                   // DMA passes of the dy tile
+    int ntiles;                    // N * tiles_y * tiles_x
+    int dy_img_bytes;
+};
+template <typename T, int K, int STRIDE, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_band_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const DwWBandParams pw) {
+    constexpr int CE = VecTraits<T>::CE, CP = CE / 2;
+    constexpr int TAPS = K * K;
+    constexpr int L = (S - 1) * STRIDE + K;
+    const DwBandParams& p = pw.b;
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // [x band: npass * 4096][dy tile: npass_y * 4096]; reused by the final fold
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int cch = p.C / CE;
+    const int chunk0 = blockIdx.x * p.TC;
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int tx = tid % p.TC, rest = tid / p.TC;
+    const int ky = rest % K, sid0 = rest / K, nthr = 256 / (p.TC * K);
+    const int chunk = chunk0 + tx;
+    const bool active = sid0 < nthr && chunk < cch;
+    dw_f32x2 acc[K][CP];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int i = 0; i < CP; ++i) acc[kx][i] = dw_f32x2{0.f, 0.f};
+    __attribute__((address_space(3))) char* const wbase = (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
+    const int pixb = p.C * (int)sizeof(T);
+    const char* const dyl = smem + p.npass * 4096;
+    for (int t = blockIdx.y; t < pw.ntiles; t += gridDim.y) {
+        const int n = t / tpi, tr = t - n * tpi;
+        const int tyi = tr / p.tiles_x, txi = tr - tyi * p.tiles_x;
+        const int oy0 = tyi * p.TH, ox00 = txi * p.TNS * S;
+        const int iy0 = oy0 * STRIDE - p.padT, ix0 = ox00 * STRIDE - p.padL;
+        __syncthreads();                                                    // the previous tile's readers are done
+        int tidv = tid;                                                     // opaque per trip: otherwise the index chains of all DMA passes are
+        asm volatile("" : "+v"(tidv));                                      // hoisted out of the tile loop as loop invariants (190+ VGPRs)
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * p.H * p.W * p.C), 0, p.img_bytes, 0x00020000);
+            int tcx = tidv % p.TCP, q = tidv / p.TCP;
+            int col = q % p.BW, row = q / p.BW;
+            const int d_t = 256 % p.TCP, d_q = 256 / p.TCP, d_c = d_q % p.BW, d_r = d_q / p.BW;
+            dw_static_for<DW_BAND_MAXPASS>([&](auto pc) {
+                constexpr int ps = decltype(pc)::value;
+                if (ps < p.npass) {
+                    const int iy = iy0 + row, ix = ix0 + col;
+                    const unsigned bad = (unsigned)iy | (unsigned)(p.H - 1 - iy) | (unsigned)ix | (unsigned)(p.W - 1 - ix) | (unsigned)(p.TC - 1 - tcx) |
+                                         (unsigned)(cch - 1 - chunk0 - tcx) | (unsigned)(p.BH - 1 - row);
+                    const unsigned off = ((unsigned)((iy * p.W + ix) * pixb + (chunk0 + tcx) * 16)) | ((bad >> 31) << 31);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(wbase + ps * 4096), 16, (int)off, 0, 0, 0);
+                    tcx += d_t;
+                    int cq = d_c;
+                    if (tcx >= p.TCP) { tcx -= p.TCP; cq++; }
+                    col += cq;
+                    int cr = d_r;
+                    if (col >= p.BW) { col -= p.BW; cr++; }
+                    row += cr;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy + (size_t)n * p.OH * p.OW * p.C), 0, pw.dy_img_bytes, 0x00020000);
+            __attribute__((address_space(3))) char* const ybase = wbase + p.npass * 4096;
+            int tcx = tidv % p.TCP, q = tidv / p.TCP;
+            int col = q % pw.DW_, row = q / pw.DW_;
+            const int d_t = 256 % p.TCP, d_q = 256 / p.TCP, d_c = d_q % pw.DW_, d_r = d_q / pw.DW_;
+            dw_static_for<DW_BAND_MAXPASS>([&](auto pc) {
+                constexpr int ps = decltype(pc)::value;
+                if (ps < pw.npass_y) {
+                    const int oy = oy0 + row, ox = ox00 + col;
+                    const unsigned bad = (unsigned)(p.OH - 1 - oy) | (unsigned)(p.OW - 1 - ox) | (unsigned)(p.TC - 1 - tcx) | (unsigned)(cch - 1 - chunk0 - tcx) |
+                                         (unsigned)(p.TH - 1 - row);
+                    const unsigned off = ((unsigned)((oy * p.OW + ox) * pixb + (chunk0 + tcx) * 16)) | ((bad >> 31) << 31);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ybase + ps * 4096), 16, (int)off, 0, 0, 0);
+                    tcx += d_t;
+                    int cq = d_c;
+                    if (tcx >= p.TCP) { tcx -= p.TCP; cq++; }
+                    col += cq;
+                    int cr = d_r;
+                    if (col >= pw.DW_) { col -= pw.DW_; cr++; }
+                    row += cr;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active) {
+            const int nst = p.TH * p.TNS;
+#pragma unroll 1
+            for (int st = sid0; st < nst; st += nthr) {
+                const int r = st / p.TNS, sxl = st - r * p.TNS;
+                const char* xb = smem + ((size_t)((r * STRIDE + ky) * p.BW + sxl * S * STRIDE) * p.TCP + tx) * 16;
+                const char* gb = dyl + ((size_t)(r * pw.DW_ + sxl * S) * p.TCP + tx) * 16;
+                // all L + S segment reads go out first (raw 16-byte chunks); the dy pixels are widened once, every x chunk when its turn
+                // comes: chunk jp feeds the (kx, j) pairs with j * STRIDE + kx == jp.  (Widening the whole segment up front as the forward
+                // kernel does needs 250+ VGPRs here: K x CE accumulators and S dy pixels stay live.)
+                Chunk<T> graw[S], raw[L];
+#pragma unroll
+                for (int j = 0; j < S; ++j) *reinterpret_cast<i32x4*>(&graw[j].v) = *reinterpret_cast<const i32x4*>(gb + (size_t)(j * p.TCP) * 16);
+#pragma unroll
+                for (int j = 0; j < L; ++j) *reinterpret_cast<i32x4*>(&raw[j].v) = *reinterpret_cast<const i32x4*>(xb + (size_t)(j * p.TCP) * 16);
+                dw_f32x2 g[S][CP];
+#pragma unroll
+                for (int j = 0; j < S; ++j)
+#pragma unroll
+                    for (int i = 0; i < CP; ++i) g[j][i] = dw_f32x2{graw[j].get(2 * i), graw[j].get(2 * i + 1)};
+#pragma unroll
+                for (int jp = 0; jp < L; ++jp) {
+                    dw_f32x2 v[CP];
+#pragma unroll
+                    for (int i = 0; i < CP; ++i) v[i] = dw_f32x2{raw[jp].get(2 * i), raw[jp].get(2 * i + 1)};
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int d = jp - kx;                                // (compile time after unrolling)
+                        if (d >= 0 && d % STRIDE == 0 && d / STRIDE < S) {
+#pragma unroll
+                            for (int i = 0; i < CP; ++i) acc[kx][i] = __builtin_elementwise_fma(v[i], g[d / STRIDE][i], acc[kx][i]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // fold the strip lanes: red[(sid * K + ky)][tx * CE + i], one filter column kx per round
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(smem);
+    const int cols = p.TC * CE;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+        if (sid0 < nthr) {
+#pragma unroll
+            for (int i = 0; i < CP; ++i) {
+                red[(sid0 * K + ky) * cols + tx * CE + 2 * i] = active ? acc[kx][i][0] : 0.f;
+                red[(sid0 * K + ky) * cols + tx * CE + 2 * i + 1] = active ? acc[kx][i][1] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (sid0 == 0 && chunk < cch) {
+#pragma unroll
+            for (int i = 0; i < CE; ++i) {
+                float sum = 0.f;
+                for (int l = 0; l < nthr; ++l) sum += red[(l * K + ky) * cols + tx * CE + i];
+                part[((long)blockIdx.y * TAPS + ky * K + kx) * p.C + (long)chunk * CE + i] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // generic filter sizes: one tap per blockIdx.z (K*K passes over the data; not on the EfficientNet path)
 template <typename T>
 __global__ __launch_bounds__(256) void dw_wgrad_tap_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const DwParams p) {
@@ -843,18 +1003,21 @@ static long dw_band_budget() {
     return v;
 }
 #define DW_BAND_LDS_BUDGET dw_band_budget()
-static bool dw_band_plan(int H, int W, int C, int OH, int OW, int K, int stride, int padT, int padL, int ce, size_t es, DwBandParams* out) {
+// kthreads > 1 (wgrad): K threads share a strip (one filter row each) and the dy tile is staged too (its passes in *npass_y)
+static bool dw_band_plan(int H, int W, int C, int OH, int OW, int K, int stride, int padT, int padL, int ce, size_t es, DwBandParams* out,
+                         int kthreads = 1, int* npass_y = nullptr) {
     if (!dw_band_enabled() || (size_t)H * W * C * es >= 0x7fffffffull) return false;
     // stride 2 stages four input pixels per output: on the large maps (56x56 / 112x112 inputs) the strip kernel, whose loads hit
     // L1 / L2 directly, is 25-40 % faster (measured); the small maps gain 10-20 % from the band
     static const int s2max = [] { const char* e = getenv("MCN_DW_BAND_S2MAX"); return e ? atoi(e) : 14; }();
-    if (stride == 2 && OH > s2max) return false;
+    if (stride == 2 && OH > s2max && kthreads == 1) return false;
     const int cch = C / ce;
     int TC = cch < 8 ? cch : 8;
     for (int d = 8; d >= 5; --d)
         if (cch % d == 0) { TC = d; break; }
     const int TCP = TC | 1;
-    const int NS = (OW + DW_BAND_S - 1) / DW_BAND_S, nthr = 256 / TC;
+    const int NS = (OW + DW_BAND_S - 1) / DW_BAND_S, nthr = 256 / (TC * kthreads);
+    if (nthr < 1) return false;
     double best = -1;
     DwBandParams b;
     memset(&b, 0, sizeof(b));
@@ -867,7 +1030,8 @@ static bool dw_band_plan(int H, int W, int C, int OH, int OW, int K, int stride,
             const int BH = (TH - 1) * stride + K, BW = (TNS * DW_BAND_S - 1) * stride + K;
             const long slots = (long)BH * BW * TCP;
             const int npass = (int)((slots + 255) / 256);
-            if (npass > DW_BAND_MAXPASS || (long)npass * 4096 > DW_BAND_LDS_BUDGET) break;
+            const int npy = npass_y ? (int)(((long)TH * TNS * DW_BAND_S * TCP + 255) / 256) : 0;
+            if (npass > DW_BAND_MAXPASS || npy > DW_BAND_MAXPASS || (long)(npass + npy) * 4096 > DW_BAND_LDS_BUDGET) break;
             const int strips = TH * TNS;
             const double util = (double)strips / (((strips + nthr - 1) / nthr) * nthr);
             const int ty = (OH + TH - 1) / TH, txn = (NS + TNS - 1) / TNS;
@@ -877,6 +1041,7 @@ static bool dw_band_plan(int H, int W, int C, int OH, int OW, int K, int stride,
                 best = score;
                 b.TH = TH; b.TNS = TNS; b.BH = BH; b.BW = BW; b.npass = npass;
                 b.tiles_y = ty; b.tiles_x = txn;
+                if (npass_y) *npass_y = npy;
             }
         }
     }
@@ -1016,10 +1181,40 @@ static DwParams dw_wgrad_params(const mcn_conv_geom* g, mcn_dtype dtype, unsigne
     *gy = (unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want);
     return p;
 }
+// band form of the wgrad (dw_wgrad_band_kernel): plan + grid.  MCN_DW_WBAND=0 switches it off.
+static bool dw_wgrad_band_plan(const mcn_conv_geom* g, mcn_dtype dtype, DwWBandParams* pw, unsigned* gx, unsigned* gy) {
+    static const int on = [] { const char* e = getenv("MCN_DW_WBAND"); return e ? atoi(e) : 1; }();
+    unsigned a, b2;
+    const DwParams p = dw_params(g, 4, false, &a, &b2);
+    const int ce = dtype == MCN_F32 ? 4 : 8;
+    const size_t es = mcn_dtype_size(dtype);
+    // stride 1 only: measured per layer (EfficientNet-B0, bf16, B = 512) 5x5 215 -> 149, 163 -> 113, 294 -> 212 us, 3x3 82 -> 75, 266 -> 233
+    // (56x56 144ch 298 -> 318); stride 2 stages four x pixels per dy pixel and loses 2-38 % against the strip / row-split kernels
+    if (on < 2 && p.SH != 1) return false;
+    if (!on || !dw_strip_ok(p) || p.C % ce || p.npix == 0 || (size_t)p.OH * p.OW * p.C * es >= 0x7fffffffull) return false;
+    DwWBandParams w;
+    memset(&w, 0, sizeof(w));
+    int npy = 0;
+    if (!dw_band_plan(p.H, p.W, p.C, p.OH, p.OW, p.KH, p.SH, p.padT, p.padL, ce, es, &w.b, p.KH, &npy)) return false;
+    w.DW_ = w.b.TNS * DW_BAND_S;
+    w.npass_y = npy;
+    w.ntiles = p.N * w.b.tiles_y * w.b.tiles_x;
+    w.dy_img_bytes = (int)((size_t)p.OH * p.OW * p.C * es);
+    const int cch = p.C / ce;
+    *gx = (unsigned)((cch + w.b.TC - 1) / w.b.TC);
+    long want = 1024 / *gx;                                            // ~4 workgroups per CU in all
+    if (want < 1) want = 1;
+    *gy = (unsigned)(w.ntiles < want ? w.ntiles : want);
+    *pw = w;
+    return true;
+}
 extern "C" size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom* g, mcn_dtype dtype) {
     if (!g || g->Cin <= 0 || g->Cin % 4 || g->KH <= 0 || g->KW <= 0 || g->N < 0) return 0;
     unsigned gx, gy;
     dw_wgrad_params(g, dtype, &gx, &gy);
+    DwWBandParams pw;
+    unsigned bx, by = 0;
+    if (mcn_dtype_ok(dtype) && g->H > 0 && g->W > 0 && g->SH > 0 && g->SW > 0 && g->DH > 0 && g->DW > 0 && dw_wgrad_band_plan(g, dtype, &pw, &bx, &by) && by > gy) gy = by;
     return align_up((size_t)gy * g->KH * g->KW * g->Cin * sizeof(float), 256);
 }
 template <typename T>
@@ -1034,7 +1229,18 @@ static int dw_wgrad_t(const void* x, const void* dy, float* dw, const mcn_conv_g
     float* part = (float*)ws;
     const size_t lds = (size_t)p.TY * p.TX * 4 * sizeof(float);
     const dim3 block(256);
-    if (dw_wgrad_rows() && dw_strip_ok(p) && p.C % VecTraits<T>::CE == 0 && sizeof(T) == 2 && p.KH == 5) {
+    DwWBandParams pw;
+    unsigned bx, by;
+    if (dw_wgrad_band_plan(g, DtypeOf<T>::value, &pw, &bx, &by)) {
+        const size_t bl = (size_t)(pw.b.npass + pw.npass_y) * 4096;
+#define DW_WBAND(KK, SS) hipLaunchKernelGGL((dw_wgrad_band_kernel<T, KK, SS, DW_BAND_S>), dim3(bx, by), block, bl, st, (const T*)x, (const T*)dy, part, pw)
+        if (p.KH == 3 && p.SH == 1) DW_WBAND(3, 1);
+        else if (p.KH == 3) DW_WBAND(3, 2);
+        else if (p.SH == 1) DW_WBAND(5, 1);
+        else DW_WBAND(5, 2);
+#undef DW_WBAND
+        gy = by;
+    } else if (dw_wgrad_rows() && dw_strip_ok(p) && p.C % VecTraits<T>::CE == 0 && sizeof(T) == 2 && p.KH == 5) {
         const size_t rl = (size_t)p.TY * p.TX * VecTraits<T>::CE * sizeof(float);
 #define DW_WROWS(KK, SS) hipLaunchKernelGGL((dw_wgrad_rows_kernel<T, KK, SS, 4>), dim3(gx, gy), block, rl, st, (const T*)x, (const T*)dy, part, p)
         if (p.SH == 1) DW_WROWS(5, 1);
