@@ -1091,8 +1091,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
-    if (br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype))) snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, 8>", tn, br, bn, conv_is_linear(g) ? "true" : "false");
-    else snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s>", tn, br, bn, conv_is_linear(g) ? "true" : "false");
+    snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype)) ? 8 : 4);
     return 1;
 }
 
