@@ -113,6 +113,8 @@ static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int forced, i
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     forced &= 0xff;
     if (forced >= 1 && forced <= 4) { *br = cand[forced - 1][0]; *bn = cand[forced - 1][1]; return; }
+    static const int env_tile = [] { const char* e = getenv("MCN_TN_TILE"); return e ? atoi(e) : 0; }();      // experiments: gathered (non-linear) wgrads only
+    if (env_tile >= 1 && env_tile <= 4 && !linear) { *br = cand[env_tile - 1][0]; *bn = cand[env_tile - 1][1]; return; }
     if (dt == MCN_F32 && linear) { *br = 64; *bn = 64; return; }
     *br = rows <= 64 ? 64 : 128;
     *bn = Cout <= 64 ? 64 : 128;

@@ -558,7 +558,10 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(4, 14, 14, 64, 64, 3, 1), (2, 28, 28, 32, 128, 1, 1), (3, 9, 11, 72, 136, 3, 1), (2, 16, 16, 16, 32, 3, 2), (8, 14, 14, 256, 64, 1, 1),
-                                  (16, 56, 56, 16, 32, 1, 1)])      # last: > 512 partial rows -> the folded (two-stage) merge
+                                  (16, 56, 56, 16, 32, 1, 1),       # > 512 partial rows -> the folded (two-stage) merge
+                                  # more tiles than resident workgroups: the persistent 1x1 kernel walks several tiles per workgroup
+                                  # (K = 64 in a 2-byte type is a one-step K loop: the LDS buffer parity alternates tile by tile)
+                                  (600, 16, 8, 64, 256, 1, 1), (350, 16, 8, 256, 128, 1, 1), (700, 16, 8, 96, 136, 1, 1)])
 def test_conv_epilogue_bn_statistics(case, dtype):
     """conv -> BN fusion: the conv writes per-(M tile, wave row) column sums / sums of squares of the values it stores;
     mcn_bn_fwd_train_fused must give what mcn_bn_fwd_train gives on the same conv output (same tf.nn.fused_batch_norm
@@ -585,9 +588,15 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]))
         _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
                                               ws.data_ptr(), ws.numel() * 4, u.stream()))
-        np.testing.assert_array_equal(u.host(y), y_plain)                       # the stored output is unchanged
+        ys = u.host(y)
+        if dtype == 'float32' and n >= 300:
+            # (fp32 layers with a thin last round of tiles run that round K-sliced — stream-K tail — so two tile shapes may sum a
+            # K loop in different orders: equal up to fp32 rounding, not bit for bit)
+            np.testing.assert_allclose(ys, y_plain, rtol=5e-6, atol=1e-5)
+        else:
+            np.testing.assert_array_equal(ys, y_plain)                          # the stored output is unchanged
         p = u.host(part).astype(np.float64)
-        yq = y_plain.astype(np.float64).reshape(-1, cout)
+        yq = ys.astype(np.float64).reshape(-1, cout)                            # the partials describe the values THIS launch stored
         m = yq.shape[0]
         for kk in range(rows):                                                   # every partial: shifted sums of its own rows
             blk = yq[kk * rpp.value:(kk + 1) * rpp.value]
