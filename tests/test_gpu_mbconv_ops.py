@@ -30,6 +30,11 @@ DW_CASES = [
     (2, 12, 14, 48, 5, 2, 'SAME', 1),            # even H stride 2 5x5: pads (1,2) — the EfficientNet 56 -> 28 / 14 -> 7 case
     (2, 9, 11, 24, 3, 2, 'SAME', 1),             # odd H stride 2 3x3: pads (1,1), width not a multiple of the strip
     (1, 13, 10, 16, 5, 2, 'SAME', 1),            # odd H / even W: pads (2,2) x (1,2)
+    # larger maps: the LDS-band kernels cut the image into several row / strip tiles (halo rows shared between tiles, last tiles partly empty)
+    (2, 40, 44, 48, 5, 1, 'SAME', 1),
+    (3, 33, 31, 72, 3, 1, 'SAME', 1),            # odd sizes: strips and tiles with ragged ends
+    (2, 28, 28, 240, 3, 2, 'SAME', 1),           # stride 2 on the band path (output 14x14)
+    (40, 56, 56, 32, 3, 1, 'SAME', 1),           # more tiles than wgrad workgroups: accumulators carried across tiles
 ]
 
 
