@@ -133,7 +133,10 @@ def _not_persistent(sym):
     geometry alone; launches with a bias, and fp32 launches with the accumulate epilogue, stay on conv_gemm_nt)."""
     import re
     m = re.match(r'conv_gemm_nt_pers<(.+), (\d+), (\d+), (\d+), (\d+)>$', sym)
-    return 'conv_gemm_nt<{}, {}, {}, 0, {}, {}>'.format(*m.groups()) if m else sym
+    if not m:
+        return sym
+    t, bm, bn, nw, e = m.groups()
+    return 'conv_gemm_nt<{}, {}, {}, 0, {}, {}>'.format(t, bm, bn, nw, 0 if e == '3' else e)      # (3 = counted statistics: persistent only)
 
 
 def instrumented_pass(model, dtype, reps=3, layers=False):

@@ -473,12 +473,20 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
 // Each partial is an accurate fp32 (count, mean, M2) thanks to its own pivot; partials are merged in double as
 // sum n*mean and sum (M2 + n*mean^2).
 #define BN_FOLD_ROWS 512
+// rpp == 0: "counted" rows part[(k*4 + {0,1,2,3})*C + c] — the fourth plane holds the number of pixel rows the row sums (a
+// persistent conv workgroup's share of the tensor, not a contiguous row range; rows with count 0 are skipped)
 __device__ __forceinline__ void fused_partial(const float* __restrict__ part, int k, int C, int c, long M, int rpp, double& sm, double& sq) {
-    long n = M - (long)k * rpp;
-    if (n > rpp) n = rpp;
+    const int planes = rpp > 0 ? 3 : 4;
+    long n;
+    if (rpp > 0) {
+        n = M - (long)k * rpp;
+        if (n > rpp) n = rpp;
+    } else {
+        n = (long)part[((long)k * 4 + 3) * C + c];
+    }
     if (n <= 0) return;
-    const double s1 = (double)part[((long)k * 3 + 0) * C + c], s2 = (double)part[((long)k * 3 + 1) * C + c];
-    const double pv = (double)part[((long)k * 3 + 2) * C + c];
+    const double s1 = (double)part[((long)k * planes + 0) * C + c], s2 = (double)part[((long)k * planes + 1) * C + c];
+    const double pv = (double)part[((long)k * planes + 2) * C + c];
     const double mean = pv + s1 / (double)n;
     const double m2 = s2 - s1 * s1 / (double)n;
     sm += (double)n * mean;
@@ -597,7 +605,7 @@ extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials
                                       const void* skip, void* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, float* batch_mean,
                                       float* batch_var, float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
                                       mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
-    if (rows_per_partial <= 0 || (int64_t)nparts * rows_per_partial < M) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: partials do not cover M rows");
+    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: partials do not cover M rows");
     if (!x || !y || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 4) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused: workspace too small");
     hipStream_t st = (hipStream_t)stream;

@@ -423,28 +423,56 @@ static int pers_slots(K kernel, int threads, int lds) {
     }
     return n;
 }
+// resident workgroups of a persistent instantiation (slots per CU x CUs), queried once per instantiation
+template <typename T, int BMV, int BNV, int EPIV>
+static long nt_pers_cap_of() {
+    static const int slots = pers_slots(conv_gemm_nt_pers<T, BMV, BNV, 4, EPIV>, 256, 2 * (BMV + BNV) * 128);
+    return (long)slots * MCN_NUM_CU;
+}
 template <typename T>
-static int launch_nt_pers(const GemmNTParams& p, int tile, long W, hipStream_t st) {
+static long nt_pers_cap(int tile, int epi) {
     const NtTile t = kNtCand[tile];
-    const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
+#define MCN_PERS_CAP(BMV, BNV)                                                                  \
+    (epi == NT_EPI_STATSC ? nt_pers_cap_of<T, BMV, BNV, NT_EPI_STATSC>()                         \
+     : epi == NT_EPI_STATS ? nt_pers_cap_of<T, BMV, BNV, NT_EPI_STATS>()                         \
+     : epi == NT_EPI_ACC ? nt_pers_cap_of<T, BMV, BNV, NT_EPI_ACC>() : nt_pers_cap_of<T, BMV, BNV, NT_EPI_STORE>())
+    if (t.bm == 128 && t.bn == 128) return MCN_PERS_CAP(128, 128);
+    return MCN_PERS_CAP(64, 64);
+#undef MCN_PERS_CAP
+}
+// Counted statistics rows (NT_EPI_STATSC): the forward launch that runs persistent AND whose workgroups each stay on one
+// channel block (tile v -> v + grid keeps the N tile when grid / 8 is a multiple of the N-tile count: xcd_remap adds v / 8
+// to a per-XCD base).  Geometry only, so that mcn_conv2d_bnstats_rows() and the launch agree.  MCN_NT_STATSC=0: off.
+template <typename T>
+static bool nt_stats_counted(int mode, long M, int Nn, int nchunks, int tile, int tile_hint, long* grid_out) {
+    static const int on = [] { const char* e = getenv("MCN_NT_STATSC"); return e ? atoi(e) : 1; }();
+    const NtTile t = kNtCand[tile];
+    if (!on || mode != NT_LINEAR || !nt_pers_tile(t, sizeof(T), NT_EPI_STATS)) return false;
+    const long ntn = (Nn + t.bn - 1) / t.bn;
+    const long W = ((M + t.bm - 1) / t.bm) * ntn;
+    if (!(tile_hint & MCN_TILE_NOSPLIT) && sk_plan(tile, W, (nchunks + 7) >> 3, sizeof(T)).slices >= 2) return false;
+    const long cap = nt_pers_cap<T>(tile, NT_EPI_STATSC);
+    if (W > cap && (cap % 8 || (cap / 8) % ntn)) return false;
+    if (grid_out) *grid_out = W < cap ? W : cap;
+    return true;
+}
+template <typename T>
+static int launch_nt_pers(const GemmNTParams& p, int tile, long W, hipStream_t st, int epi) {
+    const NtTile t = kNtCand[tile];
     const int lds = 2 * (t.bm + t.bn) * 128;
-#define MCN_LAUNCH_PERS_E(BMV, BNV, NWV, EPIV)                                                                  \
-    do {                                                                                                        \
-        static const int slots = pers_slots(conv_gemm_nt_pers<T, BMV, BNV, NWV, EPIV>, NWV * 64, 2 * (BMV + BNV) * 128); \
-        const long cap = (long)slots * MCN_NUM_CU;                                                              \
-        hipLaunchKernelGGL((conv_gemm_nt_pers<T, BMV, BNV, NWV, EPIV>), dim3((unsigned)(W < cap ? W : cap)), dim3(NWV * 64), lds, st, p); \
+    const long cap = nt_pers_cap<T>(tile, epi);
+    const dim3 grid((unsigned)(W < cap ? W : cap)), block(256);
+#define MCN_LAUNCH_PERS(BMV, BNV)                                                                                              \
+    do {                                                                                                                       \
+        if (epi == NT_EPI_STATSC) hipLaunchKernelGGL((conv_gemm_nt_pers<T, BMV, BNV, 4, NT_EPI_STATSC>), grid, block, lds, st, p);      \
+        else if (epi == NT_EPI_STATS) hipLaunchKernelGGL((conv_gemm_nt_pers<T, BMV, BNV, 4, NT_EPI_STATS>), grid, block, lds, st, p);   \
+        else if (epi == NT_EPI_ACC) hipLaunchKernelGGL((conv_gemm_nt_pers<T, BMV, BNV, 4, NT_EPI_ACC>), grid, block, lds, st, p);       \
+        else hipLaunchKernelGGL((conv_gemm_nt_pers<T, BMV, BNV, 4, NT_EPI_STORE>), grid, block, lds, st, p);                            \
     } while (0)
-#define MCN_LAUNCH_PERS(BMV, BNV, NWV)                                                   \
-    do {                                                                                 \
-        if (epi == NT_EPI_STATS) MCN_LAUNCH_PERS_E(BMV, BNV, NWV, NT_EPI_STATS);         \
-        else if (epi == NT_EPI_ACC) MCN_LAUNCH_PERS_E(BMV, BNV, NWV, NT_EPI_ACC);        \
-        else MCN_LAUNCH_PERS_E(BMV, BNV, NWV, NT_EPI_STORE);                             \
-    } while (0)
-    if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_PERS(128, 128, 4);
-    else if (t.bm == 64 && t.bn == 64) MCN_LAUNCH_PERS(64, 64, 4);
+    if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_PERS(128, 128);
+    else if (t.bm == 64 && t.bn == 64) MCN_LAUNCH_PERS(64, 64);
     else MCN_FAIL(MCN_E_UNSUPPORTED, "conv: no persistent instantiation for this tile");
 #undef MCN_LAUNCH_PERS
-#undef MCN_LAUNCH_PERS_E
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -475,8 +503,11 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
     if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) {
-        if (mode == NT_LINEAR && !p.bias && nt_pers_tile(t, sizeof(T), p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE)))
-            return launch_nt_pers<T>(p, tile, W, st);
+        const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
+        // (counted statistics rows are a property of the geometry — mcn_conv2d_bnstats_rows() promised them to the BN side — so
+        // that launch is persistent with or without a bias)
+        if (p.stats && nt_stats_counted<T>(mode, p.M, p.Nn, p.nchunks, tile, tile_hint, nullptr)) return launch_nt_pers<T>(p, tile, W, st, NT_EPI_STATSC);
+        if (mode == NT_LINEAR && !p.bias && nt_pers_tile(t, sizeof(T), epi)) return launch_nt_pers<T>(p, tile, W, st, epi);
         return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
     }
     p.sk_mode = 1;
@@ -641,6 +672,14 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     const NtTile* cand = kNtCand;
     const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
     const int wrows = cand[t].nw / 2;
+    // counted rows (rows_per_partial = 0): one row per persistent workgroup and wave row, [4][Cout] floats each
+    const int ce = ce_of(dtype), cpt = round_up(g.Cin, ce) / ce;
+    const int mode = conv_is_linear(g) ? NT_LINEAR : NT_UNIFORM;
+    long grid = 0;
+    const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
+                         : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
+                                            : nt_stats_counted<bf16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid);
+    if (counted) return (int32_t)(wrows * grid);
     if (rows_per_partial) *rows_per_partial = cand[t].bm / wrows;
     return (int32_t)(wrows * ((M + cand[t].bm - 1) / cand[t].bm));
 }
@@ -1057,7 +1096,13 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
         if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
-        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cout, cpt, mcn_dtype_size(dtype), g.tile, NT_EPI_STATS)) snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);   /* (answers for mcn_conv2d_fwd_bnstats; a biased launch, and by default a forward without statistics: conv_gemm_nt) */
+        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cout, cpt, mcn_dtype_size(dtype), g.tile, NT_EPI_STATS)) {
+            /* (answers for mcn_conv2d_fwd_bnstats; a biased launch, and by default a forward without statistics: conv_gemm_nt.  Epilogue 3 = counted statistics rows) */
+            const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, cpt, t, g.tile, nullptr)
+                                 : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, cpt, t, g.tile, nullptr)
+                                                    : nt_stats_counted<bf16_t>(mode, M, g.Cout, cpt, t, g.tile, nullptr);
+            snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, cand[t].nw, counted ? 3 : 0);
+        }
         else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return 1;
     }

@@ -232,7 +232,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 // offset carries "row past the end" / "column past Nn" in bit 31 (out of range => the store is dropped, the load returns
 // 0), the bias is folded into the accumulators under ONE uniform branch, the statistics run on packed fp32 pairs
 // (v_pk_add_f32 / v_pk_fma_f32), and the pixel of a row is its GEMM row unless the launch scatters a sub-grid (strided dgrad).
-enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2 };
+enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2, NT_EPI_STATSC = 3 };
+// NT_EPI_STATSC (conv_gemm_nt_pers only): the per-lane statistics sums are CARRIED across the tiles a persistent workgroup walks
+// (all its tiles share the channel block) and folded / written once per workgroup as a "counted" partial row
+// [s1][s2][pivot][count] — one lane fold and one row per workgroup and wave row instead of one per tile.
+template <typename T, int TN>
+struct NtStatsCarry {
+    static constexpr int NG = (int)(sizeof(typename MmaNT<T>::Acc) / 16);
+    float s1[TN][NG][4], s2[TN][NG][4], piv[TN][NG][4];
+    float count;            // pixel rows summed so far (wave-uniform)
+    bool have;              // pivot taken
+};
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // offsets that carry "out of range" in bit 31 are added with saturation (v_add_u32 ... clamp): bad row + bad column must not
 // wrap around to a valid address
@@ -278,10 +288,12 @@ struct Quad<bf16_t> {                                       // bf16 -> fp32 is a
 template <typename T, int BM, int BN, bool TAPS, int NW, int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                                             typename MmaNT<T>::Acc (&acc)[BN / 2 / MmaNT<T>::MT][BM / (NW / 2) / MmaNT<T>::MT],
-                                            const int m0, const int n0, const int lane, const int wm, const int wn) {
+                                            const int m0, const int n0, const int lane, const int wm, const int wn,
+                                            NtStatsCarry<T, BN / 2 / MmaNT<T>::MT>* carry = nullptr) {
     typedef MmaNT<T> MM;
     typedef Quad<T> Q;
-    constexpr bool STATS = EPI == NT_EPI_STATS, ACC = EPI == NT_EPI_ACC;
+    constexpr bool CARRY = EPI == NT_EPI_STATSC;
+    constexpr bool STATS = EPI == NT_EPI_STATS || CARRY, ACC = EPI == NT_EPI_ACC;
     constexpr int WROWS = NW / 2;
     constexpr int WTM = BM / WROWS, WTN = BN / 2;
     constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
@@ -404,22 +416,35 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 
     // ---- BN statistics of the STORED (rounded) values: per-lane sums of (y - pivot) and of its square over the wave's row
     // blocks, pivot = pixel row 0 of the wave row (keeps the E[y^2] - E[y]^2 cancellation out of fp32) ----
-    float s1[STATS ? TN : 1][NG][4], s2[STATS ? TN : 1][NG][4], piv[STATS ? TN : 1][NG][4];
+    float ls1[TN][NG][4], ls2[TN][NG][4], lpiv[TN][NG][4];                  // (unused and eliminated unless EPI == NT_EPI_STATS)
+    typedef float (&StatRef)[TN][NG][4];
+    StatRef s1 = [&]() -> StatRef { if constexpr (CARRY) return carry->s1; else return ls1; }();
+    StatRef s2 = [&]() -> StatRef { if constexpr (CARRY) return carry->s2; else return ls2; }();
+    StatRef piv = [&]() -> StatRef { if constexpr (CARRY) return carry->piv; else return lpiv; }();
     if constexpr (STATS) {
+        bool init = true;
+        if constexpr (CARRY) init = !carry->have;                            // (uniform) the first tile of the workgroup sets the pivot
+        if (init) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float v[4], r[4];
+                for (int g = 0; g < NG; ++g) {
+                    float v[4], r[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][0][g * 4 + e];
-                Q::unpack(Q::pack(v), r);                                     // the values as stored
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][0][g * 4 + e];
+                    Q::unpack(Q::pack(v), r);                                 // the values as stored
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    piv[j][g][e] = MM::MT == 16 ? row_first(r[e]) : __shfl(r[e], lane & ~(MM::MT - 1));        // pixel row 0 of the wave row
-                    s1[j][g][e] = s2[j][g][e] = 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        piv[j][g][e] = MM::MT == 16 ? row_first(r[e]) : __shfl(r[e], lane & ~(MM::MT - 1));        // pixel row 0 of the wave row
+                        s1[j][g][e] = s2[j][g][e] = 0.f;
+                    }
                 }
-            }
+        }
+        if constexpr (CARRY) {
+            carry->have = true;
+            const int left = p.m_end - (m0 + wm * WTM);                       // valid pixel rows of this wave row in this tile
+            carry->count += (float)(left < 0 ? 0 : (left > WTM ? WTM : left));
+        }
     }
     const bool full = m0 + BM <= p.m_end;                      // wave-uniform: no row of this tile is past the end
     // the 4 output values of accumulator (i, j, g) as stored (residual added, rounded) + their statistics
@@ -490,7 +515,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     if (!STATS || full) store_all(std::true_type{});
     else store_all(std::false_type{});
 
-    if constexpr (STATS) {
+    if constexpr (STATS && !CARRY) {
         // Fold over the MT lanes that hold different pixel rows of the same channels with a halving butterfly: at each
         // step a lane keeps half of its values and receives the partner's copies of that half (V/2 + V/4 + ... shuffles
         // instead of V per step); when one value is left the remaining steps are plain all-reduce steps.  At the end lane
@@ -527,6 +552,54 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                         *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 3 + 2) * p.Nn + n2) = f32x4{piv[jj][gg][0], piv[jj][gg][1], piv[jj][gg][2], piv[jj][gg][3]};
                 }
         }
+    }
+}
+
+// end of a persistent workgroup with carried statistics: fold the lanes once and write the counted partial row(s)
+// stats[(prow * 4 + {0,1,2,3}) * Nn + n] = sum(y - p), sum((y - p)^2), p, pixel rows summed; prow = workgroup * wave rows + wave row
+template <typename T, int BM, int BN, int NW>
+__device__ __forceinline__ void nt_stats_flush(const GemmNTParams& p, NtStatsCarry<T, BN / 2 / MmaNT<T>::MT>& st, const int n0, const int lane,
+                                               const int wm, const int wn, const int prow) {
+    typedef MmaNT<T> MM;
+    constexpr int WTN = BN / 2, TN = WTN / MM::MT;
+    constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);
+    constexpr int V = TN * NG * 4;
+    const int fr = MM::frag_row(lane);
+    float a[V], b[V];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[(j * NG + g) * 4 + e] = st.s1[j][g][e];
+                b[(j * NG + g) * 4 + e] = st.s2[j][g][e];
+            }
+    int base = 0;
+    bool writer = true;
+    LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
+    // a row spans all Nn channels but this workgroup owns only [n0, n0 + BN): the others get count 0 (the merge skips them)
+    if (wn == 0)
+        for (int c = lane; c < p.Nn; c += 64)
+            if (c < n0 || c >= n0 + BN) p.stats[((long)prow * 4 + 3) * p.Nn + c] = 0.f;
+    const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
+    const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+    const int n = n0 + wn * WTN + j * MM::MT + nl + e;
+    if (writer && n < p.Nn) {
+        p.stats[((long)prow * 4 + 0) * p.Nn + n] = a[0];
+        p.stats[((long)prow * 4 + 1) * p.Nn + n] = b[0];
+    }
+    if (fr == 0) {
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) {
+                const int n2 = n0 + wn * WTN + jj * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * gg + 4 * (lane >> 5));
+                if (n2 < p.Nn) {
+                    *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 2) * p.Nn + n2) = f32x4{st.piv[jj][gg][0], st.piv[jj][gg][1], st.piv[jj][gg][2], st.piv[jj][gg][3]};
+                    *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 3) * p.Nn + n2) = f32x4{st.count, st.count, st.count, st.count};
+                }
+            }
     }
 }
 
@@ -883,13 +956,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     bool first = true;
+    NtStatsCarry<T, TN> carry;                          // (NT_EPI_STATSC; otherwise unused)
+    carry.count = 0.f;
+    carry.have = false;
     // one tile whose first K-step sits (or is on its way) in buffer P; returns true after the workgroup's last tile
     auto body = [&](auto parc) -> bool {
         constexpr int P = decltype(parc)::value;
         typedef std::integral_constant<int, P> C0;
         typedef std::integral_constant<int, P ^ 1> C1;
         typename MM::Acc acc[TN][TM];
-        nt_init_acc<T, TN, TM>(acc, nullptr, 0, p.Nn, lane);
+        nt_init_acc<T, TN, TM>(acc, p.bias, n0 + wn * WTN, p.Nn, lane);       // (a bias costs a vmcnt(0) wait behind the previous tile's stores: the host avoids it)
         typename MM::Frag xa[2][TM], wb[2][TN];
         auto load_frags = [&](int set, int sl, const char* base) {
             const int coff = (((sl * MM::CPS + fc) ^ fsw) << 4);
@@ -929,7 +1005,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2
             if (ks + 1 < nk) gstep(ks + 1, C1{}, C0{});
         }
         __builtin_amdgcn_sched_barrier(0);              // the prefetch stays in front of the epilogue's stores
-        nt_epilogue<T, BM, BN, false, NW, EPI>(p, acc, em0, en0, lane, wm, wn);
+        nt_epilogue<T, BM, BN, false, NW, EPI>(p, acc, em0, en0, lane, wm, wn, &carry);
         __builtin_amdgcn_sched_barrier(0);
         first = false;
         v = vnext;
@@ -938,12 +1014,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2
     };
     set_tile(v);
     issue(0, S0{});
+    const int fn0 = n0;                                 // (NT_EPI_STATSC: every tile of this workgroup has this channel block — the host checks)
     for (;;) {
         if (body(S0{})) break;
         if (nk & 1) {
             if (body(S1{})) break;
         }
     }
+    if constexpr (EPI == NT_EPI_STATSC) nt_stats_flush<T, BM, BN, NW>(p, carry, fn0, lane, wm, wn, (int)blockIdx.x * WROWS + wm);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -283,7 +283,7 @@ class Lowering(object):
                 gm.tile = t
                 cand.append(int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, None)))
             gm.tile = keep
-            part = torch.zeros((max(cand), 3, y.shape[-1]), dtype=torch.float32, device=self.g.device)
+            part = torch.zeros((max(cand), 4, y.shape[-1]), dtype=torch.float32, device=self.g.device)      # (4 planes: room for counted rows)
             bn.attrs['fused_stats'] = (part, gm)
             self.fwd.add(lib.mcn_conv2d_fwd_bnstats, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')),
                          y.buf.data_ptr(), part.data_ptr(), ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)

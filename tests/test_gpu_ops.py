@@ -581,10 +581,11 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         g.tile = tile
         rpp = ctypes.c_int32(0)
         rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT[dtype], ctypes.byref(rpp))
-        assert rows > 0 and rows * rpp.value >= y_plain.size // cout
+        counted = rpp.value == 0                   # one row per persistent workgroup and wave row, [4][C]: the count is explicit
+        assert rows > 0 and (counted or rows * rpp.value >= y_plain.size // cout)
         xd, wd = u.dev(x, dtype), u.dev(w)
         y = torch.full(y_plain.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
-        part = torch.full((rows, 3, cout), float('nan'), dtype=torch.float32, device=u.DEV)
+        part = torch.full((rows, 4 if counted else 3, cout), float('nan'), dtype=torch.float32, device=u.DEV)
         ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]))
         _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
                                               ws.data_ptr(), ws.numel() * 4, u.stream()))
@@ -598,7 +599,21 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         p = u.host(part).astype(np.float64)
         yq = ys.astype(np.float64).reshape(-1, cout)                            # the partials describe the values THIS launch stored
         m = yq.shape[0]
-        for kk in range(rows):                                                   # every partial: shifted sums of its own rows
+        if counted:
+            # per channel the rows partition the pixels (a row counts 0 for the channels its workgroup does not own; whatever else
+            # it holds there is ignored) and merge to the tensor's moments
+            cnt = p[:, 3, :]
+            assert not np.isnan(cnt).any() and np.all(cnt >= 0) and np.all(cnt.sum(0) == m)
+            live = cnt > 0
+            cs = np.where(live, cnt, 1.0)
+            s1, s2, pv = (np.where(live, p[:, i, :], 0.0) for i in range(3))
+            mean_k = pv + s1 / cs
+            m2_k = s2 - s1 ** 2 / cs
+            tot_mean = (cnt * mean_k).sum(0) / m
+            tot_var = (np.where(live, m2_k + cnt * mean_k ** 2, 0.0)).sum(0) / m - tot_mean ** 2
+            np.testing.assert_allclose(tot_mean, yq.mean(0), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(tot_var, yq.var(0), rtol=2e-4)
+        for kk in range(0 if counted else rows):                                 # every partial: shifted sums of its own rows
             blk = yq[kk * rpp.value:(kk + 1) * rpp.value]
             if len(blk) == 0:
                 continue
