@@ -392,6 +392,10 @@ def main():
                            'event_bracket_overhead_us': round(bracket_us, 2)}
         out['roofline']['algorithmic_bytes_per_launch'] = int(alg_bytes / cnt)
         out['roofline'].update(pmc_traffic(name, args.dtype, args.batch))
+        # the same figure for every conv kernel symbol (round 1's dominant symbol, the 3x3 forward AND dgrad, is several symbols now)
+        out['roofline_by_kernel'] = {k: {'launches_per_step': v[0], 'ms_per_step': round(v[1], 3), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                         'frac': round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 3)}
+                                     for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])[:8] if v[1] > 0}
         tot = sum(v[1] for v in table.values())
         out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 12)]}
         out['kernel_ms_total'] = round(tot, 3)
