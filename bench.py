@@ -414,6 +414,16 @@ def main():
                            'e2e_mfma_frac': round(ips2 * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS['bf16'] * 1e12), 4)}
             del m2, o2
             torch.cuda.empty_cache()
+            # the other single-GPU configurations of BASELINE.json as secondary keys (short runs; `--model ...` gives the full line)
+            for key, mdl, bsz in (('efficientnet_b0_bf16', 'efficientnet_b0', 512), ('deeplabv3plus_bf16', 'deeplabv3plus', 16)):
+                a3 = _a.Namespace(**vars(args))
+                a3.model, a3.batch = mdl, bsz
+                m3, o3 = build_model(a3, 'bf16', 1)
+                dt3 = timed(o3, args.steps, args.warmup, 1, False)
+                out[key] = {'value': round(bsz * args.steps / dt3, 2), 'unit': 'images/sec', 'ms_per_step': round(dt3 / args.steps * 1e3, 3), 'batch': bsz,
+                            'config': 'BASELINE configs[3] (EfficientNet-B0, 224x224)' if mdl == 'efficientnet_b0' else 'BASELINE configs[4] on one GPU (DeepLabv3+, 513x513)'}
+                del m3, o3
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
