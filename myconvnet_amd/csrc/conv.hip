@@ -282,9 +282,10 @@ static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
 // window (BM + span rows of 128 bytes, span = (KH-1)*DH*IW + (KW-1)*DW pixels) plus two B buffers stay within 64 KB and 1.6x the
 // LDS of the two-buffer kernel (occupancy: fp32 64x64 keeps 4-5 workgroups per CU up to 56-wide maps).
 // Measured per layer (B = 256): fp32 7x7 492 -> 460 us, 14x14 504 -> 468, 28x28 510 -> 482, 56x56 518 -> 504 (the staging probe's
-// bound was -8 %).  The 2-byte types do NOT gain (bf16 14x14 69.9 -> 71.5 us, 56x56 91 -> 103): their 16-row fragment reads hit
-// the window at odd row offsets, where the (row >> 1) XOR swizzle is 2-way bank-conflicted for the 16x16x32 operand map, and the
-// one exposed window load per channel chunk is a larger share of their short K-steps — fp32 only by default.
+// bound was -8 %).  The 2-byte types do NOT gain (bf16 14x14 68.9 -> 69.6 us, 28x28 76.5 -> 78.9, 56x56 95 -> 104, 7x7 69 -> 63 with a
+// window swizzle that is conflict-free at every row offset; the first build, 2-way conflicted at odd offsets, measured the
+// same): the one exposed window load per channel chunk and the per-K-step fragment address arithmetic are a larger share
+// of their short K-steps (512 MFMA cycles against 1024 in fp32) — fp32 only by default.
 // MCN_NT_WINDOW: 0 = off, 1 = fp32 (default), 2 = every dtype.
 #define NT_WINDOW 3
 static int nt_window_level() {

@@ -1068,7 +1068,13 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt_win(const GemmNTParams p
     const int WB = wrows8 * 128;
     const int ZOFF = P * 128;
     const int crow = tid >> 3;
-    const int cid = (tid & 7) ^ ((crow >> 1) & 7);     // chunk this thread fetches (source-side swizzle; RPP % 16 == 0: the key is pass-invariant)
+    // Swizzle key of a WINDOW row: fragment reads start at arbitrary row offsets (tap shifts).  For the 32-row fp32 fragments
+    // (row >> 1) & 7 is conflict-free at every offset; for the 16-row x 4-chunk fragments of the 2-byte types it is 2-way
+    // conflicted unless the offset is a multiple of 4, and row & 7 is conflict-free at every offset (enumerated over the
+    // ds_read_b128 lane groups).  The B tile keeps the tile key (its rows start at multiples of 16).
+    auto wkey = [](int r) -> int { return sizeof(T) == 4 ? ((r >> 1) & 7) : (r & 7); };
+    const int cid = (tid & 7) ^ ((crow >> 1) & 7);     // B tile: chunk this thread fetches (source-side swizzle; RPP % 16 == 0: the key is pass-invariant)
+    const int cidw = (tid & 7) ^ wkey(crow);           // window rows (RPP % 8 == 0)
     const int pix_bytes = p.Cs * (int)sizeof(T);
     const int ntaps = p.ntaps, kpt = p.cpt >> 3;
     unsigned b_off[BR];
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt_win(const GemmNTParams p
                 const int j = ps * RPP + crow;
                 const int q = m0 + p.win_dmin + j;                        // input pixel of window row j
                 const unsigned bad = (unsigned)q | (unsigned)(p.M - 1 - q) | (unsigned)(P - 1 - j);      // sign bits: outside the tensor / behind the window
-                const unsigned off = ((unsigned)q * (unsigned)pix_bytes + (unsigned)(cb * 128 + cid * 16)) | ((bad >> 31) << 31);
+                const unsigned off = ((unsigned)q * (unsigned)pix_bytes + (unsigned)(cb * 128 + cidw * 16)) | ((bad >> 31) << 31);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbaseA + ps * RPP * 128), 16, (int)off, 0, 0, 0);
             }
         });
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt_win(const GemmNTParams p
         for (int i = 0; i < TM; ++i) {
             const int wr = rloc[i] + sh;
             abase[i] = wr << 7;
-            akey[i] = ((vm[i] >> t) & 1u) ? ((wr >> 1) & 7) : -1;
+            akey[i] = ((vm[i] >> t) & 1u) ? wkey(wr) : -1;
         }
         load_frags(0, 0, bbase);
 #pragma unroll
