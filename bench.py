@@ -210,7 +210,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 gm = [x for x in a if hasattr(x, '_obj')][0]._obj          # ctypes.byref(geom)
                 oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
                 ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
-                flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout
+                flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout * getattr(gm, '_flop_scale', 1.0)   # (pixel-pair stem: count the 7x7x3 MACs)
                 # one entry per GEMM launch of the call (a strided dgrad: one per stride-parity class, not all the same symbol)
                 nl = lib.mcn_conv2d_launch_list(ops[name], ctypes.byref(gm), mdt, lbuf, 1024)
                 launches = [ln.rsplit(':', 1) for ln in lbuf.value.decode().splitlines()]

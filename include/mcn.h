@@ -118,6 +118,17 @@ int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njobs, mcn_dty
                                 size_t host_table_bytes, int32_t* ndesc);
 int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, void* stream);
 
+/* Pixel-pair form of a horizontally stride-2 convolution on <= 4 input channels in a 2-byte type (the stem conv of
+ * models/resnet_v1_5.py:25 / efficientnet.py:96): the image is stored 4 channels per pixel ([N,H,W,4], x_cs = 4), two adjacent
+ * pixels are one 16-byte chunk, and the conv is the stride-(SH,1) convolution of the [N,H,W/2,8] view with a [KH,KW',8,Cout]
+ * filter (7x7/2: KW' = 4, K 392 -> 224).  mcn_conv2d_pair_geom returns 1 and fills `paired` (to be used with the ordinary
+ * mcn_conv2d_* entry points on the same buffers) when the form exists, else 0.  mcn_conv2d_pair_weights builds the paired filter
+ * (fp32, [KH][KW'][8][Cout]) from the HWIO master; mcn_conv2d_pair_wgrad_fold gathers the paired filter's gradient back to HWIO.
+ * `g` is the ORIGINAL geometry in all three. */
+int mcn_conv2d_pair_geom(const mcn_conv_geom* g, mcn_dtype dtype, mcn_conv_geom* paired);
+int mcn_conv2d_pair_weights(const float* w_hwio, float* w_paired, const mcn_conv_geom* g, mcn_dtype dtype, void* stream);
+int mcn_conv2d_pair_wgrad_fold(const float* dw_paired, float* dw_hwio, const mcn_conv_geom* g, mcn_dtype dtype, void* stream);
+
 /* profiling aid: writes the name of the GEMM kernel a conv call launches (as rocprofv3 prints it) into buf
  * (>= 64 bytes) and returns how many launches of it the call makes (stride-2 dgrad: one per parity class).  For
  * The last template argument of the printed name is the epilogue variant: 0 as printed; 1 for mcn_conv2d_fwd_bnstats;

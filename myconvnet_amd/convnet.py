@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from .graph import TORCH_DT, FlatStore, Graph, Variable, out_size, same_pads
+from .graph import MCN_DT, TORCH_DT, FlatStore, Graph, Variable, out_size, same_pads
 
 
 # ---- initializers (reference passes tf.initializers.* objects) -----------------------------------------
@@ -324,11 +324,38 @@ class ConvNet(object):
         self.compiled = True
         return self
 
+    def _plan_pixel_pairs(self):
+        """2-byte storage types: a stride-2 conv that is the only reader of the (<= 4-channel) network input runs in its pixel-pair
+        form (mcn_conv2d_pair_geom: the image is stored 4 channels per pixel, two adjacent pixels are one 16-byte chunk, the
+        7x7/2 stem becomes a 7x4 stride-(2,1) conv on 8 channels: K 392 -> 224).  The node keeps the original geometry as
+        `geom_orig`; its weights / weight gradient pass through mcn_conv2d_pair_weights / _pair_wgrad_fold in the executor.
+        MCN_PAIR_STEM=0 switches it off."""
+        import ctypes
+        if self._dtype == 'float32' or os.environ.get('MCN_PAIR_STEM', '1') == '0' or getattr(self, '_pairs_planned', False):
+            return
+        self._pairs_planned = True
+        X = self.X
+        readers = [n for n in self.graph.nodes if any(t is X for t in n.inputs)]
+        if len(readers) != 1 or readers[0].op != 'conv' or X.needs_grad:
+            return
+        n = readers[0]
+        src = n.attrs['geom']
+        g4 = _ffi.ConvGeom(*[getattr(src, f) for f, _ in _ffi.ConvGeom._fields_])
+        g4.x_cs = 4
+        pg = _ffi.ConvGeom()
+        if _ffi.lib.mcn_conv2d_pair_geom(ctypes.byref(g4), MCN_DT[self._dtype], ctypes.byref(pg)) != 1:
+            return
+        X.cs = 4
+        n.attrs['geom_orig'] = g4
+        n.attrs['geom'] = pg
+        n.attrs['flop_scale'] = float(g4.KH * g4.KW * g4.Cin) / float(pg.KH * pg.KW * pg.Cin)     # real MACs per MAC of the paired form
+
     def _allocate(self):
         g = self.graph
         if self.fuse and not getattr(self, '_fused', False):
             g.fuse()
             self._fused = True
+        self._plan_pixel_pairs()
         B = self.device_batch
         H, W, C = self._input_size
         dev = self.device

@@ -1065,6 +1065,75 @@ extern "C" int mcn_conv2d_pack_table_build(const mcn_pack_job* jobs, int32_t njo
     *ndesc = n;
     return MCN_OK;
 }
+// ---- pixel-pair form of a stride-2 convolution on few input channels (the stem) ----------------------------------------
+// A 2-byte type keeps 8 elements per 16-byte chunk: a 3-channel image padded to 8 channels wastes 5/8 of every operand byte and
+// MFMA (K = taps x 8).  With the image stored 4 channels per pixel, two horizontally adjacent pixels are one chunk, and a
+// convolution with horizontal stride 2 reads whole pairs: output ox covers input pixels 2*ox - padL .. + KW - 1, i.e. pairs
+// ox - padL' .. + KW' - 1 with padL' = ceil(padL / 2), KW' = floor((KW - 1 - padL) / 2) + padL' + 1.  That IS a convolution of
+// the [N, H, W/2, 8] view with a [KH, KW', 8, Cout] filter, horizontal stride 1: filter element (kp, parity, c) is the original
+// (kx = 2*kp + parity - (padL & 1), c), zero where kx falls outside 0..KW-1 or c >= Cin.  ResNet stem 7x7 / 2: K 392 -> 224;
+// EfficientNet stem 3x3 / 2: 72 -> 48.  The weight gradient of the paired filter is gathered back to the HWIO layout.
+static bool pair_plan(const mcn_conv_geom* g, mcn_dtype dtype, mcn_conv_geom* out) {
+    if (!g || mcn_dtype_size(dtype) != 2 || g->Cin < 1 || g->Cin > 4 || g->SW != 2 || g->DW != 1 || g->DH != 1 || g->W < 2 || (g->W & 1)) return false;
+    if (g->x_cs != 0 && g->x_cs != 4) return false;                       // the caller stores the image 4 channels per pixel
+    if (g->KW < 2 || g->padL < 0 || g->padL > g->KW - 1) return false;
+    const int OW = (g->W + g->padL + g->padR - g->KW) / 2 + 1;
+    if (OW < 1) return false;
+    const int pl = (g->padL + 1) / 2;
+    const int kw = (g->KW - 1 - g->padL) / 2 + pl + 1;
+    const int Wp = g->W / 2;
+    const int pr = OW - 1 + kw - Wp - pl;                                 // so that the paired geometry yields the same OW
+    if (pr < 0) return false;
+    if (out) {
+        *out = *g;
+        out->W = Wp; out->Cin = 8; out->KW = kw; out->SW = 1; out->padL = pl; out->padR = pr; out->x_cs = 8;
+    }
+    return true;
+}
+extern "C" int mcn_conv2d_pair_geom(const mcn_conv_geom* g, mcn_dtype dtype, mcn_conv_geom* paired) { return pair_plan(g, dtype, paired) ? 1 : 0; }
+__global__ __launch_bounds__(256) void pair_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int KH, int KW, int Cin, int Cout, int KWp, int shift) {
+    const long total = (long)KH * KWp * 8 * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % Cout);
+        long r = i / Cout;
+        const int e = (int)(r % 8);
+        r /= 8;
+        const int kp = (int)(r % KWp), ky = (int)(r / KWp);
+        const int c = e & 3, kx = 2 * kp + (e >> 2) - shift;
+        wp[i] = (c < Cin && kx >= 0 && kx < KW) ? w[(((long)ky * KW + kx) * Cin + c) * Cout + n] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void pair_wgrad_fold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int KH, int KW, int Cin, int Cout, int KWp, int shift) {
+    const long total = (long)KH * KW * Cin * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % Cout);
+        long r = i / Cout;
+        const int c = (int)(r % Cin);
+        r /= Cin;
+        const int kx = (int)(r % KW), ky = (int)(r / KW);
+        const int ks = kx + shift;
+        dw[i] = dwp[(((long)ky * KWp + (ks >> 1)) * 8 + (ks & 1) * 4 + c) * Cout + n];
+    }
+}
+extern "C" int mcn_conv2d_pair_weights(const float* w_hwio, float* w_paired, const mcn_conv_geom* g, mcn_dtype dtype, void* stream) {
+    mcn_conv_geom pg;
+    if (!w_hwio || !w_paired || !pair_plan(g, dtype, &pg)) MCN_FAIL(MCN_E_BADARG, "conv2d_pair_weights: geometry has no pixel-pair form");
+    const long total = (long)g->KH * pg.KW * 8 * g->Cout;
+    hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream, w_hwio, w_paired,
+                       g->KH, g->KW, g->Cin, g->Cout, pg.KW, g->padL & 1);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_conv2d_pair_wgrad_fold(const float* dw_paired, float* dw_hwio, const mcn_conv_geom* g, mcn_dtype dtype, void* stream) {
+    mcn_conv_geom pg;
+    if (!dw_paired || !dw_hwio || !pair_plan(g, dtype, &pg)) MCN_FAIL(MCN_E_BADARG, "conv2d_pair_wgrad_fold: geometry has no pixel-pair form");
+    const long total = (long)g->KH * g->KW * g->Cin * g->Cout;
+    hipLaunchKernelGGL(pair_wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream, dw_paired, dw_hwio,
+                       g->KH, g->KW, g->Cin, g->Cout, pg.KW, g->padL & 1);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
 extern "C" int mcn_conv2d_pack_run(const void* dev_table, int32_t ndesc, mcn_dtype dtype, void* stream) {
     if (ndesc <= 0) return MCN_OK;
     if (!dev_table) MCN_FAIL(MCN_E_BADARG, "pack_run: null table");

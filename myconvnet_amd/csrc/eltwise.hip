@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void input_prep_kernel(const float* __restrict
             store_chunk<T>(o, ch);
             continue;
         }
+        if (sizeof(T) == 2 && out_cs == 4) {                 // pixel-pair layout of the stem (4 channels per pixel): one 8-byte store
+            T v4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v4[c] = from_f32<T>(c < C ? ((NCHW ? x[(n * C + c) * HW + r] : x[p * C + c]) - mean) * scale : 0.f);
+            *reinterpret_cast<uint64_t*>(o) = *reinterpret_cast<const uint64_t*>(v4);
+            continue;
+        }
         for (int c = 0; c < out_cs; ++c) {
             float v = 0.f;
             if (c < C) {

@@ -79,6 +79,7 @@ class Lowering(object):
         if op not in d:
             src = n.attrs['geom']
             d[op] = _ffi.ConvGeom(*[getattr(src, f) for f, _ in _ffi.ConvGeom._fields_])
+            d[op]._flop_scale = n.attrs.get('flop_scale', 1.0)       # (pixel-pair form: real MACs per MAC of the launched geometry; bench.py)
         return d[op]
 
     def scratch_like(self, t, key):
@@ -155,9 +156,13 @@ class Lowering(object):
         for n in self.g.nodes:
             if n.op != 'conv':
                 continue
+            if 'geom_orig' in n.attrs:
+                # pixel-pair form (convnet._plan_pixel_pairs): the paired filter is rebuilt from the master (or its EMA shadow) in front
+                # of the batched pack
+                self.prepack.add(lib.mcn_conv2d_pair_weights, self.vptr(n.attrs['w']), self.pair_buffers(n)[0].data_ptr(), ctypes.byref(n.attrs['geom_orig']), self.dt)
             for op in (_ffi.CONV_FWD, _ffi.CONV_DGRAD):
                 if (id(n), op) in self.packed_ptr:
-                    jobs.append(_ffi.PackJob(self.vptr(n.attrs['w']), self.packed_ptr[(id(n), op)], n.attrs['geom'], op, 0))
+                    jobs.append(_ffi.PackJob(self.wsrc(n), self.packed_ptr[(id(n), op)], n.attrs['geom'], op, 0))
         if not jobs:
             return
         arr = (_ffi.PackJob * len(jobs))(*jobs)
@@ -170,6 +175,20 @@ class Lowering(object):
 
     def wp(self, n, op):
         return self.packed_ptr.get((id(n), op), 0)
+
+    def pair_buffers(self, n):
+        """(paired filter, paired filter gradient) of a conv in pixel-pair form: fp32 [KH][KW'][8][Cout], shared by the lowerings"""
+        if 'pair_buf' not in n.attrs:
+            pg = n.attrs['geom']
+            size = pg.KH * pg.KW * pg.Cin * pg.Cout
+            n.attrs['pair_buf'] = (torch.zeros(size, dtype=torch.float32, device=self.g.device), torch.zeros(size, dtype=torch.float32, device=self.g.device))
+        return n.attrs['pair_buf']
+
+    def wsrc(self, n):
+        """fp32 HWIO filter the conv entry points read for node n: the variable (master / EMA shadow), or its paired form"""
+        if 'geom_orig' in n.attrs:
+            return self.pair_buffers(n)[0].data_ptr()
+        return self.vptr(n.attrs['w'])
 
     def autotune(self, reps=3):
         """Measure, don't guess: time every tile candidate of every conv launch of this lowering on the GPU (HIP events
@@ -285,10 +304,10 @@ class Lowering(object):
             gm.tile = keep
             part = torch.zeros((max(cand), 4, y.shape[-1]), dtype=torch.float32, device=self.g.device)      # (4 planes: room for counted rows)
             bn.attrs['fused_stats'] = (part, gm)
-            self.fwd.add(lib.mcn_conv2d_fwd_bnstats, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')),
+            self.fwd.add(lib.mcn_conv2d_fwd_bnstats, x.buf.data_ptr(), self.wsrc(n), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')),
                          y.buf.data_ptr(), part.data_ptr(), ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
             return
-        self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.vptr(n.attrs['w']), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
+        self.fwd.add(lib.mcn_conv2d_fwd, x.buf.data_ptr(), self.wsrc(n), self.wp(n, _ffi.CONV_FWD), self.vptr(n.attrs.get('b')), y.buf.data_ptr(),
                      ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
 
     def bwd_conv(self, n):
@@ -300,13 +319,19 @@ class Lowering(object):
         def emit_wgrad():
             if not w.trainable:
                 return
+            paired = 'geom_orig' in n.attrs
+            dw_ptr = self.pair_buffers(n)[1].data_ptr() if paired else w.grad.data_ptr()     # pixel-pair form: gradient of the paired filter, gathered back below
             if self.overlap_wgrad:
-                self.bwd.add_side(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(),
+                self.bwd.add_side(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), dw_ptr,
                                   b.grad.data_ptr() if b is not None else 0, ctypes.byref(gw), gs, self.dt, _ffi.NHWC, self.ws2.data_ptr(),
                                   self.ws2.numel() * 4)
+                if paired:
+                    self.bwd.add_side(lib.mcn_conv2d_pair_wgrad_fold, dw_ptr, w.grad.data_ptr(), ctypes.byref(n.attrs['geom_orig']), self.dt)
             else:
-                self.bwd.add(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(),
+                self.bwd.add(lib.mcn_conv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), dw_ptr,
                              b.grad.data_ptr() if b is not None else 0, ctypes.byref(gw), gs, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+                if paired:
+                    self.bwd.add(lib.mcn_conv2d_pair_wgrad_fold, dw_ptr, w.grad.data_ptr(), ctypes.byref(n.attrs['geom_orig']), self.dt)
             self.bwd.mark(('grad_ready', tuple(v.name for v in (w, b) if v is not None)))
 
         # With the side stream the wgrad is enqueued AFTER the dgrad: its start event then sits behind the dgrad, so the

@@ -794,3 +794,46 @@ def test_conv_dgrad_with_masked_residual_add(case, dtype):
     np.testing.assert_array_equal(u.host(dx), ref)
     g2 = u.geom((n, 2 * h, 2 * w_, cin), wgt.shape, 2, 'SAME')
     assert lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(g2), u.MDT[dtype]) == 0      # strided: not eligible
+
+
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float16'])
+@pytest.mark.parametrize('case', [(2, 32, 32, 3, 64, 7, 'SAME'),      # the ResNet stem: TF SAME pads (2,3), even left pad
+                                  (3, 18, 20, 3, 32, 3, 'SAME'),      # the EfficientNet stem: pads (0,1)
+                                  (2, 16, 16, 4, 16, 5, 'SAME'),      # 4 input channels, pads (1,2): odd left pad
+                                  (1, 12, 14, 1, 8, 7, 'VALID'),      # no padding, 1 channel
+                                  (2, 9, 8, 2, 24, 3, 'SAME')])       # odd H, pads (1,0)... W even is what the form needs
+def test_conv_pixel_pair_form(case, dtype):
+    """Pixel-pair form of a stride-2 conv on <= 4 input channels (mcn_conv2d_pair_geom / _pair_weights / _pair_wgrad_fold): the
+    image stored 4 channels per pixel, run through the ORDINARY conv entry points with the paired geometry and filter, must give
+    the plain convolution and (after the fold) its weight gradient."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k, pad = case
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    w = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    xq, wq = q(x, dtype), q(w, dtype)
+    y_ref = O.conv2d_fwd(xq, wq, 2, pad)
+    g = u.geom(x.shape, w.shape, 2, pad, 1, 4)
+    pg = _ffi.ConvGeom()
+    assert lib.mcn_conv2d_pair_geom(ctypes.byref(g), u.MDT[dtype], ctypes.byref(pg)) == 1
+    assert (pg.W, pg.Cin, pg.SW, pg.x_cs, pg.SH, pg.KH) == (w_ // 2, 8, 1, 8, 2, k) and pg.KW <= (k + 2) // 2 + 1
+    assert lib.mcn_conv2d_pair_geom(ctypes.byref(g), _ffi.F32, ctypes.byref(_ffi.ConvGeom())) == 0          # 2-byte storage types only
+    x4 = np.zeros((n, h, w_, 4), np.float32)
+    x4[..., :cin] = x
+    xd, wd = u.dev(x4, dtype), u.dev(w)
+    wp = torch.full((pg.KH * pg.KW * 8 * cout,), float('nan'), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_conv2d_pair_weights(wd.data_ptr(), wp.data_ptr(), ctypes.byref(g), u.MDT[dtype], u.stream()))
+    y = torch.full(y_ref.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    ws = u.workspace(max(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(pg), u.MDT[dtype]), lib.mcn_conv2d_workspace_bytes(_ffi.CONV_WGRAD, ctypes.byref(pg), u.MDT[dtype])))
+    _ffi.check(lib.mcn_conv2d_fwd(xd.data_ptr(), wp.data_ptr(), 0, 0, y.data_ptr(), ctypes.byref(pg), u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    check(u.host(y), y_ref, dtype, 'paired fwd')
+    # the same products as the 8-channel-padded form, summed in another order: equal up to one rounding of the stored type
+    np.testing.assert_allclose(u.host(y), u.conv_fwd(x, w, 2, pad, 1, dtype), rtol=2e-2 if dtype == 'bfloat16' else 3e-3, atol=2e-2 if dtype == 'bfloat16' else 3e-3)
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dyd = u.dev(dy, dtype)
+    dwp = torch.full_like(wp, float('nan'))
+    _ffi.check(lib.mcn_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dwp.data_ptr(), 0, ctypes.byref(pg), 0.5, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    dw = torch.full(w.shape, float('nan'), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_conv2d_pair_wgrad_fold(dwp.data_ptr(), dw.data_ptr(), ctypes.byref(g), u.MDT[dtype], u.stream()))
+    check(u.host(dw), 0.5 * O.conv2d_wgrad(xq, q(dy, dtype), w.shape, 2, pad), 'float32', 'paired wgrad', rel=2e-5)
