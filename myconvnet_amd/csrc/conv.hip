@@ -116,6 +116,14 @@ static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int forced, i
     static const int env_tile = [] { const char* e = getenv("MCN_TN_TILE"); return e ? atoi(e) : 0; }();      // experiments: gathered (non-linear) wgrads only
     if (env_tile >= 1 && env_tile <= 4 && !linear) { *br = cand[env_tile - 1][0]; *bn = cand[env_tile - 1][1]; return; }
     if (dt == MCN_F32 && linear) { *br = 64; *bn = 64; return; }
+    // 256x256 on 8 waves (wave tile 64x128; 128 KB of LDS, one workgroup per CU) for the 2-byte types: half the operand bytes staged
+    // per FLOP.  Measured (bf16, B = 256): the 3x3 wgrads with >= 256 output channels gain 7-13 % (14x14 256ch 111 -> 103 us, 7x7 512ch
+    // 111 -> 99, 28x28 256ch / 2 129 -> 113, 14x14 512ch / 2 118 -> 106); the 1x1 wgrads (rows = Cin: few tiles, short splits) lose up to
+    // 60 %.  In the real step (wgrad on the side stream beside the dgrad / BN-backward chain) the rule "rows >= 4 x Cout" measured
+    // 22.86 -> 22.83 and 22.74 -> 22.96 ms: noise, and a 128 KB workgroup keeps the main stream's 64 KB dgrad workgroups off its CU —
+    // off by default.  MCN_TN_256: 0 = off (default), 1 = that rule, 2 = wherever it fits.
+    static const int big = [] { const char* e = getenv("MCN_TN_256"); return e ? atoi(e) : 0; }();
+    if (big && dt != MCN_F32 && rows >= 256 && Cout >= 256 && (big > 1 || (!linear && rows >= 4 * Cout))) { *br = 256; *bn = 256; return; }
     *br = rows <= 64 ? 64 : 128;
     *bn = Cout <= 64 ? 64 : 128;
 }
@@ -180,7 +188,7 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     return b;
 }
 
-extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 5; }    /* NT: 128x128, 128x64, 64x64, 256x128 / 8 waves and 128x128 / 8 waves (2-byte types); TN: 4 shapes */
+extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 5; }      /* (the 256x256 wgrad tile of the 2-byte types is chosen by rule, not a candidate) */    /* NT: 128x128, 128x64, 64x64, 256x128 / 8 waves and 128x128 / 8 waves (2-byte types); TN: 4 shapes */
 
 extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
@@ -532,12 +540,12 @@ static int launch_tn(const GemmTNParams& p, bool linear, int splits, int forced_
     tn_tile(p.rows, p.Nn, DtypeOf<T>::value, linear, forced_tile, &BR, &BN);
     const int tiles = ((p.rows + BR - 1) / BR) * ((p.Nn + BN - 1) / BN);
     const bool nw8 = BR == 128 && BN == 128 && tn_nw8(sizeof(T));
-    const dim3 grid(tiles, splits), block(nw8 ? 512 : 256);
+    const dim3 grid(tiles, splits), block(nw8 || BR == 256 ? 512 : 256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
 #define MCN_LAUNCH_TN(BRV, BNV, LINV, NWV)                                           \
     do {                                                                             \
         const int lds = 2 * KP * (BRV + BNV) * (int)sizeof(T);                       \
-        static bool once = (allow_lds(conv_gemm_tn<T, BRV, BNV, LINV, NWV>, 2 * 64 * (BRV + BNV) * 4), true); \
+        static bool once = (allow_lds(conv_gemm_tn<T, BRV, BNV, LINV, NWV>, 2 * KP * (BRV + BNV) * (int)sizeof(T)), true); \
         (void)once;                                                                  \
         hipLaunchKernelGGL((conv_gemm_tn<T, BRV, BNV, LINV, NWV>), grid, block, lds, st, p); \
     } while (0)
@@ -545,7 +553,10 @@ static int launch_tn(const GemmTNParams& p, bool linear, int splits, int forced_
     do {                                                             \
         if (linear) MCN_LAUNCH_TN(BRV, BNV, true, NWV); else MCN_LAUNCH_TN(BRV, BNV, false, NWV); \
     } while (0)
-    if (nw8) MCN_LAUNCH_TN_LIN(128, 128, 8);
+    if (BR == 256) {
+        if constexpr (sizeof(T) == 2) MCN_LAUNCH_TN_LIN(256, 256, 8);
+        else MCN_FAIL(MCN_E_UNSUPPORTED, "conv: the 256x256 wgrad tile is for the 2-byte types");
+    } else if (nw8) MCN_LAUNCH_TN_LIN(128, 128, 8);
     else if (BR == 128 && BN == 128) MCN_LAUNCH_TN_LIN(128, 128, 4);
     else if (BR == 128) MCN_LAUNCH_TN_LIN(128, 64, 4);
     else if (BN == 128) MCN_LAUNCH_TN_LIN(64, 128, 4);
@@ -1208,7 +1219,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
-    snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype)) ? 8 : 4);
+    snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 256 || (br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype))) ? 8 : 4);
     return 1;
 }
 
