@@ -195,6 +195,19 @@ int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t n
                            int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* conv -> BN(train) -> ReLU -> max-pool (the stem of models/resnet_v1_5.py:25-31) with the statistics from the conv epilogue: the
+ * finalize step of mcn_bn_fwd_train_fused, then ONE pass that normalises, rectifies and pools x [N,H,W,C] into pooled
+ * [N,OH,OW,C] + argmax (same values, ties and arg-max as mcn_bn_fwd_train_fused followed by mcn_maxpool_fwd; the normalised
+ * tensor is never stored).  mcn_maxpool_fwd_affine_relu is that pass on its own (scale / shift: fp32 [C]). */
+int mcn_bn_fwd_train_fused_maxpool(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma,
+                                   const float* beta, void* pooled, int8_t* argmax, float* save_mean, float* save_invstd, float* batch_mean,
+                                   float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, float eps, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH,
+                                   int32_t OW, mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+int mcn_maxpool_fwd_affine_relu(const void* x, const float* scale, const float* shift, void* y, int8_t* argmax, int32_t N, int32_t H, int32_t W,
+                                int32_t C, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW,
+                                mcn_dtype dtype, void* stream);
+
 /* replaces tf.nn.fused_batch_norm(is_training=False) (convnet.py:1889-1896, 1916-1923) */
 int mcn_bn_fwd_infer(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
                      const void* skip, void* y, int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype,

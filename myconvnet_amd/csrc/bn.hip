@@ -601,6 +601,54 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
+// statistics from the conv-epilogue partials + (scale, shift) in the workspace; returns them through the out-pointers
+static int bn_fused_finalize(const float* parts, int nparts, int rpp, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* batch_mean,
+                             float* batch_var, float* running_mean, float* running_var, float momentum, long M, int C, float eps, void* ws, hipStream_t st,
+                             float** scale_out, float** shift_out) {
+    double* fold = (double*)ws;
+    float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
+    float* shift = scale + C;
+    const dim3 fgrid((C + FIN_CH - 1) / FIN_CH), fblock(FIN_CH * FIN_LANES);
+    if (nparts > BN_FOLD_ROWS) {
+        const int rpg = (nparts + BN_FOLD_ROWS - 1) / BN_FOLD_ROWS;
+        const int n = (nparts + rpg - 1) / rpg;
+        int TX = 8;
+        while (TX < C && TX < 256) TX *= 2;
+        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + TX - 1) / TX, n), dim3(256), 0, st, parts, fold, nparts, C, M, rpp, rpg, TX);
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL((bn_fwd_finalize_fused_kernel<true>), fgrid, fblock, 0, st, parts, (const double*)fold, n, rpp, M, C, gamma, beta, eps, save_mean,
+                           save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
+    } else {
+        hipLaunchKernelGGL((bn_fwd_finalize_fused_kernel<false>), fgrid, fblock, 0, st, parts, (const double*)nullptr, nparts, rpp, M, C, gamma, beta, eps,
+                           save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
+    }
+    MCN_CHECK_LAUNCH();
+    *scale_out = scale;
+    *shift_out = shift;
+    return MCN_OK;
+}
+extern "C" int mcn_maxpool_fwd_affine_relu(const void* x, const float* scale, const float* shift, void* y, int8_t* argmax, int32_t N, int32_t H, int32_t W,
+                                           int32_t C, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW,
+                                           mcn_dtype dtype, void* stream);
+// conv -> BN(train) -> ReLU -> max-pool with the BN statistics from the conv epilogue: finalize, then ONE pass that normalises,
+// rectifies and pools (the normalised tensor is never stored; its gradient path does not need it: the BN backward recomputes the
+// ReLU mask from x, the pool backward routes by arg-max)
+extern "C" int mcn_bn_fwd_train_fused_maxpool(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma,
+                                              const float* beta, void* pooled, int8_t* argmax, float* save_mean, float* save_invstd, float* batch_mean,
+                                              float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t H, int32_t W,
+                                              int32_t C, float eps, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH,
+                                              int32_t OW, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    const int64_t M = (int64_t)N * H * W;
+    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_maxpool: partials do not cover M rows");
+    if (!x || !pooled || !argmax || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 4) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_maxpool: bad argument");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused_maxpool: workspace too small");
+    float *scale, *shift;
+    if (int rc = bn_fused_finalize(stats_partials, nparts, rows_per_partial, gamma, beta, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum,
+                                   (long)M, C, eps, ws, (hipStream_t)stream, &scale, &shift))
+        return rc;
+    return mcn_maxpool_fwd_affine_relu(x, scale, shift, pooled, argmax, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, dtype, stream);
+}
+
 extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta,
                                       const void* skip, void* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, float* batch_mean,
                                       float* batch_var, float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,

@@ -32,8 +32,12 @@ static inline unsigned pool_blocks(long n) {
     return (unsigned)b;
 }
 
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, PoolParams p) {
+// AFF: the input is read through y0 = relu(x * scale[c] + shift[c]) rounded to the storage type — the batch-norm apply pass of the
+// layer in front (the ResNet stem: conv -> BN -> ReLU -> 3x3/2 pool) folded into the pool's loads, so that the normalised
+// tensor is never written or read.  Rounding before the comparison keeps value, ties and arg-max those of the unfused pair.
+template <typename T, int VEC, bool AFF = false>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, PoolParams p,
+                                                          const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
     const int cv = p.C / VEC;
     const long total = (long)p.N * p.OH * p.OW * cv;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -46,6 +50,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         int bi[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+        float sc[VEC], sh[VEC];
+        if constexpr (AFF) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+        }
         for (int kr = 0; kr < p.KH; ++kr) {
             const int iy = oy * p.SH + kr - p.padT;
             const bool yok = (unsigned)iy < (unsigned)p.H;
@@ -54,6 +63,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 const bool ok = yok && (unsigned)ix < (unsigned)p.W;     // clamped address + select: no branch per load
                 float v[VEC];
                 pld<T, VEC>(x + (((long)n * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * p.C + c, v);
+                if constexpr (AFF) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[i] = to_f32(from_f32<T>(fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f)));
+                }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
                     if (ok && v[i] > best[i]) { best[i] = v[i]; bi[i] = kr * p.KW + ks; }   // strict '>' : first maximum wins
@@ -324,6 +337,30 @@ extern "C" int mcn_maxpool_fwd(const void* x, void* y, int8_t* argmax, int32_t N
         if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 8>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p);
         else hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 1>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_fwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+// max-pool over relu(x * scale + shift) (see maxpool_fwd_kernel<AFF>); scale / shift: fp32 [C] on the device
+extern "C" int mcn_maxpool_fwd_affine_relu(const void* x, const float* scale, const float* shift, void* y, int8_t* argmax, int32_t N, int32_t H, int32_t W,
+                                           int32_t C, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW,
+                                           mcn_dtype dtype, void* stream) {
+    int rc = pool_check(x, y, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, "maxpool_fwd_affine_relu");
+    if (rc) return rc;
+    if (!argmax || !scale || !shift) MCN_FAIL(MCN_E_BADARG, "maxpool_fwd_affine_relu: null pointer");
+    if (N == 0) return MCN_OK;
+    const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * OH * OW * C;
+    if (dtype == MCN_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4, true>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p, scale, shift);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel<float, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p, scale, shift);
+    } else if (dtype == MCN_BF16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p, scale, shift);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p, scale, shift);
+    } else if (dtype == MCN_F16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p, scale, shift);
+        else hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p, scale, shift);
+    } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_fwd_affine_relu: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }

@@ -39,6 +39,7 @@ class Lowering(object):
         self.defer_dskip = bool(model._parameters.get('defer_dskip', _env_flag('MCN_DEFER_DSKIP', True)))
         self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
         self.written = set()           # tensor ids whose .grad already holds a contribution
+        self.fused_pools = set()       # ids of max-pool nodes whose forward runs inside the BN apply pass in front of them
         self.scratch = {}
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -222,7 +223,7 @@ class Lowering(object):
             gm.tile = best
             chosen[id(gm)] = best
         for fn, args in self.fwd.calls:                     # the partial-row count of a fused conv -> BN pair follows the tile
-            if getattr(fn, '__name__', '') == 'mcn_bn_fwd_train_fused':
+            if getattr(fn, '__name__', '') in ('mcn_bn_fwd_train_fused', 'mcn_bn_fwd_train_fused_maxpool'):
                 for nd in self.g.nodes:
                     fs = nd.attrs.get('fused_stats') if nd.op == 'bn' else None
                     if fs is not None and fs[0].data_ptr() == args[1]:
@@ -448,6 +449,19 @@ class Lowering(object):
                 part, gm = a['fused_stats']
                 rpp = ctypes.c_int32(0)
                 rows = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, ctypes.byref(rpp)))
+                pool = self._pool_consumer(n)
+                if pool is not None:
+                    # conv -> BN -> ReLU -> max-pool (the stem): finalize, then one pass that normalises, rectifies and pools; y is never
+                    # written (its readers: the pool, here; the BN backward recomputes the ReLU mask from x)
+                    if 'argmax' not in pool.attrs:
+                        pool.attrs['argmax'] = torch.zeros(pool.outputs[0].shape, dtype=torch.int8, device=self.g.device)
+                    self.fused_pools.add(id(pool))
+                    N_, H_, W_ = x.shape[0], x.shape[1], x.shape[2]
+                    self.fwd.add(lib.mcn_bn_fwd_train_fused_maxpool, x.buf.data_ptr(), part.data_ptr(), rows, rpp.value, self.vptr(a['gamma']), self.vptr(a['beta']),
+                                 pool.outputs[0].buf.data_ptr(), pool.attrs['argmax'].data_ptr(), st['mean'].data_ptr(), st['invstd'].data_ptr(),
+                                 st['bmean'].data_ptr(), st['bvar'].data_ptr(), a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
+                                 float(a['momentum']), *(self._pool_args(pool)[:4] + [float(a['eps'])] + self._pool_args(pool)[4:] + [MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes]))
+                    return
                 self.fwd.add(lib.mcn_bn_fwd_train_fused, x.buf.data_ptr(), part.data_ptr(), rows, rpp.value,
                              self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
                              y.buf.data_ptr(), mask_ptr, st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
@@ -602,8 +616,21 @@ class Lowering(object):
         N, H, W, C = x.shape
         return [N, H, W, C, a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl'], y.shape[1], y.shape[2]]
 
+    def _pool_consumer(self, n):
+        """the max-pool node that is the only reader of this training-mode BN + ReLU's output (folded into the BN apply pass), or None"""
+        if os.environ.get('MCN_FUSE_BN_POOL', '1') == '0' or not self.train:
+            return None
+        a, y = n.attrs, n.outputs[0]
+        if a.get('act', 0) != _ffi.ACT_RELU or a.get('skip') is not None or len(y.consumers) != 1 or y.consumers[0].op != 'maxpool':
+            return None
+        if len(y.shape) != 4 or y is self.model.d.get('logits'):
+            return None
+        return y.consumers[0]
+
     def fwd_maxpool(self, n):
         x, y = n.inputs[0], n.outputs[0]
+        if id(n) in self.fused_pools:                       # computed by the BN apply pass in front (mcn_bn_fwd_train_fused_maxpool)
+            return
         if 'argmax' not in n.attrs:
             n.attrs['argmax'] = torch.zeros(y.shape, dtype=torch.int8, device=self.g.device)
         self.fwd.add(lib.mcn_maxpool_fwd, x.buf.data_ptr(), y.buf.data_ptr(), n.attrs['argmax'].data_ptr(), *(self._pool_args(n) + [MCN_DT[x.dtype]]))

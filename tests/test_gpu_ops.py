@@ -837,3 +837,57 @@ def test_conv_pixel_pair_form(case, dtype):
     dw = torch.full(w.shape, float('nan'), dtype=torch.float32, device=u.DEV)
     _ffi.check(lib.mcn_conv2d_pair_wgrad_fold(dwp.data_ptr(), dw.data_ptr(), ctypes.byref(g), u.MDT[dtype], u.stream()))
     check(u.host(dw), 0.5 * O.conv2d_wgrad(xq, q(dy, dtype), w.shape, 2, pad), 'float32', 'paired wgrad', rel=2e-5)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 3, 2, 'SAME'), (3, 9, 11, 16, 3, 2, 'SAME'), (2, 12, 12, 8, 2, 2, 'VALID'), (1, 7, 7, 24, 3, 1, 'SAME')])
+def test_bn_relu_maxpool_in_one_pass(case, dtype):
+    """conv -> BN(train) -> ReLU -> max-pool with the statistics from the conv epilogue (the ResNet stem): the pass that normalises,
+    rectifies and pools must give, bit for bit, the pooled values and the arg-max of mcn_bn_fwd_train_fused followed by
+    mcn_maxpool_fwd — and the same saved / running statistics."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, c, k, s, pad = case
+    cin = 8
+    x = (RNG.standard_normal((n, h, w_, cin)) + 0.5).astype(np.float32)
+    wt = (RNG.standard_normal((1, 1, cin, c)) / np.sqrt(cin)).astype(np.float32)
+    gamma = (0.5 + RNG.random(c)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    g = u.geom(x.shape, wt.shape, 1, 'SAME')
+    rpp = ctypes.c_int32(0)
+    rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT[dtype], ctypes.byref(rpp))
+    assert rows > 0
+    xd, wd, gd, bd = u.dev(x, dtype), u.dev(wt), u.dev(gamma), u.dev(beta)
+    y = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    part = torch.full((rows, 4, c), float('nan'), dtype=torch.float32, device=u.DEV)
+    ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]))
+    _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
+                                          ws.data_ptr(), ws.numel() * 4, u.stream()))
+    m = n * h * w_
+    pads = O.resolve_pads(h, w_, k, k, s, s, pad, 1, 1)
+    oh, ow = O.out_size(h, k, s, pad, 1), O.out_size(w_, k, s, pad, 1)
+    bws = u.workspace(lib.mcn_bn_workspace_bytes(m, c))
+
+    def stats():
+        return [torch.zeros(c, dtype=torch.float32, device=u.DEV) for _ in range(4)] + [torch.zeros(c, dtype=torch.float32, device=u.DEV), torch.ones(c, dtype=torch.float32, device=u.DEV)]
+    # reference: the two separate calls
+    s_ref = stats()
+    yb = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_train_fused(y.data_ptr(), part.data_ptr(), rows, rpp.value, gd.data_ptr(), bd.data_ptr(), 0, yb.data_ptr(), 0, *[t.data_ptr() for t in s_ref],
+                                          0.99, m, c, 1e-3, 1, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, u.stream()))
+    p_ref = torch.full((n, oh, ow, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    a_ref = torch.full((n, oh, ow, c), -7, dtype=torch.int8, device=u.DEV)
+    _ffi.check(lib.mcn_maxpool_fwd(yb.data_ptr(), p_ref.data_ptr(), a_ref.data_ptr(), n, h, w_, c, k, k, s, s, pads[0], pads[2], oh, ow, u.MDT[dtype], u.stream()))
+    # one pass
+    s_one = stats()
+    p_one = torch.full((n, oh, ow, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    a_one = torch.full((n, oh, ow, c), -7, dtype=torch.int8, device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_train_fused_maxpool(y.data_ptr(), part.data_ptr(), rows, rpp.value, gd.data_ptr(), bd.data_ptr(), p_one.data_ptr(), a_one.data_ptr(),
+                                                  *[t.data_ptr() for t in s_one], 0.99, n, h, w_, c, 1e-3, k, k, s, s, pads[0], pads[2], oh, ow, u.MDT[dtype],
+                                                  bws.data_ptr(), bws.numel() * 4, u.stream()))
+    np.testing.assert_array_equal(u.host(p_one), u.host(p_ref))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(a_one.cpu().numpy(), a_ref.cpu().numpy())
+    for a, b in zip(s_one, s_ref):
+        np.testing.assert_array_equal(u.host(a), u.host(b))
