@@ -228,6 +228,14 @@ int mcn_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
                float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* mcn_bn_bwd(act = ReLU, no fused residual) for a BN whose output feeds ONLY a 3x3 / stride-2 max-pool (the stem): takes the
+ * pooled gradient [N,OH,OW,C] and the pool's arg-max and routes it inside its two passes; the full-resolution gradient of the BN
+ * output (the largest gradient tensor of the network) is never written.  Same dx as mcn_maxpool_bwd + mcn_bn_bwd, bit for bit. */
+int mcn_bn_bwd_maxpool(const void* dy_pooled, const int8_t* argmax, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int32_t H, int32_t W, int32_t C,
+                       int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* gradient of fused_batch_norm(is_training=False) used INSIDE a training graph: the frozen-statistics BN of
  * update_batch_norm=False / blocks_to_train (convnet.py:1781-1789, 1915-1923).  mean / var: the running statistics the
  * forward pass (mcn_bn_fwd_infer) normalised with.  dx = dz*gamma*invstd, dgamma = sum(dz*xhat), dbeta = sum(dz), with

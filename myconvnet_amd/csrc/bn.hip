@@ -429,6 +429,140 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ---- backward of BN + ReLU whose output gradient is the gradient of a 3x3 / 2 max-pool (the ResNet stem) ---------------------
+// mcn_maxpool_bwd would write the full-resolution gradient (the largest gradient tensor of the network) for the two BN passes to
+// read it back; here both passes build their dy chunk themselves: pixel (iy, ix) is seen by at most 2 x 2 pool windows, each
+// contributes its pooled gradient where its arg-max points at the pixel; the sum is rounded to the storage type exactly as the
+// stored tensor would have been.  ReLU mask recomputed from x (forward without a fused residual), as in RELU == 2 above.
+struct PoolRoute { int H, W, OH, OW, padT, padL; };
+template <typename T, int VEC>
+__device__ __forceinline__ void pool_route_dy(const T* __restrict__ dp, const int8_t* __restrict__ arg, const PoolRoute& P, unsigned r, int C, int col,
+                                              float (&g)[VEC]) {
+    static_assert(VEC == 4 || VEC == 8, "one 16-byte chunk per thread");
+    const unsigned r2 = r / (unsigned)P.W;
+    const int ix = (int)(r - r2 * (unsigned)P.W);
+    const int n = (int)(r2 / (unsigned)P.H), iy = (int)(r2 - (unsigned)n * (unsigned)P.H);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+    const int ty0 = iy + P.padT, tx0 = ix + P.padL;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = (ty0 >> 1) - a, kr = (ty0 & 1) + 2 * a;
+        const bool yok = kr < 3 && (unsigned)oy < (unsigned)P.OH;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ox = (tx0 >> 1) - b, ks = (tx0 & 1) + 2 * b;
+            const bool ok = yok && ks < 3 && (unsigned)ox < (unsigned)P.OW;
+            const long o = (((long)n * P.OH + (ok ? oy : 0)) * P.OW + (ok ? ox : 0)) * C + (long)col * VEC;
+            float gp[VEC];
+            ldv<T, VEC>(dp + o, gp);
+            signed char ac[VEC];
+            if constexpr (VEC == 8) *reinterpret_cast<unsigned long long*>(ac) = *reinterpret_cast<const unsigned long long*>(arg + o);
+            else *reinterpret_cast<unsigned*>(ac) = *reinterpret_cast<const unsigned*>(arg + o);
+            const int code = ok ? kr * 3 + ks : -1;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (ac[i] == code) g[i] += gp[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = to_f32(from_f32<T>(g[i]));           // the value mcn_maxpool_bwd stores
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dp, const int8_t* __restrict__ arg, const PoolRoute P, const T* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ part, long M, int C, int TX, int TY, long rpb) {
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const bool active = ty < TY && col * VEC < C;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+        ldc<VEC>(mean + col * VEC, mu);
+        ldc<VEC>(invstd + col * VEC, is);
+        ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+        ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] *= is[i];
+            sh[i] -= mu[i] * sc[i];
+        }
+        const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+        for (long r = r0 + ty; r < r1; r += TY) {
+            float g[VEC], v[VEC];
+            ldv<T, VEC>(x + r * C + (long)col * VEC, v);
+            pool_route_dy<T, VEC>(dp, arg, P, (unsigned)r, C, col, g);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float gg = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+                s1[i] += gg;
+                s2[i] = fmaf(gg, (v[i] - mu[i]) * is[i], s2[i]);
+            }
+        }
+    }
+    float* r1p = red;
+    float* r2p = red + 256 * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            r1p[(ty * TX + tx) * VEC + i] = s1[i];
+            r2p[(ty * TX + tx) * VEC + i] = s2[i];
+        }
+    }
+    __syncthreads();
+    if (ty == 0 && col * VEC < C) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < TY; ++k) {
+                a += r1p[(k * TX + tx) * VEC + i];
+                b += r2p[(k * TX + tx) * VEC + i];
+            }
+            part[((long)blockIdx.y * 2 + 0) * C + col * VEC + i] = a;
+            part[((long)blockIdx.y * 2 + 1) * C + col * VEC + i] = b;
+        }
+    }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dp, const int8_t* __restrict__ arg, const PoolRoute P, const T* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ coef, T* __restrict__ dx, long M, int C,
+                                                                int TX, int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
+    ldc<VEC>(mean + col * VEC, mu);
+    ldc<VEC>(invstd + col * VEC, is);
+    ldc<VEC>(coef + col * VEC, ca);
+    ldc<VEC>(coef + C + col * VEC, cb);
+    ldc<VEC>(coef + 2 * C + col * VEC, cc);
+    ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+    ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sc[i] *= is[i];
+        sh[i] -= mu[i] * sc[i];
+    }
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float g[VEC], v[VEC];
+        ldv<T, VEC>(x + off, v);
+        pool_route_dy<T, VEC>(dp, arg, P, (unsigned)r, C, col, g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float gg = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+            const float xh = (v[i] - mu[i]) * is[i];
+            v[i] = ca[i] * (gg - cb[i] - xh * cc[i]);
+        }
+        stv<T, VEC>(dx + off, v);
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------
 #define BN_TARGET_BLOCKS 1024       /* upper bound of the row blocks (workspace sizing) */
 // row blocks per kernel by element size (same-box A/B of the whole ResNet-50 step: fp32 1024 > 768 > 2048; bf16 768 > 512 ~ 1024)
@@ -825,6 +959,44 @@ extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const ui
     else if (dtype == MCN_F16) return C % 8 == 0 ? bn_bwd_t<f16_t, 8>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st)
                                              : bn_bwd_t<f16_t, 1>(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dskip, dgamma, dbeta, grad_scale, M, C, act, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
+}
+
+template <typename T, int VEC>
+static int bn_bwd_pool_t(const void* dp, const int8_t* arg, const PoolRoute& P, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, long M, int C, void* ws, hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
+    float* part = (float*)ws;
+    float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
+    const dim3 grid(L.gx, L.gy), block(256);
+    hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dp, arg, P, (const T*)x, save_mean, save_invstd, gamma, beta,
+                       part, M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
+                       dbeta, grad_scale, coef, 0);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, VEC>), grid, block, 0, st, (const T*)dp, arg, P, (const T*)x, save_mean, save_invstd, gamma, beta, (const float*)coef, (T*)dx,
+                       M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+// mcn_bn_bwd(act = ReLU, mask recomputed from x) for a BN whose output feeds ONLY a 3x3 / stride-2 max-pool: takes the POOLED
+// gradient dy_pooled [N,OH,OW,C] and the pool's arg-max instead of the full-resolution dy (same result as mcn_maxpool_bwd
+// followed by mcn_bn_bwd, bit for bit in dx; dgamma / dbeta up to fp32 summation order — the same order here).
+extern "C" int mcn_bn_bwd_maxpool(const void* dy_pooled, const int8_t* argmax, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                                  const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    const int64_t M = (int64_t)N * H * W;
+    if (!dy_pooled || !argmax || !x || !dx || !save_mean || !save_invstd || M <= 0 || C <= 0 || OH <= 0 || OW <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd_maxpool: bad argument");
+    if (KH != 3 || KW != 3 || SH != 2 || SW != 2 || padT < 0 || padL < 0 || padT > 2 || padL > 2) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_maxpool: 3x3 / stride-2 pools only");
+    if (M >= 0xffffffffll) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_maxpool: more than 2^32 pixels");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd_maxpool: workspace too small");
+    const PoolRoute P = {H, W, OH, OW, padT, padL};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32 && C % 4 == 0) return bn_bwd_pool_t<float, 4>(dy_pooled, argmax, P, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
+    if (dtype == MCN_BF16 && C % 8 == 0) return bn_bwd_pool_t<bf16_t, 8>(dy_pooled, argmax, P, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
+    if (dtype == MCN_F16 && C % 8 == 0) return bn_bwd_pool_t<f16_t, 8>(dy_pooled, argmax, P, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_maxpool: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
 }
 
 // ---- backward of the frozen-statistics BN (fused_batch_norm(is_training=False) inside a training graph) ----------------

@@ -40,6 +40,7 @@ class Lowering(object):
         self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.fused_pools = set()       # ids of max-pool nodes whose forward runs inside the BN apply pass in front of them
+        self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.scratch = {}
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -541,9 +542,17 @@ class Lowering(object):
                          b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, act, MCN_DT[x.dtype],
                          self.ws_ptr, self.ws_bytes)
 
+        route = self.pool_routes.pop(y.id, None)             # this BN's output gradient is a 3x3 / 2 max-pool's: routed inside the passes
+
         def emit(dst):
             if frozen:
                 return emit_frozen(dst)
+            if route is not None:
+                assert act == _ffi.ACT_RELU and skip is None and yptr == 0 and lazy is None
+                self.bwd.add(lib.mcn_bn_bwd_maxpool, route.outputs[0].grad.data_ptr(), route.attrs['argmax'].data_ptr(), x.buf.data_ptr(), self.vptr(g), self.vptr(b),
+                             st['mean'].data_ptr(), st['invstd'].data_ptr(), dst, g.grad.data_ptr() if g is not None and g.trainable else 0,
+                             b.grad.data_ptr() if b is not None and b.trainable else 0, gs, *(self._pool_args(route) + [MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes]))
+                return
             self.bwd.add(lib.mcn_bn_bwd, dy_ptr, x.buf.data_ptr(), yptr, mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
                          st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,
                          b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C, act, MCN_DT[x.dtype],
@@ -637,6 +646,14 @@ class Lowering(object):
 
     def bwd_maxpool(self, n):
         x, y = n.inputs[0], n.outputs[0]
+        a = n.attrs
+        if (id(n) in self.fused_pools and os.environ.get('MCN_FUSE_BN_POOL', '1') != '2' and x.needs_grad and (a['kh'], a['kw'], a['sh'], a['sw']) == (3, 3, 2, 2)
+                and x.shape[-1] % (4 if x.dtype == 'float32' else 8) == 0 and x.id not in self.written and x.numel // x.shape[-1] < 0xffffffff):
+            # the BN in front (its forward already ran the pool) routes the pooled gradient inside its two backward passes
+            # (mcn_bn_bwd_maxpool): the full-resolution gradient is not written.  MCN_FUSE_BN_POOL=2: forward fusion only.
+            self.written.add(x.id)
+            self.pool_routes[x.id] = n
+            return
         self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_maxpool_bwd, y.grad.data_ptr(), n.attrs['argmax'].data_ptr(), dst,
                                                                 *(self._pool_args(n) + [MCN_DT[x.dtype]])))
 

@@ -891,3 +891,45 @@ def test_bn_relu_maxpool_in_one_pass(case, dtype):
     np.testing.assert_array_equal(a_one.cpu().numpy(), a_ref.cpu().numpy())
     for a, b in zip(s_one, s_ref):
         np.testing.assert_array_equal(u.host(a), u.host(b))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 'SAME'), (3, 9, 11, 16, 'SAME'), (2, 13, 12, 8, 'VALID'), (4, 32, 32, 32, 'SAME')])
+def test_bn_backward_routes_maxpool_gradient(case, dtype):
+    """mcn_bn_bwd_maxpool (BN + ReLU in front of a 3x3 / 2 max-pool: the pooled gradient is routed by arg-max inside the two BN
+    passes) against mcn_maxpool_bwd followed by mcn_bn_bwd: dx, dgamma and dbeta bit for bit."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, c, pad = case
+    x = (1.3 * RNG.standard_normal((n, h, w_, c)) + 0.2).astype(np.float32)
+    gamma = (0.5 + RNG.random(c)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    m = n * h * w_
+    out = u.bn_fwd_train(x, gamma, beta, 1e-3, dtype, act=1)
+    pads = O.resolve_pads(h, w_, 3, 3, 2, 2, pad, 1, 1)
+    oh, ow = O.out_size(h, 3, 2, pad, 1), O.out_size(w_, 3, 2, pad, 1)
+    xd, gd, bd = u.dev(x, dtype), u.dev(gamma), u.dev(beta)
+    yd = u.dev(out['y'], dtype)
+    sm, si = u.dev(out['save_mean']), u.dev(out['save_invstd'])
+    pooled = torch.empty((n, oh, ow, c), dtype=u.TDT[dtype], device=u.DEV)
+    arg = torch.empty((n, oh, ow, c), dtype=torch.int8, device=u.DEV)
+    _ffi.check(lib.mcn_maxpool_fwd(yd.data_ptr(), pooled.data_ptr(), arg.data_ptr(), n, h, w_, c, 3, 3, 2, 2, pads[0], pads[2], oh, ow, u.MDT[dtype], u.stream()))
+    dp = u.dev(RNG.standard_normal((n, oh, ow, c)).astype(np.float32), dtype)
+    ws = u.workspace(lib.mcn_bn_workspace_bytes(m, c))
+    # two steps
+    dy = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_maxpool_bwd(dp.data_ptr(), arg.data_ptr(), dy.data_ptr(), n, h, w_, c, 3, 3, 2, 2, pads[0], pads[2], oh, ow, u.MDT[dtype], u.stream()))
+    dx_ref = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg_ref, db_ref = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
+    _ffi.check(lib.mcn_bn_bwd(dy.data_ptr(), xd.data_ptr(), 0, 0, gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dx_ref.data_ptr(), 0, dg_ref.data_ptr(), db_ref.data_ptr(),
+                              0.5, m, c, 1, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, u.stream()))
+    # routed
+    dx = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg, db = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
+    _ffi.check(lib.mcn_bn_bwd_maxpool(dp.data_ptr(), arg.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                      0.5, n, h, w_, c, 3, 3, 2, 2, pads[0], pads[2], oh, ow, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, u.stream()))
+    np.testing.assert_array_equal(u.host(dx), u.host(dx_ref))
+    np.testing.assert_array_equal(u.host(dg), u.host(dg_ref))
+    np.testing.assert_array_equal(u.host(db), u.host(db_ref))
+    assert np.abs(u.host(dx)).max() > 0
