@@ -195,6 +195,21 @@ int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t n
                            int64_t M, int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Residual unit with a projection shortcut, y = relu(bn(x) + bn_s(xs)) (models/resnet_v1_5.py:63-75): the shortcut's BN needs
+ * no apply pass of its own — mcn_bn_fwd_train_fused_stats finalizes its statistics (saved / batch / running values as
+ * mcn_bn_fwd_train_fused) and leaves its affine in scale_shift [2][C] (caller-owned), mcn_bn_fwd_train_fused_affskip is
+ * mcn_bn_fwd_train_fused(act = ReLU) taking the shortcut conv's raw output xs and that affine as the residual.  Same y and ReLU mask,
+ * bit for bit, as applying the shortcut BN to a tensor first; that tensor is never written. */
+int mcn_bn_fwd_train_fused_stats(const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta,
+                                 float* save_mean, float* save_invstd, float* batch_mean, float* batch_var, float* running_mean,
+                                 float* running_var, float momentum, int64_t M, int32_t C, float eps, float* scale_shift, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int mcn_bn_fwd_train_fused_affskip(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma,
+                                   const float* beta, const void* skip_x, const float* skip_scale_shift, void* y, uint8_t* relu_mask,
+                                   float* save_mean, float* save_invstd, float* batch_mean, float* batch_var, float* running_mean,
+                                   float* running_var, float momentum, int64_t M, int32_t C, float eps, mcn_dtype dtype, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* conv -> BN(train) -> ReLU -> max-pool (the stem of models/resnet_v1_5.py:25-31) with the statistics from the conv epilogue: the
  * finalize step of mcn_bn_fwd_train_fused, then ONE pass that normalises, rectifies and pools x [N,H,W,C] into pooled
  * [N,OH,OW,C] + argmax (same values, ties and arg-max as mcn_bn_fwd_train_fused followed by mcn_maxpool_fwd; the normalised

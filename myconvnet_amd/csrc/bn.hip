@@ -259,6 +259,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// y = relu(x*scale + shift + round_T(xs*sscale + sshift)): the residual unit with a projection shortcut (conv -> BN on the skip
+// path).  The skip branch's BN apply pass is folded in: its normalised tensor, rounded to the storage type exactly as the stored
+// one would have been, is formed here from the shortcut conv's raw output and never written or read.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_apply_affskip_kernel(const T* __restrict__ x, const T* __restrict__ xs, T* __restrict__ y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ sscale, const float* __restrict__ sshift,
+                                                               long M, int C, int TX, int TY, long rpb, unsigned char* __restrict__ mask) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float sc[VEC], sh[VEC], ssc[VEC], ssh[VEC];
+    ldc<VEC>(scale + col * VEC, sc);
+    ldc<VEC>(shift + col * VEC, sh);
+    ldc<VEC>(sscale + col * VEC, ssc);
+    ldc<VEC>(sshift + col * VEC, ssh);
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float v[VEC], s[VEC];
+        ldv<T, VEC>(x + off, v);
+        ldv<T, VEC>(xs + off, s);
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float o = fmaf(v[i], sc[i], sh[i]) + to_f32(from_f32<T>(fmaf(s[i], ssc[i], ssh[i])));
+            bits |= (o > 0.f ? 1u : 0u) << i;
+            v[i] = fmaxf(o, 0.f);
+        }
+        stv<T, VEC>(y + off, v);
+        if (VEC > 1 && mask) mask[r * (C / VEC) + col] = (unsigned char)bits;
+    }
+}
+
 // ---- backward --------------------------------------------------------------------------------------
 __device__ __forceinline__ float swish_grad(float z) {
     const float sg = fast_sigmoid(z);
@@ -738,9 +771,9 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
 // statistics from the conv-epilogue partials + (scale, shift) in the workspace; returns them through the out-pointers
 static int bn_fused_finalize(const float* parts, int nparts, int rpp, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* batch_mean,
                              float* batch_var, float* running_mean, float* running_var, float momentum, long M, int C, float eps, void* ws, hipStream_t st,
-                             float** scale_out, float** shift_out) {
+                             float** scale_out, float** shift_out, float* dst = nullptr) {
     double* fold = (double*)ws;
-    float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
+    float* scale = dst ? dst : (float*)((char*)ws + bn_parts_bytes(M, C));         // dst: caller-owned [2][C] that outlives the workspace's next user
     float* shift = scale + C;
     const dim3 fgrid((C + FIN_CH - 1) / FIN_CH), fblock(FIN_CH * FIN_LANES);
     if (nparts > BN_FOLD_ROWS) {
@@ -781,6 +814,48 @@ extern "C" int mcn_bn_fwd_train_fused_maxpool(const void* x, const float* stats_
                                    (long)M, C, eps, ws, (hipStream_t)stream, &scale, &shift))
         return rc;
     return mcn_maxpool_fwd_affine_relu(x, scale, shift, pooled, argmax, N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW, dtype, stream);
+}
+
+// statistics of a training-mode BN from the conv-epilogue partials WITHOUT the apply pass: saved / batch / running statistics and
+// the affine (scale = gamma*invstd, shift = beta - mean*scale) into scale_shift [2][C] (caller-owned) for a consumer that folds
+// the normalisation into its own pass (mcn_bn_fwd_train_fused_affskip)
+extern "C" int mcn_bn_fwd_train_fused_stats(const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta, float* save_mean,
+                                            float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum,
+                                            int64_t M, int32_t C, float eps, float* scale_shift, void* ws, size_t ws_bytes, void* stream) {
+    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_stats: partials do not cover M rows");
+    if (!stats_partials || nparts <= 0 || !save_mean || !save_invstd || !scale_shift || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_stats: bad argument");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused_stats: workspace too small");
+    float *sc, *sh;
+    return bn_fused_finalize(stats_partials, nparts, rows_per_partial, gamma, beta, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, (long)M, C,
+                             eps, ws, (hipStream_t)stream, &sc, &sh, scale_shift);
+}
+// y = relu(bn(x) + bn_s(xs)): mcn_bn_fwd_train_fused(act = ReLU) whose residual input is the OUTPUT of another training-mode BN given
+// as that BN's input xs and affine skip_scale_shift [2][C] (from mcn_bn_fwd_train_fused_stats) — same y, bit for bit, as applying
+// the skip BN to a tensor first
+extern "C" int mcn_bn_fwd_train_fused_affskip(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta,
+                                              const void* skip_x, const float* skip_scale_shift, void* y, uint8_t* relu_mask, float* save_mean, float* save_invstd,
+                                              float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum, int64_t M, int32_t C,
+                                              float eps, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_affskip: partials do not cover M rows");
+    if (!x || !y || !skip_x || !skip_scale_shift || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_affskip: bad argument");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused_affskip: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *scale, *shift;
+    if (int rc = bn_fused_finalize(stats_partials, nparts, rows_per_partial, gamma, beta, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, (long)M, C,
+                                   eps, ws, st, &scale, &shift))
+        return rc;
+    const int vec = dtype == MCN_F32 ? 4 : 8;
+    if (!mcn_dtype_ok(dtype) || C % vec) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_fused_affskip: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
+    const ColLayout L = make_layout((long)M, C, vec, dtype == MCN_F32 ? bn_target<float>() : bn_target<bf16_t>());
+    const dim3 grid(L.gx, L.gy), block(256);
+#define BN_AFFSKIP(TT, VV) hipLaunchKernelGGL((bn_apply_affskip_kernel<TT, VV>), grid, block, 0, st, (const TT*)x, (const TT*)skip_x, (TT*)y, (const float*)scale, (const float*)shift, \
+                                              skip_scale_shift, skip_scale_shift + C, (long)M, C, L.TX, L.TY, L.rpb, relu_mask)
+    if (dtype == MCN_F32) BN_AFFSKIP(float, 4);
+    else if (dtype == MCN_BF16) BN_AFFSKIP(bf16_t, 8);
+    else BN_AFFSKIP(f16_t, 8);
+#undef BN_AFFSKIP
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
 }
 
 extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta,

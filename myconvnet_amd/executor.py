@@ -41,6 +41,7 @@ class Lowering(object):
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.fused_pools = set()       # ids of max-pool nodes whose forward runs inside the BN apply pass in front of them
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
+        self.aff_skips = {}            # shortcut-BN output tensor id -> (its input tensor, its affine [2][C]): applied by the consumer BN
         self.scratch = {}
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -224,13 +225,15 @@ class Lowering(object):
             gm.tile = best
             chosen[id(gm)] = best
         for fn, args in self.fwd.calls:                     # the partial-row count of a fused conv -> BN pair follows the tile
-            if getattr(fn, '__name__', '') in ('mcn_bn_fwd_train_fused', 'mcn_bn_fwd_train_fused_maxpool'):
+            name = getattr(fn, '__name__', '')
+            if name in ('mcn_bn_fwd_train_fused', 'mcn_bn_fwd_train_fused_maxpool', 'mcn_bn_fwd_train_fused_affskip', 'mcn_bn_fwd_train_fused_stats'):
+                ip = 0 if name == 'mcn_bn_fwd_train_fused_stats' else 1          # position of (partials, rows, rows_per_partial) in the call
                 for nd in self.g.nodes:
                     fs = nd.attrs.get('fused_stats') if nd.op == 'bn' else None
-                    if fs is not None and fs[0].data_ptr() == args[1]:
+                    if fs is not None and fs[0].data_ptr() == args[ip]:
                         rpp = ctypes.c_int32(0)
-                        args[2] = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(fs[1]), self.dt, ctypes.byref(rpp)))
-                        args[3] = rpp.value
+                        args[ip + 1] = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(fs[1]), self.dt, ctypes.byref(rpp)))
+                        args[ip + 2] = rpp.value
         return chosen
 
     # ---- input / labels ---------------------------------------------------------------------------------
@@ -450,6 +453,23 @@ class Lowering(object):
                 part, gm = a['fused_stats']
                 rpp = ctypes.c_int32(0)
                 rows = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(gm), self.dt, ctypes.byref(rpp)))
+                aff = self.aff_skips.get(skip.id) if skip is not None else None
+                if aff is not None:
+                    # residual input = the output of a shortcut BN that ran statistics-only: fold its apply pass into this one
+                    assert a.get('act', 0) == _ffi.ACT_RELU
+                    self.fwd.add(lib.mcn_bn_fwd_train_fused_affskip, x.buf.data_ptr(), part.data_ptr(), rows, rpp.value, self.vptr(a['gamma']), self.vptr(a['beta']),
+                                 aff[0].buf.data_ptr(), aff[1].data_ptr(), y.buf.data_ptr(), mask_ptr, st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(),
+                                 st['bvar'].data_ptr(), a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
+                                 float(a['momentum']), M, C, float(a['eps']), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+                    return
+                if self._affine_consumer(n) is not None:
+                    if 'aff_out' not in a:
+                        a['aff_out'] = torch.zeros(2 * C, dtype=torch.float32, device=self.g.device)
+                    self.aff_skips[y.id] = (x, a['aff_out'])
+                    self.fwd.add(lib.mcn_bn_fwd_train_fused_stats, part.data_ptr(), rows, rpp.value, self.vptr(a['gamma']), self.vptr(a['beta']), st['mean'].data_ptr(),
+                                 st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(), a['mu'].data.data_ptr() if single else 0,
+                                 a['sigma'].data.data_ptr() if single else 0, float(a['momentum']), M, C, float(a['eps']), a['aff_out'].data_ptr(), self.ws_ptr, self.ws_bytes)
+                    return
                 pool = self._pool_consumer(n)
                 if pool is not None:
                     # conv -> BN -> ReLU -> max-pool (the stem): finalize, then one pass that normalises, rectifies and pools; y is never
@@ -624,6 +644,30 @@ class Lowering(object):
         a = n.attrs
         N, H, W, C = x.shape
         return [N, H, W, C, a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl'], y.shape[1], y.shape[2]]
+
+    def _stats_fusable(self, bn):
+        """will fwd_conv accumulate this training-mode BN's statistics in its producer's epilogue?"""
+        x = bn.inputs[0]
+        prod = x.producer
+        if prod is None or prod.op != 'conv' or self._bn_consumer(prod) is not bn or x.shape[-1] % (4 if self.g.dtype == 'float32' else 8):
+            return False
+        return int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(self.op_geom(prod, _ffi.CONV_FWD)), self.dt, None)) > 0
+
+    def _affine_consumer(self, n):
+        """projection shortcut: this training-mode BN (no activation, no residual) feeds ONLY the residual input of another
+        training-mode BN + ReLU whose statistics also come from a conv epilogue -> that BN folds this one's apply pass into its own
+        (mcn_bn_fwd_train_fused_stats / _affskip); returns it, or None.  MCN_FUSE_BN_SKIP=0 switches it off."""
+        if os.environ.get('MCN_FUSE_BN_SKIP', '1') == '0' or not self.train:
+            return None
+        a, y = n.attrs, n.outputs[0]
+        if a.get('act', 0) or a.get('skip') is not None or len(y.consumers) != 1:
+            return None
+        m = y.consumers[0]
+        if m.op != 'bn' or m.attrs.get('skip') is not y or m.inputs[0] is y or m.attrs.get('act', 0) != _ffi.ACT_RELU or not m.attrs.get('update'):
+            return None
+        if y.shape != m.inputs[0].shape or not self._stats_fusable(m) or m not in self.g.nodes or self.g.nodes.index(m) < self.g.nodes.index(n):
+            return None
+        return m
 
     def _pool_consumer(self, n):
         """the max-pool node that is the only reader of this training-mode BN + ReLU's output (folded into the BN apply pass), or None"""

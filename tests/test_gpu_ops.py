@@ -933,3 +933,65 @@ def test_bn_backward_routes_maxpool_gradient(case, dtype):
     np.testing.assert_array_equal(u.host(dg), u.host(dg_ref))
     np.testing.assert_array_equal(u.host(db), u.host(db_ref))
     assert np.abs(u.host(dx)).max() > 0
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 8, 8, 64), (3, 7, 5, 24), (4, 14, 14, 256)])
+def test_projection_shortcut_bn_folded_into_consumer(shape, dtype):
+    """y = relu(bn(x) + bn_s(xs)) with the shortcut BN run statistics-only (mcn_bn_fwd_train_fused_stats) and applied inside the main
+    BN's pass (mcn_bn_fwd_train_fused_affskip) against the two full calls: y, ReLU mask and all statistics bit for bit."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, c = shape
+    m = n * h * w_
+    cin = 16
+    xin = (RNG.standard_normal((n, h, w_, cin)) + 0.3).astype(np.float32)
+    w1 = (RNG.standard_normal((1, 1, cin, c)) / 4).astype(np.float32)
+    w2 = (RNG.standard_normal((1, 1, cin, c)) / 4 + 0.05).astype(np.float32)
+    g = u.geom(xin.shape, w1.shape, 1, 'SAME')
+    rpp = ctypes.c_int32(0)
+    rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT[dtype], ctypes.byref(rpp))
+    assert rows > 0
+    xd = u.dev(xin, dtype)
+    ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]))
+
+    def conv(wt):
+        y = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        part = torch.full((rows, 4, c), float('nan'), dtype=torch.float32, device=u.DEV)
+        wd = u.dev(wt)
+        _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
+                                              ws.data_ptr(), ws.numel() * 4, u.stream()))
+        return y, part
+    x, px = conv(w1)
+    xs, ps = conv(w2)
+    gm, bm = u.dev((0.5 + RNG.random(c)).astype(np.float32)), u.dev((0.3 * RNG.standard_normal(c)).astype(np.float32))
+    gs, bs = u.dev((0.5 + RNG.random(c)).astype(np.float32)), u.dev((0.3 * RNG.standard_normal(c)).astype(np.float32))
+    bws = u.workspace(lib.mcn_bn_workspace_bytes(m, c))
+    nb = max(int(lib.mcn_bn_relu_mask_bytes(m, c, u.MDT[dtype])), 1)
+
+    def stats():
+        return [torch.zeros(c, dtype=torch.float32, device=u.DEV) for _ in range(4)] + [torch.zeros(c, dtype=torch.float32, device=u.DEV), torch.ones(c, dtype=torch.float32, device=u.DEV)]
+    # reference: shortcut BN to a tensor, then the main BN with that tensor as residual
+    st_s, st_m = stats(), stats()
+    s_t = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_train_fused(xs.data_ptr(), ps.data_ptr(), rows, rpp.value, gs.data_ptr(), bs.data_ptr(), 0, s_t.data_ptr(), 0, *[t.data_ptr() for t in st_s],
+                                          0.99, m, c, 1e-3, 0, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, u.stream()))
+    y_ref = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    k_ref = torch.full((nb,), 0xAA, dtype=torch.uint8, device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_train_fused(x.data_ptr(), px.data_ptr(), rows, rpp.value, gm.data_ptr(), bm.data_ptr(), s_t.data_ptr(), y_ref.data_ptr(), k_ref.data_ptr(),
+                                          *[t.data_ptr() for t in st_m], 0.99, m, c, 1e-3, 1, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, u.stream()))
+    # folded
+    st_s2, st_m2 = stats(), stats()
+    aff = torch.full((2 * c,), float('nan'), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_train_fused_stats(ps.data_ptr(), rows, rpp.value, gs.data_ptr(), bs.data_ptr(), *[t.data_ptr() for t in st_s2], 0.99, m, c, 1e-3, aff.data_ptr(),
+                                                bws.data_ptr(), bws.numel() * 4, u.stream()))
+    y = torch.full((n, h, w_, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    k = torch.full((nb,), 0xAA, dtype=torch.uint8, device=u.DEV)
+    _ffi.check(lib.mcn_bn_fwd_train_fused_affskip(x.data_ptr(), px.data_ptr(), rows, rpp.value, gm.data_ptr(), bm.data_ptr(), xs.data_ptr(), aff.data_ptr(), y.data_ptr(), k.data_ptr(),
+                                                  *[t.data_ptr() for t in st_m2], 0.99, m, c, 1e-3, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, u.stream()))
+    np.testing.assert_array_equal(u.host(y), u.host(y_ref))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(k.cpu().numpy(), k_ref.cpu().numpy())
+    for a, b in zip(st_s2 + st_m2, st_s + st_m):
+        np.testing.assert_array_equal(u.host(a), u.host(b))
