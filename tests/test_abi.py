@@ -83,3 +83,24 @@ def test_missing_library_fails_loudly(tmp_path):
     from myconvnet_amd import _ffi
     with pytest.raises(ImportError, match='no CPU fallback'):
         _ffi.load(str(tmp_path / 'libmcn_hip.so'))
+
+
+def test_pixel_pair_geometry_without_gpu():
+    """mcn_conv2d_pair_geom (no launch): the stride-2 stem on <= 4 channels in a 2-byte type becomes a stride-(SH,1) conv of the
+    [N,H,W/2,8] view; fp32, odd widths, wide inputs and stride-1 convs have no such form."""
+    import ctypes
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    g = _ffi.conv_geom(256, 224, 224, 3, 64, 7, 7, 2, 2, 1, 1, (2, 3, 2, 3), 4)              # ResNet stem, TF SAME pads
+    pg = _ffi.ConvGeom()
+    assert lib.mcn_conv2d_pair_geom(ctypes.byref(g), _ffi.BF16, ctypes.byref(pg)) == 1
+    assert (pg.N, pg.H, pg.W, pg.Cin, pg.Cout, pg.KH, pg.KW, pg.SH, pg.SW, pg.padT, pg.padB, pg.padL, pg.padR, pg.x_cs) == (256, 224, 112, 8, 64, 7, 4, 2, 1, 2, 3, 1, 2, 8)
+    g3 = _ffi.conv_geom(8, 224, 224, 3, 32, 3, 3, 2, 2, 1, 1, (0, 1, 0, 1), 4)               # EfficientNet stem
+    assert lib.mcn_conv2d_pair_geom(ctypes.byref(g3), _ffi.F16, ctypes.byref(pg)) == 1 and (pg.KW, pg.padL, pg.padR, pg.W) == (2, 0, 1, 112)
+    assert lib.mcn_conv2d_pair_geom(ctypes.byref(g), _ffi.F32, ctypes.byref(pg)) == 0        # 4-element chunks: nothing to gain
+    for bad in (_ffi.conv_geom(8, 224, 223, 3, 64, 7, 7, 2, 2, 1, 1, (2, 3, 2, 2), 4),        # odd width
+                _ffi.conv_geom(8, 224, 224, 8, 64, 7, 7, 2, 2, 1, 1, (2, 3, 2, 3), 8),        # more than 4 channels
+                _ffi.conv_geom(8, 224, 224, 3, 64, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1), 4),        # stride 1
+                _ffi.conv_geom(8, 224, 224, 3, 64, 7, 7, 2, 2, 1, 1, (2, 3, 2, 3), 8)):       # image stored 8 channels per pixel
+        assert lib.mcn_conv2d_pair_geom(ctypes.byref(bad), _ffi.BF16, ctypes.byref(pg)) == 0
+    assert lib.mcn_conv2d_pair_weights(0, 0, ctypes.byref(g), _ffi.BF16, 0) == _ffi.E_BADARG
