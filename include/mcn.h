@@ -243,6 +243,16 @@ int mcn_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
                float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* Squeeze-excite backward without the gradient tensor of the block's input (models/efficientnet.py:152-163): x_se (the output of a
+ * BN + swish) is read by the SE branch's global average pool and by y = x_se * m; its gradient round(round(dy*m) + dgap/HW) is
+ * composed inside the BN's two backward passes (mcn_bn_bwd_se; dy = gradient of y, se_mask = m [N,C], dgap [N,C] = gradient of the
+ * pooled tensor), mcn_channel_scale_bwd_dm is the reduction half of mcn_channel_scale_bwd (dm[n,c] = sum_hw dy * x_se).  Bit-identical
+ * to mcn_channel_scale_bwd + mcn_global_avgpool_bwd_acc + mcn_bn_bwd(act = swish). */
+int mcn_channel_scale_bwd_dm(const void* dy, const void* x, void* dm, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream);
+int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                  const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C,
+                  mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* mcn_bn_bwd(act = ReLU, no fused residual) for a BN whose output feeds ONLY a 3x3 / stride-2 max-pool (the stem): takes the
  * pooled gradient [N,OH,OW,C] and the pool's arg-max and routes it inside its two passes; the full-resolution gradient of the BN
  * output (the largest gradient tensor of the network) is never written.  Same dx as mcn_maxpool_bwd + mcn_bn_bwd, bit for bit. */

@@ -596,6 +596,119 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restr
     }
 }
 
+// ---- backward of BN + swish whose output x_se feeds a squeeze-excite block (models/efficientnet.py:152-163) --------------------
+// x_se has two readers, the global average pool of the SE branch and the channel scale y = x_se * m[n,c]; its gradient is
+//   g = round_T(round_T(dy * m[n,c]) + dgap[n,c] / HW)
+// (what mcn_channel_scale_bwd writes, then mcn_global_avgpool_bwd_acc adds to).  Both BN passes form g themselves from the gradient
+// of the scaled tensor, the SE mask and the pooled branch's gradient: the channel-scale backward keeps only its reduction
+// (mcn_channel_scale_bwd_dm) and the gradient tensor of x_se — three passes over the widest activations of the network — is gone.
+template <typename T, int VEC>
+__device__ __forceinline__ void se_route_dy(const T* __restrict__ dy, const T* __restrict__ m, const T* __restrict__ dgap, long off, long nc, float inv_hw, float (&g)[VEC]) {
+    float mm[VEC], q[VEC];
+    ldv<T, VEC>(dy + off, g);
+    ldv<T, VEC>(m + nc, mm);
+    ldv<T, VEC>(dgap + nc, q);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = to_f32(from_f32<T>(fmaf(q[i], inv_hw, to_f32(from_f32<T>(g[i] * mm[i])))));      // (explicit fma: as gap_bwd_kernel<ACC>)
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_se_kernel(const T* __restrict__ dy, const T* __restrict__ m, const T* __restrict__ dgap, long HW, const T* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ part, long M, int C, int TX, int TY, long rpb) {
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const bool active = ty < TY && col * VEC < C;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+        ldc<VEC>(mean + col * VEC, mu);
+        ldc<VEC>(invstd + col * VEC, is);
+        ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+        ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] *= is[i];
+            sh[i] -= mu[i] * sc[i];
+        }
+        const float inv_hw = 1.f / (float)HW;
+        const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+        for (long r = r0 + ty; r < r1; r += TY) {
+            const long off = r * C + (long)col * VEC;
+            float g[VEC], v[VEC];
+            ldv<T, VEC>(x + off, v);
+            se_route_dy<T, VEC>(dy, m, dgap, off, (long)((unsigned)r / (unsigned)HW) * C + (long)col * VEC, inv_hw, g);       // (32-bit division: the host checks M < 2^32)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float gg = g[i] * swish_grad(fmaf(v[i], sc[i], sh[i]));
+                s1[i] += gg;
+                s2[i] = fmaf(gg, (v[i] - mu[i]) * is[i], s2[i]);
+            }
+        }
+    }
+    float* r1p = red;
+    float* r2p = red + 256 * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            r1p[(ty * TX + tx) * VEC + i] = s1[i];
+            r2p[(ty * TX + tx) * VEC + i] = s2[i];
+        }
+    }
+    __syncthreads();
+    if (ty == 0 && col * VEC < C) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < TY; ++k) {
+                a += r1p[(k * TX + tx) * VEC + i];
+                b += r2p[(k * TX + tx) * VEC + i];
+            }
+            part[((long)blockIdx.y * 2 + 0) * C + col * VEC + i] = a;
+            part[((long)blockIdx.y * 2 + 1) * C + col * VEC + i] = b;
+        }
+    }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restrict__ dy, const T* __restrict__ m, const T* __restrict__ dgap, long HW, const T* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ coef, T* __restrict__ dx, long M, int C, int TX,
+                                                              int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
+    ldc<VEC>(mean + col * VEC, mu);
+    ldc<VEC>(invstd + col * VEC, is);
+    ldc<VEC>(coef + col * VEC, ca);
+    ldc<VEC>(coef + C + col * VEC, cb);
+    ldc<VEC>(coef + 2 * C + col * VEC, cc);
+    ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+    ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sc[i] *= is[i];
+        sh[i] -= mu[i] * sc[i];
+    }
+    const float inv_hw = 1.f / (float)HW;
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float g[VEC], v[VEC];
+        ldv<T, VEC>(x + off, v);
+        se_route_dy<T, VEC>(dy, m, dgap, off, (long)((unsigned)r / (unsigned)HW) * C + (long)col * VEC, inv_hw, g);       // (32-bit division: the host checks M < 2^32)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float gg = g[i] * swish_grad(fmaf(v[i], sc[i], sh[i]));
+            const float xh = (v[i] - mu[i]) * is[i];
+            v[i] = ca[i] * (gg - cb[i] - xh * cc[i]);
+        }
+        stv<T, VEC>(dx + off, v);
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------
 #define BN_TARGET_BLOCKS 1024       /* upper bound of the row blocks (workspace sizing) */
 // row blocks per kernel by element size (same-box A/B of the whole ResNet-50 step: fp32 1024 > 768 > 2048; bf16 768 > 512 ~ 1024)
@@ -1072,6 +1185,41 @@ extern "C" int mcn_bn_bwd_maxpool(const void* dy_pooled, const int8_t* argmax, c
     if (dtype == MCN_BF16 && C % 8 == 0) return bn_bwd_pool_t<bf16_t, 8>(dy_pooled, argmax, P, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
     if (dtype == MCN_F16 && C % 8 == 0) return bn_bwd_pool_t<f16_t, 8>(dy_pooled, argmax, P, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_maxpool: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
+}
+
+template <typename T, int VEC>
+static int bn_bwd_se_t(const void* dy, const void* m, const void* dgap, long HW, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, long M, int C, void* ws, hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
+    float* part = (float*)ws;
+    float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
+    const dim3 grid(L.gx, L.gy), block(256);
+    hipLaunchKernelGGL((bn_bwd_reduce_se_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)m, (const T*)dgap, HW, (const T*)x, save_mean,
+                       save_invstd, gamma, beta, part, M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
+                       dbeta, grad_scale, coef, 0);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_bwd_apply_se_kernel<T, VEC>), grid, block, 0, st, (const T*)dy, (const T*)m, (const T*)dgap, HW, (const T*)x, save_mean, save_invstd, gamma, beta,
+                       (const float*)coef, (T*)dx, M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+// mcn_bn_bwd(act = swish) for the BN in front of a squeeze-excite block: dy is the gradient of the SCALED tensor, se_mask [N,C] the SE
+// factors, dgap [N,C] the gradient of the SE branch's global average pool; the gradient of the BN's output is composed inside the
+// two passes (bit-identical to mcn_channel_scale_bwd + mcn_global_avgpool_bwd_acc + mcn_bn_bwd)
+extern "C" int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype,
+                             void* ws, size_t ws_bytes, void* stream) {
+    const int64_t M = (int64_t)N * HW;
+    if (!dy || !se_mask || !dgap || !x || !dx || !save_mean || !save_invstd || N <= 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd_se: bad argument");
+    if (M >= 0xffffffffll) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se: more than 2^32 pixels");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd_se: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32 && C % 4 == 0) return bn_bwd_se_t<float, 4>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
+    if (dtype == MCN_BF16 && C % 8 == 0) return bn_bwd_se_t<bf16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
+    if (dtype == MCN_F16 && C % 8 == 0) return bn_bwd_se_t<f16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
 }
 
 // ---- backward of the frozen-statistics BN (fused_batch_norm(is_training=False) inside a training graph) ----------------

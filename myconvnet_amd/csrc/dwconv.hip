@@ -1350,6 +1350,60 @@ __global__ __launch_bounds__(256) void chscale_bwd_kernel(const T* __restrict__ 
         store_chunk<T>(dm + (n * cch + chunk) * CE, o);
     }
 }
+// dm only (the dx half of chscale_bwd_kernel is composed inside the BN backward: mcn_bn_bwd_se)
+template <typename T>
+__global__ __launch_bounds__(256) void chscale_bwd_dm_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dm, long HW, int C, int TX, int TY) {
+    constexpr int CE = VecTraits<T>::CE;
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int cch = C / CE;
+    const int chunk = blockIdx.x * TX + tx;
+    const long n = blockIdx.y;
+    const bool active = ty < TY && chunk < cch;
+    float acc[CE];
+#pragma unroll
+    for (int i = 0; i < CE; ++i) acc[i] = 0.f;
+    if (active) {
+        for (long r = ty; r < HW; r += TY) {
+            const long off = ((n * HW + r) * cch + chunk) * CE;
+            const Chunk<T> g = load_chunk<T>(dy + off), v = load_chunk<T>(x + off);
+#pragma unroll
+            for (int i = 0; i < CE; ++i) acc[i] = fmaf(g.get(i), v.get(i), acc[i]);
+        }
+    }
+    const int cols = TX * CE;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < CE; ++i) red[ty * cols + tx * CE + i] = acc[i];
+    }
+    __syncthreads();
+    if (ty == 0 && chunk < cch) {
+        Chunk<T> o;
+#pragma unroll
+        for (int i = 0; i < CE; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < TY; ++k) s += red[k * cols + tx * CE + i];
+            o.set(i, s);
+        }
+        store_chunk<T>(dm + (n * cch + chunk) * CE, o);
+    }
+}
+extern "C" int mcn_channel_scale_bwd_dm(const void* dy, const void* x, void* dm, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream) {
+    if (!dy || !x || !dm || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_bwd_dm: bad argument");
+    if (!mcn_dtype_ok(dtype)) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd_dm: dtype %d unsupported", (int)dtype);
+    const int ce = dtype == MCN_F32 ? 4 : 8;
+    if (C % ce) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd_dm: C=%d must be a multiple of the 16-byte chunk", C);
+    if (N == 0) return MCN_OK;
+    const int cch = C / ce;
+    const int TX = best_tx(cch, 32), TY = 256 / TX;
+    const dim3 grid((unsigned)((cch + TX - 1) / TX), (unsigned)N), block(256);
+    const size_t lds = (size_t)TY * TX * ce * sizeof(float);
+    if (dtype == MCN_F32) hipLaunchKernelGGL((chscale_bwd_dm_kernel<float>), grid, block, lds, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dm, (long)HW, C, TX, TY);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((chscale_bwd_dm_kernel<f16_t>), grid, block, lds, (hipStream_t)stream, (const f16_t*)dy, (const f16_t*)x, (f16_t*)dm, (long)HW, C, TX, TY);
+    else hipLaunchKernelGGL((chscale_bwd_dm_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dm, (long)HW, C, TX, TY);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
 extern "C" int mcn_channel_scale_bwd(const void* dy, const void* x, const void* m, void* dx, void* dm, int32_t N, int64_t HW, int32_t C,
                                      mcn_dtype dtype, void* stream) {
     if (!dy || !x || !m || !dx || !dm || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_bwd: bad argument");

@@ -281,13 +281,14 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const T* __restrict__ dy, 
         const long n = pq / HW;
         float g[VEC];
         pld<T, VEC>(dy + n * C + c, g);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) g[i] *= inv;
         if (ACC) {                                               // dx += : the second gradient contribution of an SE block's input
             float o[VEC];
             pld<T, VEC>(dx + pq * C + c, o);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) g[i] += o[i];
+            for (int i = 0; i < VEC; ++i) g[i] = fmaf(g[i], inv, o[i]);       // (explicit fma: mcn_bn_bwd_se composes the same value)
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) g[i] *= inv;
         }
         pst<T, VEC>(dx + pq * C + c, g);
     }

@@ -41,6 +41,7 @@ class Lowering(object):
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.fused_pools = set()       # ids of max-pool nodes whose forward runs inside the BN apply pass in front of them
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
+        self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
         self.aff_skips = {}            # shortcut-BN output tensor id -> (its input tensor, its affine [2][C]): applied by the consumer BN
         self.scratch = {}
 
@@ -380,11 +381,41 @@ class Lowering(object):
         N, H, W, C = x.shape
         self.fwd.add(lib.mcn_channel_scale_fwd, x.buf.data_ptr(), m.buf.data_ptr(), y.buf.data_ptr(), N, H * W, C, MCN_DT[x.dtype])
 
+    def _se_route(self, n):
+        """squeeze-excite pattern around this channel scale: its input x is the output of a training-mode BN + swish and is read only by
+        the SE branch's global average pool and by this node -> x's gradient is composed inside that BN's backward passes
+        (mcn_bn_bwd_se) and never written.  Returns the pool node or None.  MCN_FUSE_SE=0 switches it off."""
+        x, m = n.inputs[0], n.inputs[1]
+        if os.environ.get('MCN_FUSE_SE', '1') == '0' or not self.train or not x.needs_grad or not m.needs_grad or x.id in self.written:
+            return None
+        bn = x.producer
+        if bn is None or bn.op != 'bn' or bn.attrs.get('act', 0) != _ffi.ACT_SWISH or not bn.attrs.get('update') or bn.attrs.get('skip') is not None:
+            return None
+        others = [c for c in x.consumers if c is not n]
+        if len(others) != 1 or others[0].op != 'gap' or len(x.shape) != 4 or x.shape[-1] % (4 if x.dtype == 'float32' else 8):
+            return None
+        return others[0]
+
     def bwd_chscale(self, n):
         x, m, y = n.inputs[0], n.inputs[1], n.outputs[0]
         N, H, W, C = x.shape
         dt = MCN_DT[x.dtype]
         post = []
+        gap = self._se_route(n)
+        if gap is not None:
+            # reduction half only; the BN in front composes round(round(dy * m) + dgap / HW) itself (bwd_gap adds its part of the route)
+            if m.id not in self.written:
+                self.written.add(m.id)
+                dm = m.grad.data_ptr()
+            else:
+                sc = self.scratch_like(m, 'chscale_dm')
+                dm = sc.data_ptr()
+                post.append((m.grad.data_ptr(), sc.data_ptr(), m.grad.numel(), MCN_DT[m.dtype]))
+            self.bwd.add(lib.mcn_channel_scale_bwd_dm, y.grad.data_ptr(), x.buf.data_ptr(), dm, N, H * W, C, dt)
+            for a in post:
+                self.bwd.add(lib.mcn_accumulate, *a)
+            self.se_routes[x.id] = {'dy': y.grad.data_ptr(), 'm': m.buf.data_ptr(), 'gap': gap}
+            return
 
         def target(t, key):
             if t.id not in self.written:
@@ -563,10 +594,18 @@ class Lowering(object):
                          self.ws_ptr, self.ws_bytes)
 
         route = self.pool_routes.pop(y.id, None)             # this BN's output gradient is a 3x3 / 2 max-pool's: routed inside the passes
+        se = self.se_routes.pop(y.id, None)                  # ... or a squeeze-excite block's (channel scale + pooled branch)
 
         def emit(dst):
             if frozen:
                 return emit_frozen(dst)
+            if se is not None:
+                assert act == _ffi.ACT_SWISH and skip is None and lazy is None and 'dgap' in se
+                N_, HW_ = x.shape[0], M // x.shape[0]
+                self.bwd.add(lib.mcn_bn_bwd_se, se['dy'], se['m'], se['dgap'], x.buf.data_ptr(), self.vptr(g), self.vptr(b), st['mean'].data_ptr(), st['invstd'].data_ptr(),
+                             dst, g.grad.data_ptr() if g is not None and g.trainable else 0, b.grad.data_ptr() if b is not None and b.trainable else 0, gs,
+                             N_, HW_, C, MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+                return
             if route is not None:
                 assert act == _ffi.ACT_RELU and skip is None and yptr == 0 and lazy is None
                 self.bwd.add(lib.mcn_bn_bwd_maxpool, route.outputs[0].grad.data_ptr(), route.attrs['argmax'].data_ptr(), x.buf.data_ptr(), self.vptr(g), self.vptr(b),
@@ -717,6 +756,11 @@ class Lowering(object):
     def bwd_gap(self, n):
         x, y = n.inputs[0], n.outputs[0]
         N, H, W, C = x.shape
+        r = self.se_routes.get(x.id)
+        if r is not None and r['gap'] is n:                 # squeeze-excite route: the BN backward reads this pooled gradient directly
+            r['dgap'] = y.grad.data_ptr()
+            self.written.add(x.id)
+            return
         # (accumulating form when x.grad already holds the channel-scale branch's contribution: no scratch tensor + add pass)
         self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_global_avgpool_bwd_acc if acc else lib.mcn_global_avgpool_bwd, y.grad.data_ptr(), dst,
                                                          N, H * W, C, MCN_DT[x.dtype]))

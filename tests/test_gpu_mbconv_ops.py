@@ -127,3 +127,48 @@ def test_se_channel_scale(shape, dtype):
     dx_ref, dm_ref = O.channel_scale_bwd(dyq, xq, mq)
     check(dx, dx_ref, dtype, 'se dx')
     check(dm, dm_ref, dtype, 'se dm')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 7, 7, 32), (4, 5, 9, 144), (2, 14, 14, 480)])
+def test_bn_backward_composes_squeeze_excite_gradient(shape, dtype):
+    """mcn_bn_bwd_se + mcn_channel_scale_bwd_dm against mcn_channel_scale_bwd + mcn_global_avgpool_bwd_acc + mcn_bn_bwd(swish): dx, dgamma,
+    dbeta and dm bit for bit."""
+    import ctypes
+    import torch
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, c = shape
+    hw, m_ = h * w_, n * h * w_
+    x = (1.2 * RNG.standard_normal(shape) + 0.1).astype(np.float32)
+    gamma = (0.5 + RNG.random(c)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    out = u.bn_fwd_train(x, gamma, beta, 1e-3, dtype, act=2)                 # BN + swish: x_se
+    xd, gd, bd = u.dev(x, dtype), u.dev(gamma), u.dev(beta)
+    xse = u.dev(out['y'], dtype)
+    sm, si = u.dev(out['save_mean']), u.dev(out['save_invstd'])
+    mk = u.dev(RNG.random((n, c)).astype(np.float32), dtype)
+    dy = u.dev(RNG.standard_normal(shape).astype(np.float32), dtype)
+    dgap = u.dev(RNG.standard_normal((n, c)).astype(np.float32), dtype)
+    ws = u.workspace(lib.mcn_bn_workspace_bytes(m_, c))
+    st = u.stream()
+    # three kernels
+    dxse = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dm_ref = torch.full((n, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_channel_scale_bwd(dy.data_ptr(), xse.data_ptr(), mk.data_ptr(), dxse.data_ptr(), dm_ref.data_ptr(), n, hw, c, u.MDT[dtype], st))
+    _ffi.check(lib.mcn_global_avgpool_bwd_acc(dgap.data_ptr(), dxse.data_ptr(), n, hw, c, u.MDT[dtype], st))
+    dx_ref = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg_ref, db_ref = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
+    _ffi.check(lib.mcn_bn_bwd(dxse.data_ptr(), xd.data_ptr(), 0, 0, gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dx_ref.data_ptr(), 0, dg_ref.data_ptr(), db_ref.data_ptr(),
+                              0.5, m_, c, 2, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, st))
+    # composed
+    dm = torch.full((n, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_channel_scale_bwd_dm(dy.data_ptr(), xse.data_ptr(), dm.data_ptr(), n, hw, c, u.MDT[dtype], st))
+    dx = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg, db = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
+    _ffi.check(lib.mcn_bn_bwd_se(dy.data_ptr(), mk.data_ptr(), dgap.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                 db.data_ptr(), 0.5, n, hw, c, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, st))
+    for a, b in ((dx, dx_ref), (dg, dg_ref), (db, db_ref), (dm, dm_ref)):
+        np.testing.assert_array_equal(u.host(a), u.host(b))
+    assert np.abs(u.host(dx)).max() > 0
