@@ -1276,17 +1276,18 @@ extern "C" int mcn_dwconv2d_wgrad(const void* x, const void* dy, float* dw, cons
 
 // ---- squeeze-excite channel scale: y[n,h,w,c] = x[n,h,w,c] * m[n,c] (models/efficientnet.py:161) ---------------------
 template <typename T>
-__global__ __launch_bounds__(256) void chscale_fwd_kernel(const T* __restrict__ x, const T* __restrict__ m, T* __restrict__ y, long total, long HW, int cch) {
+__global__ __launch_bounds__(256) void chscale_fwd_kernel(const T* __restrict__ x, const T* __restrict__ m, T* __restrict__ y, long total_, long HW, int cch) {
     constexpr int CE = VecTraits<T>::CE;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long pix = i / cch;
-        const int ch = (int)(i - pix * cch);
-        const long n = pix / HW;
-        const Chunk<T> a = load_chunk<T>(x + i * CE), b = load_chunk<T>(m + (n * cch + ch) * CE);
+    const unsigned total = (unsigned)total_;                       // (host: < 2^32 chunks — two 64-bit divisions per 16 bytes were most of this kernel)
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned pix = i / (unsigned)cch;
+        const int ch = (int)(i - pix * (unsigned)cch);
+        const long n = pix / (unsigned)HW;
+        const Chunk<T> a = load_chunk<T>(x + (long)i * CE), b = load_chunk<T>(m + (n * cch + ch) * CE);
         Chunk<T> o;
 #pragma unroll
         for (int k = 0; k < CE; ++k) o.set(k, a.get(k) * b.get(k));
-        store_chunk<T>(y + i * CE, o);
+        store_chunk<T>(y + (long)i * CE, o);
     }
 }
 extern "C" int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream) {
@@ -1296,6 +1297,7 @@ extern "C" int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int3
     if (C % ce) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: C=%d must be a multiple of the 16-byte chunk", C);
     const long total = (long)N * HW * (C / ce);
     if (total == 0) return MCN_OK;
+    if (total >= 0xffffffffl) MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_fwd: more than 2^32 chunks (32-bit index arithmetic)");
     long b = (total + 255) / 256;
     if (b > 4096) b = 4096;
     if (dtype == MCN_F32) hipLaunchKernelGGL((chscale_fwd_kernel<float>), dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)m, (float*)y, total, (long)HW, C / ce);

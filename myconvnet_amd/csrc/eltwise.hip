@@ -153,11 +153,12 @@ extern "C" int mcn_cast(const void* src, mcn_dtype sd, void* dst, mcn_dtype dd, 
 template <typename T, bool NCHW>
 __global__ __launch_bounds__(256) void input_prep_kernel(const float* __restrict__ x, T* __restrict__ y, long npix, int HW, int C, int out_cs,
                                                          float mean, float scale) {
-    const long stride = (long)gridDim.x * blockDim.x;
+    const unsigned stride = gridDim.x * blockDim.x;
     constexpr int CE = (int)(16 / sizeof(T));
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+    for (unsigned pu = blockIdx.x * blockDim.x + threadIdx.x; pu < (unsigned)npix; pu += stride) {       // (host: npix < 2^32)
+        const long p = pu;
         T* o = y + p * out_cs;
-        const long n = p / HW, r = p - n * HW;
+        const long n = pu / (unsigned)HW, r = p - n * HW;
         if (out_cs == CE) {                                  // the padded pixel is one 16-byte chunk: one store, not out_cs
             Chunk<T> ch;
 #pragma unroll
@@ -191,6 +192,7 @@ extern "C" int mcn_input_prep(const float* x, void* y, int32_t N, int32_t H, int
     if (!x || !y || N < 0 || H <= 0 || W <= 0 || C <= 0 || out_cs < C) MCN_FAIL(MCN_E_BADARG, "input_prep: bad argument");
     const long npix = (long)N * H * W;
     if (npix == 0) return MCN_OK;
+    if (npix >= 0xffffffffl) MCN_FAIL(MCN_E_UNSUPPORTED, "input_prep: more than 2^32 pixels");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ew_blocks(npix)), block(256);
     const bool nchw = src_layout == MCN_NCHW;

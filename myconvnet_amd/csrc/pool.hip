@@ -38,14 +38,14 @@ static inline unsigned pool_blocks(long n) {
 template <typename T, int VEC, bool AFF = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, PoolParams p,
                                                           const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
-    const int cv = p.C / VEC;
-    const long total = (long)p.N * p.OH * p.OW * cv;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cv) * VEC;
-        long r = idx / cv;
-        const int ox = (int)(r % p.OW);
-        r /= p.OW;
-        const int oy = (int)(r % p.OH), n = (int)(r / p.OH);
+    const unsigned cv = (unsigned)(p.C / VEC);
+    const unsigned total = (unsigned)((long)p.N * p.OH * p.OW * cv);       // (host: < 2^32 — 32-bit index arithmetic: four 64-bit divisions per item cost more than the window)
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        unsigned r = idx / cv;
+        const int c = (int)(idx - r * cv) * VEC;
+        const unsigned r1 = r / (unsigned)p.OW;
+        const int ox = (int)(r - r1 * (unsigned)p.OW);
+        const int n = (int)(r1 / (unsigned)p.OH), oy = (int)(r1 - (unsigned)n * (unsigned)p.OH);
         float best[VEC];
         int bi[VEC];
 #pragma unroll
@@ -272,13 +272,14 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T
 }
 template <typename T, int VEC, bool ACC = false>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int HW, int C) {
-    const int cv = C / VEC;
-    const long total = (long)N * HW * cv;
+    const unsigned cv = (unsigned)(C / VEC);
+    const unsigned total = (unsigned)((long)N * HW * cv);                   // (host: < 2^32)
     const float inv = 1.f / (float)HW;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cv) * VEC;
-        const long pq = idx / cv;
-        const long n = pq / HW;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned pqu = idx / cv;
+        const int c = (int)(idx - pqu * cv) * VEC;
+        const long pq = pqu;
+        const long n = pqu / (unsigned)HW;
         float g[VEC];
         pld<T, VEC>(dy + n * C + c, g);
         if (ACC) {                                               // dx += : the second gradient contribution of an SE block's input
@@ -300,6 +301,7 @@ static int pool_check(const void* a, const void* b, int N, int H, int W, int C, 
     if (!a || !b || N < 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || SH <= 0 || SW <= 0 || padT < 0 || padL < 0 || OH <= 0 || OW <= 0 ||
         KH * KW > 127)
         MCN_FAIL(MCN_E_BADARG, "%s: bad argument", name);
+    if ((long)N * H * W * C >= 0xffffffffl || (long)N * OH * OW * C >= 0xffffffffl) MCN_FAIL(MCN_E_UNSUPPORTED, "%s: more than 2^32 elements (32-bit index arithmetic)", name);
     return MCN_OK;
 }
 #define POOL_DISPATCH(KERNEL, TOTAL, ...)                                                                        \
@@ -525,6 +527,7 @@ extern "C" int mcn_global_avgpool_fwd(const void* x, void* y, int32_t N, int32_t
 extern "C" int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream) {
     if (!dy || !dx || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "global_avgpool_bwd_acc: bad argument");
     if (N == 0) return MCN_OK;
+    if ((long)N * HW * C >= 0xffffffffl) MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_bwd_acc: more than 2^32 elements (32-bit index arithmetic)");
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * HW * C;
     if (dtype == MCN_F32) {
@@ -543,6 +546,7 @@ extern "C" int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, i
 extern "C" int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void* stream) {
     if (!dy || !dx || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "global_avgpool_bwd: bad argument");
     if (N == 0) return MCN_OK;
+    if ((long)N * HW * C >= 0xffffffffl) MCN_FAIL(MCN_E_UNSUPPORTED, "global_avgpool_bwd: more than 2^32 elements (32-bit index arithmetic)");
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * HW * C;
     if (dtype == MCN_F32) {
