@@ -149,7 +149,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     from myconvnet_amd._ffi import lib, check
     low = model._train_low
     sp = model.stream_ptr()
-    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
     mdt = _ffi.F32 if dtype == 'fp32' else _ffi.BF16
     buf = ctypes.create_string_buffer(128)
     lbuf = ctypes.create_string_buffer(1024)
@@ -219,8 +219,10 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                     epi = ', 1>'
                 elif (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
                     epi = ', 2>'                                           # ... with the accumulate epilogue
+                elif name == 'mcn_conv2d_dgrad_bnred':
+                    epi = ', 4>'                                           # ... with the BN-backward sums
                 launches = [(k.replace(', 0>', epi) if epi else k, int(t)) for k, t in launches]
-                if (epi == ', 2>' and dtype == 'fp32') or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
+                if (epi == ', 2>' and dtype == 'fp32') or epi == ', 4>' or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
                     # fp32 keeps conv_gemm_nt for the accumulate epilogue; by default only the statistics forward is persistent
                     launches = [(_not_persistent(k), t) for k, t in launches]
                 key = max(launches, key=lambda kt: kt[1])[0]               # (per-layer table: the launch with the most taps)
@@ -230,6 +232,8 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 byt = es * (xe + gm.N * oh * ow * gm.Cout) + (4 if name == 'mcn_conv2d_wgrad' else es) * gm.KH * gm.KW * gm.Cin * gm.Cout
                 if (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
                     byt += es * xe                                         # accumulate / fused residual fan-in: one more read of a dx-sized tensor
+                if name == 'mcn_conv2d_dgrad_bnred':
+                    byt += es * xe                                         # the BN's input, read beside the dx tile for sum dy' * x
                 if layers:
                     r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
                     r[0] += 1

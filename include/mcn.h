@@ -243,6 +243,21 @@ int mcn_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
                float grad_scale, int64_t M, int32_t C, mcn_act act, mcn_dtype dtype, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* BN-backward reduction in the epilogue of the dgrad that produces dy (the bottleneck's inner BNs: conv -> BN -> ReLU -> conv): when a
+ * conv is the ONLY reader of a training-mode BN + ReLU's output, its dgrad mcn_conv2d_dgrad_bnred also accumulates, per (M tile,
+ * wave row), sum dy' and sum dy' * x (dy' = the gradient it stores where the forward's ReLU bit is set, bn_x = the BN's input, relu_mask =
+ * the byte mask of mcn_bn_fwd_train*) into red_partials [rows][2][Cin], rows = mcn_conv2d_dgrad_bnred_rows() (0: not eligible);
+ * mcn_bn_bwd_from_partials then finalizes from those rows and runs only the apply pass: the BN backward's reduction pass over (dy, x)
+ * is gone.  dx / dgamma / dbeta as mcn_bn_bwd up to the order of fp32 sums. */
+int32_t mcn_conv2d_dgrad_bnred_rows(const mcn_conv_geom* geom, mcn_dtype dtype);
+int mcn_conv2d_dgrad_bnred(const void* dy, const float* w_hwio, const void* w_packed, void* dx, const void* bn_x, const uint8_t* relu_mask,
+                           float* red_partials, const mcn_conv_geom* geom, mcn_dtype dtype, mcn_layout layout, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int mcn_bn_bwd_from_partials(const void* dy, const void* x, const uint8_t* relu_mask, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_invstd, const float* red_partials, int32_t nparts, void* dx,
+                             float* dgamma, float* dbeta, float grad_scale, int64_t M, int32_t C, mcn_dtype dtype, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* Squeeze-excite backward without the gradient tensor of the block's input (models/efficientnet.py:152-163): x_se (the output of a
  * BN + swish) is read by the SE branch's global average pool and by y = x_se * m; its gradient round(round(dy*m) + dgap/HW) is
  * composed inside the BN's two backward passes (mcn_bn_bwd_se; dy = gradient of y, se_mask = m [N,C], dgap [N,C] = gradient of the

@@ -397,16 +397,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = dbeta/M, coef[2][c] = dgamma/M
+// raw_mean != nullptr: the second partial is sum dy' * x (conv-epilogue partials, mcn_conv2d_dgrad_bnred), not sum dy' * xhat:
+// sum dy' * xhat = invstd * (sum dy' * x - mean * sum dy'), in double
 __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, long M, int C,
                                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                             float grad_scale, float* __restrict__ coef, int frozen) {
+                                                                             float grad_scale, float* __restrict__ coef, int frozen,
+                                                                             const float* __restrict__ raw_mean = nullptr) {
     __shared__ double sh[FIN_CH * FIN_LANES * 2];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const int lane = threadIdx.x / FIN_CH;
     double a, b;
     fin_reduce(part, nparts, C, c, lane, sh, a, b);
     if (lane != 0 || c >= C) return;
+    if (raw_mean) b = (double)invstd[c] * (b - (double)raw_mean[c] * a);
     if (dbeta) dbeta[c] = (float)a * grad_scale;
     if (dgamma) dgamma[c] = (float)b * grad_scale;
     coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
@@ -1220,6 +1224,71 @@ extern "C" int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dg
     if (dtype == MCN_BF16 && C % 8 == 0) return bn_bwd_se_t<bf16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
     if (dtype == MCN_F16 && C % 8 == 0) return bn_bwd_se_t<f16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
+}
+
+// groups of rpg rows of [nparts][2][C] sums -> fold[(g*2 + {0,1})*C + c] (summed in double, fixed order)
+__global__ __launch_bounds__(256) void bn_bwd_fold_partials_kernel(const float* __restrict__ part, float* __restrict__ fold, int nparts, int C, int rpg, int TX) {
+    __shared__ double red[256 * 2];
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = blockIdx.x * TX + tx;
+    const int r0 = blockIdx.y * rpg, r1 = min(nparts, r0 + rpg);
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = r0 + ty; r < r1; r += TY) {
+            a += (double)part[((long)r * 2 + 0) * C + c];
+            b += (double)part[((long)r * 2 + 1) * C + c];
+        }
+    red[threadIdx.x * 2] = a;
+    red[threadIdx.x * 2 + 1] = b;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    a = 0.0, b = 0.0;
+    for (int k = 0; k < TY; ++k) {
+        a += red[(k * TX + tx) * 2];
+        b += red[(k * TX + tx) * 2 + 1];
+    }
+    fold[((long)blockIdx.y * 2 + 0) * C + c] = (float)a;
+    fold[((long)blockIdx.y * 2 + 1) * C + c] = (float)b;
+}
+
+// BN + ReLU backward whose reduction pass ran in the epilogue of the dgrad that produced dy (mcn_conv2d_dgrad_bnred): finalize from
+// those partial rows ([nparts][2][C]: sum dy', sum dy' * x), then the apply pass with the forward's ReLU byte mask.
+extern "C" int mcn_bn_bwd_from_partials(const void* dy, const void* x, const uint8_t* relu_mask, const float* gamma, const float* beta, const float* save_mean,
+                                        const float* save_invstd, const float* red_partials, int32_t nparts, void* dx, float* dgamma, float* dbeta,
+                                        float grad_scale, int64_t M, int32_t C, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !relu_mask || !dx || !save_mean || !save_invstd || !red_partials || nparts <= 0 || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd_from_partials: bad argument");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd_from_partials: workspace too small");
+    const int vec = dtype == MCN_F32 ? 4 : 8;
+    if (!mcn_dtype_ok(dtype) || C % vec) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_from_partials: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
+    const float* rows = red_partials;
+    if (nparts > BN_FOLD_ROWS) {
+        // a dgrad leaves one row per (M tile, wave row) — 12 000-25 000 for the 56 x 56 layers: fold them with the whole chip first (the
+        // finalize kernel has C / FIN_CH workgroups)
+        const int rpg = (nparts + BN_FOLD_ROWS - 1) / BN_FOLD_ROWS;
+        const int n = (nparts + rpg - 1) / rpg;
+        int TX = 8;
+        while (TX < C && TX < 256) TX *= 2;
+        hipLaunchKernelGGL(bn_bwd_fold_partials_kernel, dim3((C + TX - 1) / TX, n), dim3(256), 0, st, red_partials, (float*)ws, nparts, C, rpg, TX);
+        MCN_CHECK_LAUNCH();
+        rows = (const float*)ws;
+        nparts = n;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, rows, nparts, (long)M, C, gamma, save_invstd, dgamma,
+                       dbeta, grad_scale, coef, 0, save_mean);
+    MCN_CHECK_LAUNCH();
+    const ColLayout L = make_layout((long)M, C, vec, dtype == MCN_F32 ? bn_target<float>() : bn_target<bf16_t>());
+    const dim3 grid(L.gx, L.gy), block(256);
+#define BN_BWD_APPLY_M(TT, VV) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, VV, 4, false>), grid, block, 0, st, (const TT*)dy, (const TT*)x, (const TT*)relu_mask, save_mean, save_invstd, \
+                                                  gamma, beta, (const float*)coef, (TT*)dx, (TT*)nullptr, (long)M, C, L.TX, L.TY, L.rpb)
+    if (dtype == MCN_F32) BN_BWD_APPLY_M(float, 4);
+    else if (dtype == MCN_BF16) BN_BWD_APPLY_M(bf16_t, 8);
+    else BN_BWD_APPLY_M(f16_t, 8);
+#undef BN_BWD_APPLY_M
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
 }
 
 // ---- backward of the frozen-statistics BN (fused_batch_norm(is_training=False) inside a training graph) ----------------

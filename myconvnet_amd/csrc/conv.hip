@@ -347,6 +347,7 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
     do {                                                                             \
         if (epi == NT_EPI_STATS) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_STATS);  \
         else if (epi == NT_EPI_ACC) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_ACC); \
+        else if (epi == NT_EPI_BNRED) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_BNRED); \
         else MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_STORE);                      \
     } while (0)
 #define MCN_LAUNCH_NT_MODE(BMV, BNV, NWV)                                                 \
@@ -354,13 +355,14 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
         if (reduce) {                                                                     \
             if (epi == NT_EPI_STATS) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STATS>), grid, block, 0, st, p);    \
             else if (epi == NT_EPI_ACC) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_ACC>), grid, block, 0, st, p);   \
+            else if (epi == NT_EPI_BNRED) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_BNRED>), grid, block, 0, st, p); \
             else hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STORE>), grid, block, 0, st, p);                        \
         } else if (mode_nt == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_LINEAR);         \
         else if (mode_nt == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_UNIFORM);         \
         else MCN_LAUNCH_NT(BMV, BNV, NWV, NT_GENERIC);                                    \
     } while (0)
     // epilogue variant: the accumulate modes have their own instantiation (batched loads), so do the BN statistics
-    const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
+    const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : (p.red_part ? NT_EPI_BNRED : NT_EPI_STORE));
     if (mode == NT_WINDOW && !reduce) {
         const int wlds = nt_window_lds(p.win_rows - t.bm, t);
 #define MCN_LAUNCH_WIN_E(BMV, BNV, EPIV)                                                                  \
@@ -373,6 +375,7 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
     do {                                                                                                  \
         if (epi == NT_EPI_STATS) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_STATS);                                \
         else if (epi == NT_EPI_ACC) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_ACC);                               \
+        else if (epi == NT_EPI_BNRED) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_BNRED);                           \
         else MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_STORE);                                                    \
     } while (0)
         if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_WIN(128, 128);
@@ -512,11 +515,11 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
     if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) {
-        const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : NT_EPI_STORE);
+        const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : (p.red_part ? NT_EPI_BNRED : NT_EPI_STORE));
         // (counted statistics rows are a property of the geometry — mcn_conv2d_bnstats_rows() promised them to the BN side — so
         // that launch is persistent with or without a bias)
         if (p.stats && nt_stats_counted<T>(mode, p.M, p.Nn, p.nchunks, tile, tile_hint, nullptr)) return launch_nt_pers<T>(p, tile, W, st, NT_EPI_STATSC);
-        if (mode == NT_LINEAR && !p.bias && nt_pers_tile(t, sizeof(T), epi)) return launch_nt_pers<T>(p, tile, W, st, epi);
+        if (mode == NT_LINEAR && !p.bias && epi != NT_EPI_BNRED && nt_pers_tile(t, sizeof(T), epi)) return launch_nt_pers<T>(p, tile, W, st, epi);
         return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
     }
     p.sk_mode = 1;
@@ -714,7 +717,8 @@ static inline int pos_mod(int a, int m) { return ((a % m) + m) % m; }
 
 template <typename T>
 static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, void* dx, const Geo& g, int accumulate, mcn_dtype dt,
-                        void* ws, size_t ws_bytes, hipStream_t st, const void* add_src = nullptr, const unsigned char* add_mask = nullptr) {
+                        void* ws, size_t ws_bytes, hipStream_t st, const void* add_src = nullptr, const unsigned char* add_mask = nullptr,
+                        const void* red_x = nullptr, const unsigned char* red_mask = nullptr, float* red_part = nullptr) {
     const long Min = (long)g.N * g.H * g.W;
     if (Min == 0) return MCN_OK;
     if (!mfma_dgrad_ok(g, dt)) {
@@ -792,6 +796,7 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         if (hipMemsetAsync(dx, 0, (size_t)Min * g.Cin * sizeof(T), st) != hipSuccess) MCN_FAIL(MCN_E_LAUNCH, "conv2d_dgrad: memset failed");
     }
     char* wsp = w_packed ? (char*)const_cast<void*>(w_packed) : (char*)ws;
+    int red_row = 0;                                   // BN-backward partial rows: one block of rows per stride-parity launch
     for (int k = 0; k < ncls; ++k) {
         const Cls& c = cls[k];
         const int OHs = (g.H - c.py + g.SH - 1) / g.SH, OWs = (g.W - c.px + g.SW - 1) / g.SW;
@@ -816,6 +821,11 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         p.cpt = Cp / ce; p.ntaps = c.nt; p.nchunks = c.nt * p.cpt; p.sy = 1; p.sx = 1; p.Nn = g.Cin;
         p.OHf = g.H; p.OWf = g.W; p.ldo = g.Cin; p.osy = g.SH; p.osx = g.SW; p.oy0 = c.py; p.ox0 = c.px; p.accumulate = add_src ? 2 : accumulate;
         p.add_src = add_src; p.add_mask = add_mask;
+        p.red_x = red_x; p.red_mask = red_mask; p.red_part = red_part; p.red_row0 = red_row;
+        if (red_part) {
+            const NtTile rt = kNtCand[pick_nt_tile<T>(p.M, p.Nn, g.tile)];
+            red_row += (rt.nw / 2) * ((p.M + rt.bm - 1) / rt.bm);
+        }
         p.in_bytes = (unsigned)((size_t)g.N * g.OH * g.OW * g.Cout * sizeof(T));
         p.wt_bytes = (unsigned)((size_t)g.Cin * c.nt * Cp * sizeof(T));
         const bool linear = c.nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
@@ -863,6 +873,43 @@ extern "C" int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w, const 
     if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
     if (dtype == MCN_F16) return conv_dgrad_t<f16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
     return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask);
+}
+
+// dgrad whose output dx IS the gradient of a BN + ReLU's output (the conv is that BN's only reader): the epilogue also accumulates the
+// BN's backward sums — per (M tile, wave row) partial rows [rows][2][Cin]: sum dy', sum dy' * x with dy' = the stored dx where the
+// forward's ReLU bit is set, x = the BN's input — so that the BN backward needs no reduction pass over (dy, x)
+// (mcn_bn_bwd_from_partials).  rows: mcn_conv2d_dgrad_bnred_rows() (0 = geometry not eligible: use mcn_conv2d_dgrad).
+extern "C" int32_t mcn_conv2d_dgrad_bnred_rows(const mcn_conv_geom* gg, mcn_dtype dtype) {
+    Geo g;
+    if (!gg || geo_from(gg, &g) || !mcn_dtype_ok(dtype) || !mfma_dgrad_ok(g, dtype) || g.xcs != g.Cin) return 0;
+    long rows = 0;
+    for (int py = 0; py < g.SH && py < g.H; ++py)
+        for (int px = 0; px < g.SW && px < g.W; ++px) {
+            int nt = 0;
+            for (int r = 0; r < g.KH; ++r)
+                for (int s2 = 0; s2 < g.KW; ++s2)
+                    if (!pos_mod(py + g.pT - r * g.DH, g.SH) && !pos_mod(px + g.pL - s2 * g.DW, g.SW)) nt++;
+            if (!nt) continue;
+            const int OHs = (g.H - py + g.SH - 1) / g.SH, OWs = (g.W - px + g.SW - 1) / g.SW;
+            const long M = (long)g.N * OHs * OWs;
+            const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
+            rows += (long)(kNtCand[t].nw / 2) * ((M + kNtCand[t].bm - 1) / kNtCand[t].bm);
+        }
+    return rows > 0x7fffffffl ? 0 : (int32_t)rows;
+}
+extern "C" int mcn_conv2d_dgrad_bnred(const void* dy, const float* w, const void* w_packed, void* dx, const void* bn_x, const uint8_t* relu_mask,
+                                      float* red_partials, const mcn_conv_geom* gg, mcn_dtype dtype, mcn_layout layout, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_bnred: only NHWC activations");
+    if (!dy || !w || !dx || !bn_x || !relu_mask || !red_partials) MCN_FAIL(MCN_E_BADARG, "conv2d_dgrad_bnred: null pointer");
+    if (mcn_conv2d_dgrad_bnred_rows(gg, dtype) <= 0) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_bnred: geometry not eligible (mcn_conv2d_dgrad_bnred_rows() == 0)");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, nullptr, nullptr, bn_x, relu_mask, red_partials);
+    if (dtype == MCN_F16) return conv_dgrad_t<f16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, nullptr, nullptr, bn_x, relu_mask, red_partials);
+    return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, nullptr, nullptr, bn_x, relu_mask, red_partials);
 }
 
 // ---- wgrad -----------------------------------------------------------------------------------------------

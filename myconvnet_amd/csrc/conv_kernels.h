@@ -54,6 +54,13 @@ struct GemmNTParams {
     int win_dmin, win_rows; // conv_gemm_nt_win: smallest tap offset in pixels (dy*IW + dx) and the rows of the input window BM + (dmax - dmin)
     unsigned out_bytes;     // bytes of the whole output tensor (set by launch_nt: buffer range of the epilogue's stores / loads)
     int epi_flags;          // experiments (MCN_NT_EPI_FLAGS): 1 = no lane pairing (8-byte bf16 accesses), 2 = byte-wise mask loads
+    // NT_EPI_BNRED (dgrad whose output IS the gradient of a BN + ReLU output): the BN's backward sums ride in this epilogue.
+    // red_x = the BN's input (layout of `out`), red_mask = the forward's ReLU byte mask (one byte per 16-byte chunk), red_part =
+    // partial rows [rows][2][Nn] = sum dy', sum dy' * x over the pixel rows of a wave row, dy' = the stored gradient where the mask bit is set
+    const void* red_x;
+    const unsigned char* red_mask;
+    float* red_part;
+    int red_row0;           // first partial row of this launch (a strided dgrad launches once per stride-parity class)
     int tap[MCN_MAX_TAPS];  // (dy & 0xffff) | (dx << 16) per filter tap: 32-bit so that a wave-uniform tap index is a scalar load
                             // (byte tables are fetched with vector loads whose waits drain the LDS-DMA queue)
 };
@@ -232,7 +239,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // offset carries "row past the end" / "column past Nn" in bit 31 (out of range => the store is dropped, the load returns
 // 0), the bias is folded into the accumulators under ONE uniform branch, the statistics run on packed fp32 pairs
 // (v_pk_add_f32 / v_pk_fma_f32), and the pixel of a row is its GEMM row unless the launch scatters a sub-grid (strided dgrad).
-enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2, NT_EPI_STATSC = 3 };
+enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2, NT_EPI_STATSC = 3, NT_EPI_BNRED = 4 };
 // NT_EPI_STATSC (conv_gemm_nt_pers only): the per-lane statistics sums are CARRIED across the tiles a persistent workgroup walks
 // (all its tiles share the channel block) and folded / written once per workgroup as a "counted" partial row
 // [s1][s2][pivot][count] — one lane fold and one row per workgroup and wave row instead of one per tile.
@@ -294,6 +301,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     typedef Quad<T> Q;
     constexpr bool CARRY = EPI == NT_EPI_STATSC;
     constexpr bool STATS = EPI == NT_EPI_STATS || CARRY, ACC = EPI == NT_EPI_ACC;
+    constexpr bool BNRED = EPI == NT_EPI_BNRED;
+    constexpr bool LD = ACC || BNRED;                          // the epilogue loads a tensor in the output's layout (+ a byte mask)
     constexpr int WROWS = NW / 2;
     constexpr int WTM = BM / WROWS, WTN = BN / 2;
     constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
@@ -345,17 +354,19 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 
     // ---- accumulate modes: ALL loads of the epilogue are issued back to back in front of the first store (with LDS-DMA in the
     // kernel hipcc waits vmcnt(0) at the first use of every ordinary load, which also drains the stores in front of it) ----
-    typename Q::Bits prev[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
-    unsigned char mbits[ACC ? TM : 1][ACC ? TN : 1][ACC ? NG : 1];
-    if constexpr (ACC) {
+    typename Q::Bits prev[LD ? TM : 1][LD ? TN : 1][LD ? NG : 1];
+    unsigned char mbits[LD ? TM : 1][LD ? TN : 1][LD ? NG : 1];
+    if constexpr (LD) {
         constexpr int CEL = 16 / ES;                                    // elements per mask byte
         constexpr int MB = WTN / CEL;                                   // mask bytes per pixel for this wave's WTN channels: 4, 8 or 16
         static_assert(MB % 4 == 0, "mask bytes per wave row");
-        const bool masked = p.accumulate == 2;
-        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(masked ? p.add_src : (const void*)p.out), 0, (int)p.out_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.add_mask), 0, masked ? (int)(p.out_bytes >> 4) : 0, 0x00020000);
+        const bool masked = BNRED || p.accumulate == 2;
+        const void* const lsrc = BNRED ? p.red_x : (masked ? p.add_src : (const void*)p.out);
+        const unsigned char* const lmask = BNRED ? p.red_mask : p.add_mask;
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(lsrc), 0, (int)p.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(lmask), 0, masked ? (int)(p.out_bytes >> 4) : 0, 0x00020000);
         // one wide mask load per row block (instead of a byte per accumulator) when the wave's channel range is whole
-        const bool wide = masked && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)p.add_mask & 15) == 0 && !(p.epi_flags & 2);
+        const bool wide = masked && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)lmask & 15) == 0 && !(p.epi_flags & 2);
         unsigned mw[TM][MB / 4];
         const unsigned wcol = (unsigned)((n0 + wn * WTN) * ES) | (((unsigned)(p.Nn - 1 - (n0 + wn * WTN)) >> 31) << 31);
 #pragma unroll
@@ -446,6 +457,14 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
             carry->count += (float)(left < 0 ? 0 : (left > WTM ? WTM : left));
         }
     }
+    if constexpr (BNRED) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1[j][g][e] = s2[j][g][e] = 0.f;
+    }
     const bool full = m0 + BM <= p.m_end;                      // wave-uniform: no row of this tile is past the end
     // the 4 output values of accumulator (i, j, g) as stored (residual added, rounded) + their statistics
     auto value = [&](int i, int j, int g, bool rowvalid) -> typename Q::Bits {
@@ -461,6 +480,22 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
             for (int e = 0; e < 4; ++e) v[e] += (mb >> e) & 1u ? pr[e] : 0.f;
         }
         const typename Q::Bits o = Q::pack(v);
+        if constexpr (BNRED) {
+            // BN-backward sums of the gradient as stored: dy' = dy where the forward's ReLU bit is set; rows past the end load x = 0 and
+            // mask = 0 (out-of-range buffer offsets), so they add nothing
+            float r[4], xv[4];
+            Q::unpack(o, r);
+            Q::unpack(prev[i][j][g], xv);
+            const unsigned mb = ES == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (col(j, g) & 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 d = f32x2{(mb >> (2 * h)) & 1u ? r[2 * h] : 0.f, (mb >> (2 * h + 1)) & 1u ? r[2 * h + 1] : 0.f};
+                const f32x2 a = f32x2{s1[j][g][2 * h], s1[j][g][2 * h + 1]} + d;
+                const f32x2 b = __builtin_elementwise_fma(d, f32x2{xv[2 * h], xv[2 * h + 1]}, f32x2{s2[j][g][2 * h], s2[j][g][2 * h + 1]});
+                s1[j][g][2 * h] = a[0]; s1[j][g][2 * h + 1] = a[1];
+                s2[j][g][2 * h] = b[0]; s2[j][g][2 * h + 1] = b[1];
+            }
+        }
         if constexpr (STATS) {
             float r[4];
             Q::unpack(o, r);
@@ -515,6 +550,30 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     if (!STATS || full) store_all(std::true_type{});
     else store_all(std::false_type{});
 
+    if constexpr (BNRED) {
+        constexpr int V = TN * NG * 4;
+        float a[V], b[V];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[(j * NG + g) * 4 + e] = s1[j][g][e];
+                    b[(j * NG + g) * 4 + e] = s2[j][g][e];
+                }
+        int base = 0;
+        bool writer = true;
+        LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
+        const int prow = p.red_row0 + ((m0 - p.m_begin) / BM) * WROWS + wm;
+        const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
+        const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
+        const int n = n0 + wn * WTN + j * MM::MT + nl + e;
+        if (writer && n < p.Nn) {
+            p.red_part[((long)prow * 2 + 0) * p.Nn + n] = a[0];
+            p.red_part[((long)prow * 2 + 1) * p.Nn + n] = b[0];
+        }
+    }
     if constexpr (STATS && !CARRY) {
         // Fold over the MT lanes that hold different pixel rows of the same channels with a halving butterfly: at each
         // step a lane keeps half of its values and receives the partner's copies of that half (V/2 + V/4 + ... shuffles

@@ -43,6 +43,12 @@ class Lowering(object):
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
         self.aff_skips = {}            # shortcut-BN output tensor id -> (its input tensor, its affine [2][C]): applied by the consumer BN
+        # BN-backward sums (sum dy', sum dy' * x) in the epilogue of the dgrad that produces that BN's output gradient (the two inner BNs
+        # of a bottleneck).  Measured on one box, B=256: the BN backward's kernels lose 0.6 ms (bf16) / 1.0 ms (fp32) and the dgrads gain
+        # nothing, yet with the wgrad on its side stream the step is 68.83 vs 68.92 ms in fp32 and 22.35 vs 22.25 ms in bf16 — the reduction
+        # pass is HBM-bound and was already running under the MFMA-bound wgrad (serial launch order: 71.28 vs 71.79 ms fp32, 22.44 vs
+        # 22.55 ms bf16).  On for fp32, off for the 2-byte types.
+        self.fuse_bn_bwd_red = bool(model._parameters.get('fuse_bn_bwd_red', _env_flag('MCN_FUSE_BN_BWD_RED', graph.dtype == 'float32')))
         self.scratch = {}
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -198,7 +204,7 @@ class Lowering(object):
         """Measure, don't guess: time every tile candidate of every conv launch of this lowering on the GPU (HIP events
         on the launch stream, data already in the buffers) and pin the fastest through mcn_conv_geom.tile.  The result
         of a conv does not depend on the tile except for the fp32 summation order of the split wgrad."""
-        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
         sp = torch.cuda.current_stream(self.g.device).cuda_stream
         self.prepack.run(sp)
         chosen = {}
@@ -235,6 +241,12 @@ class Lowering(object):
                         rpp = ctypes.c_int32(0)
                         args[ip + 1] = int(lib.mcn_conv2d_bnstats_rows(ctypes.byref(fs[1]), self.dt, ctypes.byref(rpp)))
                         args[ip + 2] = rpp.value
+        for fn, args in self.bwd.calls:                     # ... and so does the row count of a dgrad -> BN-backward pair
+            if getattr(fn, '__name__', '') == 'mcn_bn_bwd_from_partials':
+                for nd in self.g.nodes:
+                    br = nd.attrs.get('bwd_red') if nd.op == 'bn' else None
+                    if br is not None and br[0].data_ptr() == args[7]:
+                        args[8] = int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(br[1]), self.dt))
         return chosen
 
     # ---- input / labels ---------------------------------------------------------------------------------
@@ -292,6 +304,21 @@ class Lowering(object):
             return None
         c = y.consumers[0]
         if c.op != 'bn' or not c.attrs['update'] or c.inputs[0] is not y or c not in self.g.nodes:
+            return None
+        return c
+
+    def _red_conv(self, bn):
+        """The conv that is the only reader of this training-mode BN + ReLU's output and whose dgrad can accumulate the BN's backward
+        sums in its epilogue (mcn_conv2d_dgrad_bnred), else None."""
+        a = bn.attrs
+        x, y = bn.inputs[0], bn.outputs[0]
+        if not (self.train and self.fuse_bn_bwd_red and a['update'] and a.get('act', 0) == _ffi.ACT_RELU and a.get('skip') is None
+                and x.needs_grad and len(y.consumers) == 1):
+            return None
+        c = y.consumers[0]
+        if c.op != 'conv' or c.inputs[0] is not y or c not in self.g.nodes or 'geom_orig' in c.attrs or x.shape[-1] % (4 if self.g.dtype == 'float32' else 8):
+            return None
+        if self._pool_consumer(bn) is not None or lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(self.op_geom(c, _ffi.CONV_DGRAD)), self.dt) <= 0:
             return None
         return c
 
@@ -353,6 +380,14 @@ class Lowering(object):
             self.written.add(x.id)
             self.bwd.add(lib.mcn_conv2d_dgrad_addmasked, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), lazy[0], lazy[1],
                          ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+        elif x.needs_grad and x.producer is not None and x.producer.op == 'bn' and x.producer.attrs.get('bwd_red', (None, None, None))[2] is n:
+            # x = relu(bn(u)), read by this conv only: the epilogue also leaves the BN backward's sums (bwd_bn then runs its apply pass only)
+            pa = x.producer.attrs
+            assert x.id not in self.written and gm is pa['bwd_red'][1]
+            self.written.add(x.id)
+            self.bwd.add(lib.mcn_conv2d_dgrad_bnred, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), x.producer.inputs[0].buf.data_ptr(),
+                         pa['relu_mask'].data_ptr(), pa['bwd_red'][0].data_ptr(), ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+            pa['bwd_red_done'] = True
         elif x.needs_grad:
             self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_conv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), dst,
                                                              ctypes.byref(gm), acc, self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes))
@@ -472,14 +507,25 @@ class Lowering(object):
         if self.train and a['update']:
             st = a['saved']
             single = self.model.world_size == 1
+            a.pop('bwd_red', None)
+            a.pop('bwd_red_done', None)
             # a BN with a fused residual cannot recompute its ReLU mask from x: keep [y > 0] as one byte per 16-byte chunk
             # (the backward then reads 1/16 of the bytes of y, twice)
             mask_ptr = 0
-            if skip is not None and a.get('act', 0) == _ffi.ACT_RELU and x.needs_grad:
+            red = self._red_conv(n)                   # (the dgrad epilogue that sums this BN's backward terms reads the same byte mask)
+            if (skip is not None or red is not None) and a.get('act', 0) == _ffi.ACT_RELU and x.needs_grad:
                 nb = int(lib.mcn_bn_relu_mask_bytes(M, C, MCN_DT[x.dtype]))
                 if nb:
                     a['relu_mask'] = torch.zeros(nb, dtype=torch.uint8, device=self.g.device)
                     mask_ptr = a['relu_mask'].data_ptr()
+                    if red is not None:
+                        gd = self.op_geom(red, _ffi.CONV_DGRAD)
+                        keep, cand = gd.tile, []
+                        for t in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_DGRAD) + 1):     # room for any tile the autotuner may pin
+                            gd.tile = t
+                            cand.append(int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(gd), self.dt)))
+                        gd.tile = keep
+                        a['bwd_red'] = (torch.zeros((max(cand), 2, C), dtype=torch.float32, device=self.g.device), gd, red)
             if 'fused_stats' in a:
                 part, gm = a['fused_stats']
                 rpp = ctypes.c_int32(0)
@@ -611,6 +657,14 @@ class Lowering(object):
                 self.bwd.add(lib.mcn_bn_bwd_maxpool, route.outputs[0].grad.data_ptr(), route.attrs['argmax'].data_ptr(), x.buf.data_ptr(), self.vptr(g), self.vptr(b),
                              st['mean'].data_ptr(), st['invstd'].data_ptr(), dst, g.grad.data_ptr() if g is not None and g.trainable else 0,
                              b.grad.data_ptr() if b is not None and b.trainable else 0, gs, *(self._pool_args(route) + [MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes]))
+                return
+            if a.get('bwd_red_done'):
+                assert act == _ffi.ACT_RELU and skip is None and lazy is None and mptr
+                part, gd = a['bwd_red'][0], a['bwd_red'][1]
+                self.bwd.add(lib.mcn_bn_bwd_from_partials, dy_ptr, x.buf.data_ptr(), mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(), st['invstd'].data_ptr(),
+                             part.data_ptr(), int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(gd), self.dt)), dst,
+                             g.grad.data_ptr() if g is not None and g.trainable else 0, b.grad.data_ptr() if b is not None and b.trainable else 0, gs, M, C,
+                             MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
                 return
             self.bwd.add(lib.mcn_bn_bwd, dy_ptr, x.buf.data_ptr(), yptr, mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(),
                          st['invstd'].data_ptr(), dst, dskip_ptr, g.grad.data_ptr() if g is not None and g.trainable else 0,

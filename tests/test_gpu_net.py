@@ -203,6 +203,38 @@ def test_resnet_fp32_bn_statistics_from_conv_epilogue():
         assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_resnet_bn_backward_sums_from_dgrad_epilogue(dtype):
+    """fuse_bn_bwd_red (default: fp32 only): the two inner BNs of every bottleneck take their backward sums from the epilogue of the
+    dgrad that produces their output gradient.  Same step with the switch off: gradients agree up to the order of the fp32 sums
+    (fp32) / to bf16 rounding of dx around unchanged sums (bf16)."""
+    import myconvnet_amd as M
+    res = {}
+    x = np.random.default_rng(67).random((BATCH, 64, 64, 3)).astype(np.float32)
+    for on in (True, False):
+        model, spec, params, stats = make_resnet(50, dtype, True, fuse_bn_bwd_red=on)
+        names = [getattr(fn, '__name__', '') for fn, _ in model._train_low.bwd.calls]
+        assert ('mcn_conv2d_dgrad_bnred' in names) == on and ('mcn_bn_bwd_from_partials' in names) == on
+        if on:
+            assert names.count('mcn_conv2d_dgrad_bnred') == names.count('mcn_bn_bwd_from_partials') == 32      # 16 bottlenecks x (BN0, BN1)
+        opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+        model.feed(x, LABELS)
+        loss, _, _ = opt._step(None)
+        res[on] = (loss, model.get_variables('grad'))
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])          # the forward pass is the same launches
+    if dtype == 'float32':
+        worst = max((rel_l2(res[True][1][k], v), k) for k, v in res[False][1].items() if np.linalg.norm(v) > 1e-6)
+        assert worst[0] <= 2e-5, worst
+    else:
+        # bf16 storage: a 1e-7 change of a BN's coefficients re-rounds a few of its dx elements by one bf16 ulp, and 50 layers amplify
+        # that about as much as they amplify fp32 rounding above (x 200).  Measured: whole gradient 4.5e-3, tensors <= 1e-2 except the
+        # stem's beta (a sum that nearly cancels) at 8e-2 — hence the aggregate criteria of test_resnet_step_bf16.
+        flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in sorted(res[False][1])])
+        assert rel_l2(flat(res[True][1]), flat(res[False][1])) <= 2e-2
+        worst = min((cosine(res[True][1][k], v), k) for k, v in res[False][1].items() if np.linalg.norm(v) > 1e-6)
+        assert worst[0] >= 0.99, worst
+
+
 def cosine(a, b):
     a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
     return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))

@@ -995,3 +995,66 @@ def test_projection_shortcut_bn_folded_into_consumer(shape, dtype):
     np.testing.assert_array_equal(k.cpu().numpy(), k_ref.cpu().numpy())
     for a, b in zip(st_s2 + st_m2, st_s + st_m):
         np.testing.assert_array_equal(u.host(a), u.host(b))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 256, 1, 1),        # bottleneck conv_2 (1x1): its dgrad produces BN1's dy
+                                  (3, 14, 14, 64, 64, 3, 1),         # conv_1 (3x3): BN0's dy (fp32: the window kernel)
+                                  (2, 16, 16, 128, 128, 3, 2),       # stride 2: four parity launches share the partial rows
+                                  (2, 9, 11, 72, 40, 3, 1),          # ragged tiles
+                                  (8, 16, 16, 8, 8, 3, 1),           # one 16-byte chunk of channels (the width-reduced test networks)
+                                  (8, 16, 16, 8, 32, 1, 1),
+                                  (40, 28, 28, 128, 128, 3, 1)])     # fp32: stream-K tail in the same launch
+def test_dgrad_accumulates_bn_backward_sums(case, dtype):
+    """mcn_conv2d_dgrad_bnred: dx as mcn_conv2d_dgrad, plus partial rows whose column sums are sum dy' and sum dy' * x (dy' = the stored dx
+    where the forward's ReLU bit is set); mcn_bn_bwd_from_partials then gives the BN backward of mcn_bn_bwd (reduction order aside)."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k, s = case
+    xbn = (1.2 * RNG.standard_normal((n, h, w_, cin)) + 0.2).astype(np.float32)      # the BN's input (= output of the conv in front)
+    gamma = (0.5 + RNG.random(cin)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(cin)).astype(np.float32)
+    fw = u.bn_fwd_train(xbn, gamma, beta, 1e-3, dtype, act=1, want_mask=True)
+    wt = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    g = u.geom(xbn.shape, wt.shape, s, 'SAME')
+    oh, ow = O.out_size(h, k, s, 'SAME', 1), O.out_size(w_, k, s, 'SAME', 1)
+    dy = RNG.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    rows = lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(g), u.MDT[dtype])
+    assert rows > 0
+    dx_ref = u.conv_dgrad(dy, wt, xbn.shape, s, 'SAME', 1, dtype)
+    dyd, wd, xd = u.dev(dy, dtype), u.dev(wt), u.dev(xbn, dtype)
+    mk = torch.as_tensor(fw['relu_mask']).to(u.DEV)
+    dx = torch.full(xbn.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    part = torch.full((rows, 2, cin), float('nan'), dtype=torch.float32, device=u.DEV)
+    ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype]))
+    _ffi.check(lib.mcn_conv2d_dgrad_bnred(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), xd.data_ptr(), mk.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC,
+                                          ws.data_ptr(), ws.numel() * 4, u.stream()))
+    np.testing.assert_array_equal(u.host(dx), dx_ref)
+    p = u.host(part).astype(np.float64)
+    assert not np.isnan(p).any()
+    ce = 4 if dtype == 'float32' else 8
+    bits = np.unpackbits(fw['relu_mask'][:n * h * w_ * (cin // ce)].reshape(-1, cin // ce, 1), axis=2, bitorder='little')[:, :, :ce].reshape(-1, cin).astype(np.float64)
+    np.testing.assert_array_equal(bits, (fw['y'].reshape(-1, cin) > 0).astype(np.float64))
+    dxm = dx_ref.reshape(-1, cin).astype(np.float64) * bits
+    xq = q(xbn, dtype).reshape(-1, cin)
+    np.testing.assert_allclose(p[:, 0].sum(0), dxm.sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm).sum(0).max())
+    np.testing.assert_allclose(p[:, 1].sum(0), (dxm * xq).sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm * xq).sum(0).max())
+    # the BN backward from those rows against the three-pass kernel
+    m = n * h * w_
+    gd, bd, sm, si = u.dev(gamma), u.dev(beta), u.dev(fw['save_mean']), u.dev(fw['save_invstd'])
+    bws = u.workspace(lib.mcn_bn_workspace_bytes(m, cin))
+
+    def run(fn, *extra):
+        o = torch.full(xbn.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        dg, db = torch.zeros(cin, device=u.DEV), torch.zeros(cin, device=u.DEV)
+        fn(o, dg, db)
+        return u.host(o), u.host(dg), u.host(db)
+    a = run(lambda o, dg, db: _ffi.check(lib.mcn_bn_bwd(dx.data_ptr(), xd.data_ptr(), 0, mk.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), o.data_ptr(), 0,
+                                                        dg.data_ptr(), db.data_ptr(), 0.5, m, cin, 1, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, u.stream())))
+    b = run(lambda o, dg, db: _ffi.check(lib.mcn_bn_bwd_from_partials(dx.data_ptr(), xd.data_ptr(), mk.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                                                                      part.data_ptr(), rows, o.data_ptr(), dg.data_ptr(), db.data_ptr(), 0.5, m, cin, u.MDT[dtype],
+                                                                      bws.data_ptr(), bws.numel() * 4, u.stream())))
+    check(b[0], a[0], dtype, 'dx from partials', rel=2e-5 if dtype == 'float32' else 4e-3)
+    check(b[1], a[1], 'float32', 'dgamma', rel=1e-4)
+    check(b[2], a[2], 'float32', 'dbeta', rel=1e-4)
