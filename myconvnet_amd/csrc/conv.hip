@@ -538,13 +538,29 @@ static bool tn_nw8(size_t es) {
     return v < 0 ? es == 2 : v != 0;
 }
 template <typename T>
-static int launch_tn(const GemmTNParams& p, bool linear, int splits, int forced_tile, hipStream_t st) {
+static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forced_tile, hipStream_t st) {
     int BR, BN;
-    tn_tile(p.rows, p.Nn, DtypeOf<T>::value, linear, forced_tile, &BR, &BN);
-    const int tiles = ((p.rows + BR - 1) / BR) * ((p.Nn + BN - 1) / BN);
+    tn_tile(p_in.rows, p_in.Nn, DtypeOf<T>::value, linear, forced_tile, &BR, &BN);
+    const int tiles = ((p_in.rows + BR - 1) / BR) * ((p_in.Nn + BN - 1) / BN);
     const bool nw8 = BR == 128 && BN == 128 && tn_nw8(sizeof(T));
     const dim3 grid(tiles, splits), block(nw8 || BR == 256 ? 512 : 256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
+    // XCD-aware order (conv_gemm_tn): the tiles of a split run next to each other on one XCD.  Measured per layer (B = 256, serial
+    // launches): bf16 28x28 128ch 3x3 123 -> 83 us, 56x56 128ch 3x3 / 2 130 -> 99, the 1x1 layers with 4-16 tiles per split -12...-30 %,
+    // fp32 1x1 layers with 4-8 tiles -3...-7 %; the 3x3 layers with 256+ channels (36+ tiles per split, 15-30 long splits) LOSE 10-12 % in
+    // both types, also with the tiles in sub-groups of 8 / 16 / 32 (MCN_TN_GRP), and the 1x1 layers with 64+ tiles are a wash: so the
+    // order is used up to 16 tiles per split (32 for one-tap filters).  MCN_TN_GRP=0: off; N: sub-groups of N wherever splits > 1.
+    static const int grp_env = [] { const char* e = getenv("MCN_TN_GRP"); return e ? atoi(e) : -1; }();
+    GemmTNParams p = p_in;
+    p.grp = 0;
+    if (splits > 1) {
+        if (grp_env > 0) {
+            const int nch = (tiles + grp_env - 1) / grp_env;
+            p.grp = (tiles + nch - 1) / nch;
+        } else if (grp_env < 0 && tiles <= (p.ntaps == 1 ? 32 : 16)) {
+            p.grp = tiles;
+        }
+    }
 #define MCN_LAUNCH_TN(BRV, BNV, LINV, NWV)                                           \
     do {                                                                             \
         const int lds = 2 * KP * (BRV + BNV) * (int)sizeof(T);                       \

@@ -79,6 +79,7 @@ struct GemmTNParams {
     int nsteps, steps_per_split;
     unsigned x_bytes, dy_bytes;
     int dbg;                // DEBUG probes (MCN_TN_DBG): 1 = X staged for the first K-step only, 2 = DY likewise (wrong results, timing only)
+    int grp;                // > 0: XCD-aware order — groups of grp tiles of one split next to each other on one XCD
     signed char tdy[MCN_MAX_TAPS];
     signed char tdx[MCN_MAX_TAPS];
 };
@@ -1341,8 +1342,20 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int ntn = (p.Nn + BN - 1) / BN;
-    const int r0 = (blockIdx.x / ntn) * BR, n0 = (blockIdx.x % ntn) * BN;
-    const int split = blockIdx.y;
+    // the tiles of one split (all taps / channel blocks over the same pixel range) read the same dy rows and overlapping x rows: keep
+    // groups of p.grp of them on one XCD, next to each other in its dispatch order, so that its L2 serves all but the first of a group
+    // (order: group of tiles, split, tile in the group; every group but the last has exactly p.grp tiles)
+    int tile = blockIdx.x, split = blockIdx.y;
+    if (p.grp > 0) {
+        const int nt = gridDim.x, ns = gridDim.y;
+        const int L = xcd_remap(blockIdx.y * nt + blockIdx.x, nt * ns);
+        const int k = L / (ns * p.grp);
+        const int rem = L - k * ns * p.grp;
+        const int sz = min(p.grp, nt - k * p.grp);
+        split = rem / sz;
+        tile = k * p.grp + rem - split * sz;
+    }
+    const int r0 = (tile / ntn) * BR, n0 = (tile % ntn) * BN;
     const int ks0 = split * p.steps_per_split;
     const int ks1 = min(p.nsteps, ks0 + p.steps_per_split);
 
