@@ -145,6 +145,38 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
     if (splits > nsteps) splits = nsteps;
     if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
+    static const int model = [] { const char* e = getenv("MCN_TN_SPLITS"); return e ? atoi(e) : 1; }();
+    if (model > 1 || (model == 1 && BR == 128 && BN == 128 && !conv_is_linear(g))) {
+        // Whole rounds: a CU holds occ = 2 workgroups of the 128 x 128 tile (64 KB of LDS), the chip 512; a launch of W = tiles x splits
+        // workgroups runs W / slots full rounds and a tail.  A full round costs occ x (steps + c0) MFMA-bound step times per CU, a tail
+        // round ceil(rem / 256) of them (one workgroup alone on a CU does not fill its pipes: at least 1.3); c0 = slab write + read
+        // back + prologue, in steps.  Pick the split count with the lowest modelled time.  The fixed target above gave the 3x3 layers
+        // with 256+ channels 1044-1152 workgroups = two rounds + a nearly empty third: 14x14 256ch 547 -> 389 us (bf16) / 545 -> 493
+        // (fp32), 28x28 256ch / 2 127 -> 85, 7x7 512ch 112 -> 93 (serial launches, B = 256).  The smaller tiles keep the target: their
+        // 3-5 workgroups per CU are not priced well by this model (64 x 64 fp32 1x1 layers +8 %, MCN_TN_SPLITS=2 to see it).
+        int occ = (160 * 1024) / (2 * KP * (BR + BN) * (int)mcn_dtype_size(dt));
+        if (occ > 4) occ = 4;
+        const int slots = 256 * (occ < 1 ? 1 : occ);
+        const double c0 = 4.0;
+        double best = 1e30;
+        int best_s = splits;
+        const int smax = nsteps < 512 ? nsteps : 512;
+        for (int s2 = 1; s2 <= smax; ++s2) {
+            const int sps2 = (nsteps + s2 - 1) / s2;
+            const int sr = (nsteps + sps2 - 1) / sps2;          // the split count this step count really gives
+            if (sr != s2) continue;
+            const long W = (long)tiles * s2;
+            const long full = W / slots, rem = W % slots;
+            double tail = 0.0;
+            if (rem) {
+                tail = (double)((rem + 255) / 256);
+                if (tail < 1.3) tail = 1.3;
+            }
+            const double cost = ((double)full * occ + tail) * ((double)sps2 + c0);
+            if (cost < best * 0.999) { best = cost; best_s = s2; }
+        }
+        splits = best_s;
+    }
     int sps = (nsteps + splits - 1) / splits;
     if (sps < 1) sps = 1;
     splits = (nsteps + sps - 1) / sps;
