@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 TRAIN_FLOP_PER_IMAGE = 2 * (3 * (4087136256 + 2048000) - 118013952)      # 24,299,077,632
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}                             # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                                                     # HBM3E, same guide
 
 
 def parse():
@@ -390,10 +391,19 @@ def main():
         dom = max(convs.items(), key=lambda kv: kv[1][1])                 # the kernel symbol with the most time per step
         name, (cnt, ms_k, flop, alg_bytes) = dom
         ach = flop / (ms_k * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': name, 'launches_per_step': cnt, 'avg_launch_us': round(ms_k / cnt * 1e3, 2),
-                           'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
-                           'frac': round(ach / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
-                           'event_bracket_overhead_us': round(bracket_us, 2)}
+        # which roof bounds this symbol: its arithmetic intensity (FLOP per algorithmic byte) against the ridge point peak FLOP/s / peak B/s
+        # (fp32 19.7 FLOP/B, bf16 312 FLOP/B: the 1x1 layers of the 2-byte types sit under the HBM roof, every fp32 conv under the MFMA roof)
+        hbm_bound = alg_bytes > 0 and flop / alg_bytes < PEAK_TFLOPS[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+        if hbm_bound:
+            gbs = alg_bytes / (ms_k * 1e-3) / 1e9
+            out['roofline'] = {'bound': 'hbm', 'kernel': name, 'launches_per_step': cnt, 'avg_launch_us': round(ms_k / cnt * 1e3, 2),
+                               'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                               'mfma_tflops': round(ach, 2), 'event_bracket_overhead_us': round(bracket_us, 2)}
+        else:
+            out['roofline'] = {'bound': 'mfma', 'kernel': name, 'launches_per_step': cnt, 'avg_launch_us': round(ms_k / cnt * 1e3, 2),
+                               'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                               'frac': round(ach / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
+                               'event_bracket_overhead_us': round(bracket_us, 2)}
         out['roofline']['algorithmic_bytes_per_launch'] = int(alg_bytes / cnt)
         out['roofline'].update(pmc_traffic(name, args.dtype, args.batch))
         # the same figure for every conv kernel symbol (round 1's dominant symbol, the 3x3 forward AND dgrad, is several symbols now)
