@@ -65,6 +65,15 @@ struct GemmNTParams {
                             // (byte tables are fetched with vector loads whose waits drain the LDS-DMA queue)
 };
 
+// Cache policy of the LDS-DMA loads of the activation operands (build-time experiments): the aux immediate of buffer_load ... lds,
+// 2 = nt (streaming).  MCN_DMA_AUX_A: A operand of the NT kernels (activations; the packed filter stays cached); MCN_DMA_AUX_X: x and dy
+// of the wgrad.
+#ifndef MCN_DMA_AUX_A
+#define MCN_DMA_AUX_A 0
+#endif
+#ifndef MCN_DMA_AUX_X
+#define MCN_DMA_AUX_X 0
+#endif
 struct GemmTNParams {
     const void* x;
     const void* dy;
@@ -770,11 +779,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : 1)) void conv_
     auto dma = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, auto ldsc) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(wbase + decltype(ldsc)::value), 16, (int)off, 0, 0, 0);
     };
+    auto dma_act = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, auto ldsc) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(wbase + decltype(ldsc)::value), 16, (int)off, 0, 0, MCN_DMA_AUX_A);
+    };
     // setc: LDS buffer index
     auto issue = [&](int ks, auto setc) {
         constexpr int S = decltype(setc)::value;
         auto ldA = [&](auto ic, unsigned off) {
-            dma(rsA, off, std::integral_constant<int, S * TILE_BYTES + decltype(ic)::value * RPP * 128>{});
+            dma_act(rsA, off, std::integral_constant<int, S * TILE_BYTES + decltype(ic)::value * RPP * 128>{});
         };
         auto ldB = [&](auto ic, unsigned off) {
             dma(rsB, off, std::integral_constant<int, S * TILE_BYTES + BM * 128 + decltype(ic)::value * RPP * 128>{});
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbase + (S * TILE_BYTES + i * RPP * 128)), 16,
-                                                     (int)((a_off[i] + (unsigned)ks * 128u) | oob), 0, 0, 0);
+                                                     (int)((a_off[i] + (unsigned)ks * 128u) | oob), 0, 0, MCN_DMA_AUX_A);
         });
         static_for<BR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -1157,7 +1169,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_nt_win(const GemmNTParams p
                 const int q = m0 + p.win_dmin + j;                        // input pixel of window row j
                 const unsigned bad = (unsigned)q | (unsigned)(p.M - 1 - q) | (unsigned)(P - 1 - j);      // sign bits: outside the tensor / behind the window
                 const unsigned off = ((unsigned)q * (unsigned)pix_bytes + (unsigned)(cb * 128 + cidw * 16)) | ((bad >> 31) << 31);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbaseA + ps * RPP * 128), 16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbaseA + ps * RPP * 128), 16, (int)off, 0, 0, MCN_DMA_AUX_A);
             }
         });
     };
@@ -1425,14 +1437,14 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
                 if (py[i] >= p.OH) { py[i] -= p.OH; pimg[i] += 1; }
                 pimg[i] += dKi;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * (NT * 16))), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * (NT * 16))), 16, (int)off, 0, 0, MCN_DMA_AUX_X);
         });
         if (!((p.dbg & 2) && ks != ks0))
         static_for<DN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + dpr + DPR * i;
             const unsigned off = (((unsigned)m * (unsigned)p.ldy + (unsigned)dn) * (unsigned)sizeof(T)) | doob | (((unsigned)(p.M - 1 - m) >> 31) << 31);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + XBYTES + i * (NT * 16))), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + XBYTES + i * (NT * 16))), 16, (int)off, 0, 0, MCN_DMA_AUX_X);
         });
     };
     constexpr int ACCN = CF::MT == 16 ? 4 : 16;
