@@ -715,10 +715,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
 
 // ---- host ------------------------------------------------------------------------------------------
 #define BN_TARGET_BLOCKS 1024       /* upper bound of the row blocks (workspace sizing) */
-// row blocks per kernel by element size (same-box A/B of the whole ResNet-50 step: fp32 1024 > 768 > 2048; bf16 768 > 512 ~ 1024)
-#define BN_TGT_BF16 768
+// row blocks per kernel by element size (same-box A/B of the whole ResNet-50 step: fp32 1024 > 768 > 2048; bf16, since the chunk loads
+// are streaming: 1024 21.56-21.58 ms, 768 21.62-21.70, 512 21.82-21.85 — before that 768 > 512 ~ 1024)
+#define BN_TGT_BF16 1024
 template <typename T>
-static constexpr int bn_target() { return sizeof(T) == 2 ? BN_TGT_BF16 : 1024; }
+static int bn_target() {
+    static const int env = [] { const char* e = getenv("MCN_BN_TGT"); const int v = e ? atoi(e) : 0; return v > BN_TARGET_BLOCKS ? BN_TARGET_BLOCKS : v; }();   // experiments
+    return env > 0 ? env : (sizeof(T) == 2 ? BN_TGT_BF16 : 1024);
+}
 static size_t bn_parts_bytes(long M, int C) {
     // worst case over vector widths: gy <= BN_TARGET_BLOCKS
     return align_up((size_t)BN_TARGET_BLOCKS * 2 * C * sizeof(float), 256);
