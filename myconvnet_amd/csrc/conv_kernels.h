@@ -96,6 +96,13 @@ struct GemmTNParams {
 __device__ __forceinline__ i32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
 }
+// the epilogue's read of a tensor in the output's layout (residual / accumulate source, BN input): read once (MCN_EPI_AUX: 2 = nt)
+#ifndef MCN_EPI_AUX
+#define MCN_EPI_AUX 0
+#endif
+__device__ __forceinline__ i32x4 buf_load16_epi(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, MCN_EPI_AUX);
+}
 
 // ------------------------------------------------------------------------------------------------
 // MFMA policies
@@ -398,7 +405,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                 const unsigned srow = rowoff[2 * q] ^ ((rowoff[2 * q] ^ rowoff[2 * q + 1]) & oddmask);   // (a select here compiles to a stack array + indexed load)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const i32x4 w = buf_load16(rsS, sat_add(srow, coloff[j][0] - pairshift));
+                    const i32x4 w = buf_load16_epi(rsS, sat_add(srow, coloff[j][0] - pairshift));
                     const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)w[0], (unsigned)w[2], false, false);
                     const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)w[1], (unsigned)w[3], false, false);
                     prev[2 * q][j][0] = u32x2{lo[0], hi[0]};
@@ -411,7 +418,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) prev[i][j][g] = __builtin_bit_cast(typename Q::Bits, buf_load16(rsS, sat_add(rowoff[i], coloff[j][g])));
+                    for (int g = 0; g < NG; ++g) prev[i][j][g] = __builtin_bit_cast(typename Q::Bits, buf_load16_epi(rsS, sat_add(rowoff[i], coloff[j][g])));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
