@@ -2,7 +2,7 @@
 """bench.py — images/sec of the ResNet-v1.5-50 training step (forward + backward + fused Nesterov/L2/EMA update
 [+ RCCL gradient all-reduce]) on synthetic 224x224x3 batches, B = 256 per GPU, on N MI355X of one node.
 
-    python bench.py --gpus N --steps K --warmup W [--dtype fp32|bf16] [--batch 256]
+    python bench.py --gpus N --steps K --warmup W [--dtype fp32|bf16|fp16] [--batch 256]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
@@ -16,7 +16,8 @@ At N=1 the line also carries:
                  of record rides along as `numpy_port` (B=8)
   config.fetch = false: the timed step skips the reference's per-step device->host copy of Y_all / pred and the numpy
                  score (optimizers.py:590-594, :410); everything else of `_step` is inside the timed region
-  bf16         — a secondary measurement of the same step in bf16 (the north-star arithmetic), unless --dtype bf16.
+  bf16, fp16   — secondary measurements of the same step with bf16 storage (the north-star arithmetic) and with the reference's own
+                 half precision (fp16 storage, loss scaling 128), only in the default fp32 run.
 roofline.traffic = HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh; null if absent).
 --model efficientnet_b0 | deeplabv3plus: BASELINE configs[3] / configs[4] on one GPU (secondary workloads, no roofline object).
 --no-overlap: wgrad on the main stream (profiling: per-kernel averages are then not stretched by co-running kernels).
@@ -34,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TRAIN_FLOP_PER_IMAGE = 2 * (3 * (4087136256 + 2048000) - 118013952)      # 24,299,077,632
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}                             # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'fp16': 2500.0}                             # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                                                     # HBM3E, same guide
 
 
@@ -43,7 +44,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32')
+    ap.add_argument('--dtype', choices=['fp32', 'bf16', 'fp16'], default='fp32',
+                    help="fp16 = the reference's own half precision (convnet.py:63 half_precision + optimizers.py:102-111 loss scaling, factor 128)")
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 256; 512 for --model efficientnet_b0)')
     ap.add_argument('--model', default='resnet50', choices=['resnet50', 'efficientnet_b0', 'deeplabv3plus'],
                     help='resnet50 = the headline workload (BASELINE configs[1]/[2]); efficientnet_b0 = configs[3], deeplabv3plus = configs[4] on one GPU (secondary, SURVEY 8f-2 / 8f-3)')
@@ -64,10 +66,10 @@ def build_model(args, dtype, world):
     import myconvnet_amd as M
     cls = {'efficientnet_b0': M.EfficientNetB0, 'deeplabv3plus': M.DeepLabV3PlusResNet50}.get(args.model, M.ResNet50)
     size, classes = (513, 19) if args.model == 'deeplabv3plus' else (224, 1000)          # configs[4]: 513x513 synthetic Cityscapes
-    model = cls([size, size, 3], classes, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype == 'bf16'),
-                       seed=0, overlap_wgrad=not args.no_overlap, device='cuda:{}'.format(local_device()))
+    model = cls([size, size, 3], classes, batch_size=args.batch * world, num_gpus=world, half_precision=(dtype != 'fp32'),
+                       half_precision_dtype=('float16' if dtype == 'fp16' else 'bfloat16'), seed=0, overlap_wgrad=not args.no_overlap, device='cuda:{}'.format(local_device()))
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90,
-                              update_ema=not args.no_ema)
+                              update_ema=not args.no_ema, loss_scaling_factor=(128.0 if dtype == 'fp16' else 1.0))
     rank = int(os.environ.get('RANK', 0))
     rng = np.random.default_rng(1234 + rank)                               # SURVEY §8d synthetic inputs
     x = rng.random((args.batch, size, size, 3), dtype=np.float32)
@@ -151,7 +153,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     low = model._train_low
     sp = model.stream_ptr()
     ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
-    mdt = _ffi.F32 if dtype == 'fp32' else _ffi.BF16
+    mdt = {'fp32': _ffi.F32, 'bf16': _ffi.BF16, 'fp16': _ffi.F16}[dtype]
     buf = ctypes.create_string_buffer(128)
     lbuf = ctypes.create_string_buffer(1024)
     table, rows = {}, {}
@@ -361,7 +363,7 @@ def main():
         title = {'efficientnet_b0': ('EfficientNet-B0', 224, 'configs[3]'), 'deeplabv3plus': ('DeepLabv3+ (ResNet-50 OS16 backbone)', 513, 'configs[4]')}[args.model]
         out = {'metric': 'images/sec {} {}x{} synthetic training step'.format(title[0], title[1], title[1]), 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+               'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[args.dtype], 'data': 'synthetic',
                'config': {'workload': '{} {} {}x{} synthetic training step (BASELINE {}), batch={}/GPU'.format(title[0], args.dtype, title[1], title[1], title[2], args.batch),
                           'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world), 'ema': not args.no_ema, 'fetch': False},
                'conv_macs_per_image': int(model.conv_macs), 'params': int(model.params)}
@@ -377,7 +379,7 @@ def main():
         'metric': 'images/sec ResNet-v1.5-50 224x224 synthetic training step',
         'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+        'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[args.dtype], 'data': 'synthetic',
         'config': {'workload': 'ResNet-v1.5-50 {} 224x224 synthetic ImageNet-1k training step (fwd+bwd+Nesterov/L2/EMA), batch={}/GPU'
                    .format(args.dtype, args.batch), 'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world),
                    'ema': not args.no_ema, 'fetch': False},
@@ -426,6 +428,12 @@ def main():
             ips2 = args.batch * args.steps / dt2
             out['bf16'] = {'value': round(ips2, 2), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
                            'e2e_mfma_frac': round(ips2 * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS['bf16'] * 1e12), 4)}
+            del m2, o2
+            torch.cuda.empty_cache()
+            # the reference's own half precision: fp16 storage + loss scaling (same kernels, the f16 MFMA instead of the bf16 one)
+            m2, o2 = build_model(a2, 'fp16', 1)
+            dt2 = timed(o2, args.steps, args.warmup, 1, args.autotune)
+            out['fp16'] = {'value': round(args.batch * args.steps / dt2, 2), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3), 'loss_scaling_factor': 128.0}
             del m2, o2
             torch.cuda.empty_cache()
             # the other single-GPU configurations of BASELINE.json as secondary keys (short runs; `--model ...` gives the full line)

@@ -710,7 +710,8 @@ __device__ __forceinline__ void nt_init_acc(typename MmaNT<T>::Acc (&acc)[TN][TM
 // minimum waves per SIMD the register allocator must leave room for: the 8-wave 128x128 tile exists to put two workgroups
 // (4 waves per SIMD) on a CU; everything else takes what it gets
 template <typename T, int BM, int BN, int MODE, int NW = 4, int EPI = NT_EPI_STORE>
-__global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : 1)) void conv_gemm_nt(const GemmNTParams p) {
+// (2-byte 128 x 128 tiles: two workgroups per CU by LDS — keep the registers there too; the fp16 statistics epilogue had drifted to 304)
+__global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : (sizeof(T) == 2 && BM == 128 && BN == 128 ? 2 : 1))) void conv_gemm_nt(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int CE = VecTraits<T>::CE;
     constexpr bool TAPS = MODE != NT_LINEAR;
@@ -1121,7 +1122,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2
 // ------------------------------------------------------------------------------------------------
 #define MCN_WIN_MAXPASS 16
 template <typename T, int BM, int BN, int NW, int EPI>
-__global__ __launch_bounds__(NW * 64) void conv_gemm_nt_win(const GemmNTParams p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && NW == 4 && BM == 128 && BN == 128 ? 2 : 1)) void conv_gemm_nt_win(const GemmNTParams p) {
     typedef MmaNT<T> MM;
     constexpr int NT = NW * 64, RPP = NT / 8, WROWS = NW / 2;
     constexpr int BR = BN / RPP;
