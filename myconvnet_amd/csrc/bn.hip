@@ -304,8 +304,10 @@ __device__ __forceinline__ float swish_grad(float z) {
 // RELU == 3: swish, dz = dy * (s + z*s*(1-s)), s = sigmoid(z), z recomputed from x the same way (no residual).
 // RELU == 4: mask from the bit mask the forward apply pass wrote (one byte per 16-byte chunk; `y` then points to it):
 //            1/16 of the bytes of reading y itself — used for the BNs with a fused residual.
+// (4 waves per SIMD: the grid is 1024 blocks = 4 per CU; the 2-byte variants with a y-based mask / swish had compiled to 132-155
+// registers, i.e. 3 blocks per CU and a second, third-full round)
 template <typename T, int VEC, int RELU>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+__global__ __launch_bounds__(256, 4) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ part, long M, int C, int TX, int TY, long rpb) {
