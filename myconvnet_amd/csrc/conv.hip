@@ -127,6 +127,12 @@ static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int forced, i
     *br = rows <= 64 ? 64 : 128;
     *bn = Cout <= 64 ? 64 : 128;
 }
+// three-stage LDS ring (conv_gemm_tn3, 8 waves, one workgroup per CU) for the fp32 128 x 128 tile: MCN_TN_RING 0 = off, 1 = gathered
+// (3x3 / strided) wgrads, 2 = every fp32 128 x 128 wgrad
+static bool tn_ring(size_t es, int BR, int BN, bool linear) {
+    static const int v = [] { const char* e = getenv("MCN_TN_RING"); return e ? atoi(e) : 0; }();
+    return v > 0 && es == 4 && BR == 128 && BN == 128 && (!linear || v > 1);
+}
 static inline bool conv_is_linear(const Geo& g) {
     return g.KH * g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
 }
@@ -154,7 +160,7 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
         // with 256+ channels 1044-1152 workgroups = two rounds + a nearly empty third: 14x14 256ch 547 -> 389 us (bf16) / 545 -> 493
         // (fp32), 28x28 256ch / 2 127 -> 85, 7x7 512ch 112 -> 93 (serial launches, B = 256).  The smaller tiles keep the target: their
         // 3-5 workgroups per CU are not priced well by this model (64 x 64 fp32 1x1 layers +8 %, MCN_TN_SPLITS=2 to see it).
-        int occ = (160 * 1024) / (2 * KP * (BR + BN) * (int)mcn_dtype_size(dt));
+        int occ = (160 * 1024) / ((tn_ring(mcn_dtype_size(dt), BR, BN, conv_is_linear(g)) ? 3 : 2) * KP * (BR + BN) * (int)mcn_dtype_size(dt));
         if (occ > 4) occ = 4;
         const int slots = 256 * (occ < 1 ? 1 : occ);
         const double c0 = 4.0;
@@ -574,8 +580,9 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
     int BR, BN;
     tn_tile(p_in.rows, p_in.Nn, DtypeOf<T>::value, linear, forced_tile, &BR, &BN);
     const int tiles = ((p_in.rows + BR - 1) / BR) * ((p_in.Nn + BN - 1) / BN);
+    const bool ring = tn_ring(sizeof(T), BR, BN, linear);
     const bool nw8 = BR == 128 && BN == 128 && tn_nw8(sizeof(T));
-    const dim3 grid(tiles, splits), block(nw8 || BR == 256 ? 512 : 256);
+    const dim3 grid(tiles, splits), block(nw8 || ring || BR == 256 ? 512 : 256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
     // XCD-aware order (conv_gemm_tn): the tiles of a split run next to each other on one XCD.  Measured per layer (B = 256, serial
     // launches): bf16 28x28 128ch 3x3 123 -> 83 us, 56x56 128ch 3x3 / 2 130 -> 99, the 1x1 layers with 4-16 tiles per split -12...-30 %,
@@ -604,7 +611,20 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
     do {                                                             \
         if (linear) MCN_LAUNCH_TN(BRV, BNV, true, NWV); else MCN_LAUNCH_TN(BRV, BNV, false, NWV); \
     } while (0)
-    if (BR == 256) {
+    if (ring) {
+        if constexpr (sizeof(T) == 4) {
+            const int lds = 3 * KP * (128 + 128) * (int)sizeof(T);
+            if (linear) {
+                static bool once = (allow_lds(conv_gemm_tn3<T, 128, 128, true, 8>, lds), true);
+                (void)once;
+                hipLaunchKernelGGL((conv_gemm_tn3<T, 128, 128, true, 8>), grid, block, lds, st, p);
+            } else {
+                static bool once = (allow_lds(conv_gemm_tn3<T, 128, 128, false, 8>, lds), true);
+                (void)once;
+                hipLaunchKernelGGL((conv_gemm_tn3<T, 128, 128, false, 8>), grid, block, lds, st, p);
+            }
+        }
+    } else if (BR == 256) {
         if constexpr (sizeof(T) == 2) MCN_LAUNCH_TN_LIN(256, 256, 8);
         else MCN_FAIL(MCN_E_UNSUPPORTED, "conv: the 256x256 wgrad tile is for the 2-byte types");
     } else if (nw8) MCN_LAUNCH_TN_LIN(128, 128, 8);
@@ -1314,7 +1334,8 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
-    snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 256 || (br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype))) ? 8 : 4);
+    if (tn_ring(mcn_dtype_size(dtype), br, bn, conv_is_linear(g))) snprintf(buf, buflen, "conv_gemm_tn3<%s, 128, 128, %s, 8>", tn, conv_is_linear(g) ? "true" : "false");
+    else snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 256 || (br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype))) ? 8 : 4);
     return 1;
 }
 

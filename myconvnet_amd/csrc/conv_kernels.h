@@ -1340,8 +1340,11 @@ __device__ __forceinline__ int tn_key(int p) { return (p & 3) | (((p >> 3) & 1) 
 // NW waves per workgroup: 4 = 2x2 waves; 8 = 4x2 waves on the same tile (wave tile BR/4 x BN/2): the 128x128 tile needs 64 KB of LDS,
 // i.e. two workgroups per CU — with 4 waves each a SIMD holds 2 waves and its MFMA pipe idles whenever both sit at the
 // barrier / DMA wait (fp32: 69 % busy by SQ_VALU_MFMA_BUSY_CYCLES); 8 waves put 4 on every SIMD at the same tile traffic.
-template <typename T, int BR, int BN, bool LINEAR, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
+// STAGES = 3: a ring of three LDS buffers — the DMA of K-step k+2 is issued at K-step k, two steps of MFMAs cover its latency and the
+// wait in front of a step is `vmcnt(DMAs of one stage)`, not vmcnt(0).  (conv_gemm_tn3: 96 KB for the fp32 128 x 128 tile, one
+// 8-wave workgroup per CU.)
+template <typename T, int BR, int BN, bool LINEAR, int NW, int STAGES>
+__device__ __forceinline__ void tn_body(const GemmTNParams& p) {
     typedef TNCfg<T> CF;
     constexpr int CE = VecTraits<T>::CE;
     constexpr int KP = CF::KP;
@@ -1469,9 +1472,18 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
     // one K-step (KP pixels) from LDS buffer `buf`; the DMA of the next step goes to the other buffer right after the
     // barrier that retires its readers and flies under this step's MFMAs
     auto kstep = [&](int ks, auto cur, auto nxt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (ks + 1 < ks1) issue(ks + 1, nxt);
+        if constexpr (STAGES == 3) {
+            // `nxt` is the buffer of step ks + 2 (read last in step ks - 1: every wave is past that once it reaches this barrier);
+            // step ks + 1's DMAs, issued one step ago, may stay in flight (loads retire in issue order)
+            if (ks + 1 < ks1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XN + DN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ks + 2 < ks1) issue(ks + 2, nxt);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ks + 1 < ks1) issue(ks + 1, nxt);
+        }
         const char* xs = smem + decltype(cur)::value * TILE_BYTES;
         const char* ds = xs + XBYTES;
         if constexpr (sizeof(T) == 2) {
@@ -1532,10 +1544,21 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
             }
         }
     };
-    if (ks0 < ks1) issue(ks0, B0{});
-    for (int ks = ks0; ks < ks1; ks += 2) {
-        kstep(ks, B0{}, B1{});
-        if (ks + 1 < ks1) kstep(ks + 1, B1{}, B0{});
+    if constexpr (STAGES == 3) {
+        typedef std::integral_constant<int, 2> B2;
+        if (ks0 < ks1) issue(ks0, B0{});
+        if (ks0 + 1 < ks1) issue(ks0 + 1, B1{});
+        for (int ks = ks0; ks < ks1; ks += 3) {
+            kstep(ks, B0{}, B2{});
+            if (ks + 1 < ks1) kstep(ks + 1, B1{}, B0{});
+            if (ks + 2 < ks1) kstep(ks + 2, B2{}, B1{});
+        }
+    } else {
+        if (ks0 < ks1) issue(ks0, B0{});
+        for (int ks = ks0; ks < ks1; ks += 2) {
+            kstep(ks, B0{}, B1{});
+            if (ks + 1 < ks1) kstep(ks + 1, B1{}, B0{});
+        }
     }
 
     // ---- store the partial tile to this split's slab (row-major [rows][Nn]) --------------------
@@ -1558,6 +1581,15 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
                 const int n = n0 + wc * WTN + j * CF::MT + col;
                 if (r < p.rows && n < p.Nn) slab[(size_t)r * p.Nn + n] = acc[i][j][e];
             }
+}
+
+template <typename T, int BR, int BN, bool LINEAR, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
+    tn_body<T, BR, BN, LINEAR, NW, 2>(p);
+}
+template <typename T, int BR, int BN, bool LINEAR, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_tn3(const GemmTNParams p) {
+    tn_body<T, BR, BN, LINEAR, NW, 3>(p);
 }
 
 // dw[t][c][n] = scale * sum_split slab[split][t*Cp + c][n]   (c < Cin).  16 outputs x 16 split lanes per block (the stem: 9408
