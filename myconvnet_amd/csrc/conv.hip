@@ -130,8 +130,10 @@ static void tn_tile(int rows, int Cout, mcn_dtype dt, bool linear, int forced, i
 // three-stage LDS ring (conv_gemm_tn3, 8 waves, one workgroup per CU) for the fp32 128 x 128 tile: MCN_TN_RING 0 = off, 1 = gathered
 // (3x3 / strided) wgrads, 2 = every fp32 128 x 128 wgrad
 static bool tn_ring(size_t es, int BR, int BN, bool linear) {
-    static const int v = [] { const char* e = getenv("MCN_TN_RING"); return e ? atoi(e) : 0; }();
-    return v > 0 && es == 4 && BR == 128 && BN == 128 && (!linear || v > 1);
+    static const int v = [] { const char* e = getenv("MCN_TN_RING"); return e ? atoi(e) : 0; }();      // bits: 1 gathered 128x128, 2 linear 128x128, 4 the 64x64 tile (48 KB: three workgroups per CU)
+    if (es != 4) return false;
+    if (BR == 128 && BN == 128) return (v & (linear ? 2 : 1)) != 0;
+    return BR == 64 && BN == 64 && (v & 4) != 0;
 }
 static inline bool conv_is_linear(const Geo& g) {
     return g.KH * g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
@@ -582,7 +584,7 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
     const int tiles = ((p_in.rows + BR - 1) / BR) * ((p_in.Nn + BN - 1) / BN);
     const bool ring = tn_ring(sizeof(T), BR, BN, linear);
     const bool nw8 = BR == 128 && BN == 128 && tn_nw8(sizeof(T));
-    const dim3 grid(tiles, splits), block(nw8 || ring || BR == 256 ? 512 : 256);
+    const dim3 grid(tiles, splits), block(nw8 || (ring && BR == 128) || BR == 256 ? 512 : 256);
     const int KP = sizeof(T) == 4 ? 32 : 64;
     // XCD-aware order (conv_gemm_tn): the tiles of a split run next to each other on one XCD.  Measured per layer (B = 256, serial
     // launches): bf16 28x28 128ch 3x3 123 -> 83 us, 56x56 128ch 3x3 / 2 130 -> 99, the 1x1 layers with 4-16 tiles per split -12...-30 %,
@@ -611,7 +613,13 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
     do {                                                             \
         if (linear) MCN_LAUNCH_TN(BRV, BNV, true, NWV); else MCN_LAUNCH_TN(BRV, BNV, false, NWV); \
     } while (0)
-    if (ring) {
+    if (ring && BR == 64) {
+        if constexpr (sizeof(T) == 4) {
+            const int lds = 3 * KP * (64 + 64) * (int)sizeof(T);
+            if (linear) hipLaunchKernelGGL((conv_gemm_tn3<T, 64, 64, true, 4>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((conv_gemm_tn3<T, 64, 64, false, 4>), grid, dim3(256), lds, st, p);
+        }
+    } else if (ring) {
         if constexpr (sizeof(T) == 4) {
             const int lds = 3 * KP * (128 + 128) * (int)sizeof(T);
             if (linear) {
@@ -1334,7 +1342,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
-    if (tn_ring(mcn_dtype_size(dtype), br, bn, conv_is_linear(g))) snprintf(buf, buflen, "conv_gemm_tn3<%s, 128, 128, %s, 8>", tn, conv_is_linear(g) ? "true" : "false");
+    if (tn_ring(mcn_dtype_size(dtype), br, bn, conv_is_linear(g))) snprintf(buf, buflen, "conv_gemm_tn3<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 128 ? 8 : 4);
     else snprintf(buf, buflen, "conv_gemm_tn<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 256 || (br == 128 && bn == 128 && tn_nw8(mcn_dtype_size(dtype))) ? 8 : 4);
     return 1;
 }
