@@ -87,7 +87,7 @@ struct GemmTNParams {
     int Nn, ldy;
     int nsteps, steps_per_split;
     unsigned x_bytes, dy_bytes;
-    int dbg;                // DEBUG probes (MCN_TN_DBG): 1 = X staged for the first K-step only, 2 = DY likewise (wrong results, timing only)
+    int dbg;                // DEBUG probes (MCN_TN_DBG): 1 = X staged for the first K-step only, 2 = DY likewise (wrong results, timing only); 32 = early DMA issue (correct results)
     int grp;                // > 0: XCD-aware order — groups of grp tiles of one split next to each other on one XCD
     signed char tdy[MCN_MAX_TAPS];
     signed char tdx[MCN_MAX_TAPS];
@@ -1479,6 +1479,17 @@ __device__ __forceinline__ void tn_body(const GemmTNParams& p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (ks + 2 < ks1) issue(ks + 2, nxt);
+        } else if (p.dbg & 32) {
+            // early issue: the next step's DMAs do not wait for THIS step's data — barrier (everybody has finished reading `nxt`), issue,
+            // then wait for this step's DMAs only (the ones just issued stay in flight) and a second barrier to see the other threads' data
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ks + 1 < ks1) {
+                issue(ks + 1, nxt);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XN + DN) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
