@@ -602,10 +602,14 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
             p.grp = tiles;
         }
     }
+    // MCN_TN_LDS_KB (experiment): request at least this much LDS per wgrad workgroup — caps the workgroups per CU (81: one, 54: two) so
+    // that the side stream's wgrad leaves LDS to the main stream's kernels
+    static const int lds_floor = [] { const char* e = getenv("MCN_TN_LDS_KB"); return e ? atoi(e) * 1024 : 0; }();
 #define MCN_LAUNCH_TN(BRV, BNV, LINV, NWV)                                           \
     do {                                                                             \
-        const int lds = 2 * KP * (BRV + BNV) * (int)sizeof(T);                       \
-        static bool once = (allow_lds(conv_gemm_tn<T, BRV, BNV, LINV, NWV>, 2 * KP * (BRV + BNV) * (int)sizeof(T)), true); \
+        int lds = 2 * KP * (BRV + BNV) * (int)sizeof(T);                             \
+        if (lds < lds_floor) lds = lds_floor;                                        \
+        static bool once = (allow_lds(conv_gemm_tn<T, BRV, BNV, LINV, NWV>, 160 * 1024), true); \
         (void)once;                                                                  \
         hipLaunchKernelGGL((conv_gemm_tn<T, BRV, BNV, LINV, NWV>), grid, block, lds, st, p); \
     } while (0)
