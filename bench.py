@@ -410,7 +410,9 @@ def main():
         out['roofline'].update(pmc_traffic(name, args.dtype, args.batch))
         # the same figure for every conv kernel symbol (round 1's dominant symbol, the 3x3 forward AND dgrad, is several symbols now)
         out['roofline_by_kernel'] = {k: {'launches_per_step': v[0], 'ms_per_step': round(v[1], 3), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1),
-                                         'frac': round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 3)}
+                                         'frac': round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 3),
+                                         'gbs': round(v[3] / (v[1] * 1e-3) / 1e9, 0), 'algorithmic_bytes_per_launch': int(v[3] / max(v[0], 1)),
+                                         'traffic': pmc_traffic(k, args.dtype, args.batch).get('traffic')}
                                      for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])[:8] if v[1] > 0}
         tot = sum(v[1] for v in table.values())
         out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 12)]}
