@@ -148,7 +148,10 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
     const int tiles = ((rows + BR - 1) / BR) * ((g.Cout + BN - 1) / BN);
     // workgroups in total: ~4 per CU in fp32; bf16 (2-3 resident per CU, HBM-side bound) prefers fewer, longer splits — same-box
     // A/B of the whole step: 1536 / 1024 / 768 -> fp32 73.1 / 72.5 / 73.2 ms, bf16 25.6 / 25.4 / 25.1 ms; 512 / 256 -> bf16 24.95 / 25.2 ms
-    const int target = dt == MCN_F32 ? 1024 : 512;
+    static const int target_env = [] { const char* e = getenv("MCN_TN_TARGET"); return e ? atoi(e) : 0; }();      // experiments
+    // (re-measured at the end of round 2, XCD-aware order and streaming BN loads in place: bf16 384 / 512 / 768 / 1024 -> 21.45-21.61 /
+    // 21.26-21.54 / 21.19-21.44 / 21.73 ms; fp32 768 ... 1536 within 0.2 %)
+    const int target = target_env > 0 ? target_env : (dt == MCN_F32 ? 1024 : 768);
     int splits = (target + tiles - 1) / tiles;
     if (splits > nsteps) splits = nsteps;
     if (splits > 512) splits = 512;
