@@ -183,7 +183,7 @@ int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const
  * of the layer output less per BN; same tf.nn.fused_batch_norm semantics, convnet.py:1883-1914).  Caller-owned buffer.
  * *rows_per_partial == 0 on return announces COUNTED rows: [rows][4][Cout] fp32 — sum(y-p), sum((y-p)^2), p and the number of
  * pixel rows summed (the launch runs as persistent workgroups, each keeps its sums across all the tiles it walks and writes
- * one row per wave row at the end; a row's pixels are not a contiguous range).  Size the buffer for 4 planes per row and
+ * one row at the end; a row's pixels are not a contiguous range).  Size the buffer for 4 planes per row and
  * hand rows_per_partial through to mcn_bn_fwd_train_fused unchanged. */
 int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* geom, mcn_dtype dtype, int32_t* rows_per_partial);
 int mcn_conv2d_fwd_bnstats(const void* x, const float* w_hwio, const void* w_packed, const float* bias, void* y,

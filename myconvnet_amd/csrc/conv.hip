@@ -770,14 +770,14 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     const NtTile* cand = kNtCand;
     const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
     const int wrows = cand[t].nw / 2;
-    // counted rows (rows_per_partial = 0): one row per persistent workgroup and wave row, [4][Cout] floats each
+    // counted rows (rows_per_partial = 0): one row per persistent workgroup (its wave rows are merged in the flush), [4][Cout] floats each
     const int ce = ce_of(dtype), cpt = round_up(g.Cin, ce) / ce;
     const int mode = conv_is_linear(g) ? NT_LINEAR : NT_UNIFORM;
     long grid = 0;
     const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
                          : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
                                             : nt_stats_counted<bf16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid);
-    if (counted) return (int32_t)(wrows * grid);
+    if (counted) return (int32_t)grid;
     if (rows_per_partial) *rows_per_partial = cand[t].bm / wrows;
     return (int32_t)(wrows * ((M + cand[t].bm - 1) / cand[t].bm));
 }

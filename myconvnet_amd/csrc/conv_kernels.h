@@ -631,13 +631,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     }
 }
 
-// end of a persistent workgroup with carried statistics: fold the lanes once and write the counted partial row(s)
-// stats[(prow * 4 + {0,1,2,3}) * Nn + n] = sum(y - p), sum((y - p)^2), p, pixel rows summed; prow = workgroup * wave rows + wave row
+// end of a persistent workgroup with carried statistics: fold the lanes once, merge the wave rows through LDS and write ONE counted
+// partial row per workgroup: stats[(prow * 4 + {0,1,2,3}) * Nn + n] = sum(y - p), sum((y - p)^2), p, pixel rows summed; prow = workgroup.
+// Wave row w > 0 summed around its own pivot p_w: with d = p_w - p_0, sum(y - p_0) = s1_w + n_w d and
+// sum((y - p_0)^2) = s2_w + 2 d s1_w + n_w d^2 (d is of the order of the standard deviation: no cancellation added).
 template <typename T, int BM, int BN, int NW>
 __device__ __forceinline__ void nt_stats_flush(const GemmNTParams& p, NtStatsCarry<T, BN / 2 / MmaNT<T>::MT>& st, const int n0, const int lane,
-                                               const int wm, const int wn, const int prow) {
+                                               const int wm, const int wn, const int prow, char* smem) {
     typedef MmaNT<T> MM;
-    constexpr int WTN = BN / 2, TN = WTN / MM::MT;
+    constexpr int WROWS = NW / 2, WTN = BN / 2, TN = WTN / MM::MT;
     constexpr int NG = (int)(sizeof(typename MM::Acc) / 16);
     constexpr int V = TN * NG * 4;
     const int fr = MM::frag_row(lane);
@@ -654,6 +656,34 @@ __device__ __forceinline__ void nt_stats_flush(const GemmNTParams& p, NtStatsCar
     int base = 0;
     bool writer = true;
     LaneFold<V, MM::MT / 2>::run(a, b, lane, base, writer);
+    // the pivot of the channel whose totals this lane ended up with (flat index `base` in (j, g, e) order)
+    float pv = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv = ((j * NG + g) * 4 + e) == base ? st.piv[j][g][e] : pv;
+    float* const sh = reinterpret_cast<float*>(smem);                  // [WROWS - 1][2][64][4] floats: s1, s2, pivot, count
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has left the K loop's LDS tiles
+    if (wm > 0) {
+        float* d = sh + ((((wm - 1) * 2 + wn) * 64 + lane) << 2);
+        d[0] = a[0]; d[1] = b[0]; d[2] = pv; d[3] = st.have ? st.count : 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wm != 0) return;
+    float count = st.count;
+#pragma unroll
+    for (int w = 1; w < WROWS; ++w) {
+        const float* d = sh + ((((w - 1) * 2 + wn) * 64 + lane) << 2);
+        const float n1 = d[3];
+        if (n1 > 0.f) {                                                // (uniform per wave: a wave row without pixel rows has no pivot)
+            const float dp = d[2] - pv;
+            a[0] += d[0] + n1 * dp;
+            b[0] += d[1] + 2.f * dp * d[0] + n1 * dp * dp;
+            count += n1;
+        }
+    }
     // a row spans all Nn channels but this workgroup owns only [n0, n0 + BN): the others get count 0 (the merge skips them)
     if (wn == 0)
         for (int c = lane; c < p.Nn; c += 64)
@@ -673,7 +703,7 @@ __device__ __forceinline__ void nt_stats_flush(const GemmNTParams& p, NtStatsCar
                 const int n2 = n0 + wn * WTN + jj * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * gg + 4 * (lane >> 5));
                 if (n2 < p.Nn) {
                     *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 2) * p.Nn + n2) = f32x4{st.piv[jj][gg][0], st.piv[jj][gg][1], st.piv[jj][gg][2], st.piv[jj][gg][3]};
-                    *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 3) * p.Nn + n2) = f32x4{st.count, st.count, st.count, st.count};
+                    *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 3) * p.Nn + n2) = f32x4{count, count, count, count};
                 }
             }
     }
@@ -1101,7 +1131,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (BM == 128 && BN == 128 ? 2
             if (body(S1{})) break;
         }
     }
-    if constexpr (EPI == NT_EPI_STATSC) nt_stats_flush<T, BM, BN, NW>(p, carry, fn0, lane, wm, wn, (int)blockIdx.x * WROWS + wm);
+    if constexpr (EPI == NT_EPI_STATSC) nt_stats_flush<T, BM, BN, NW>(p, carry, fn0, lane, wm, wn, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
