@@ -765,22 +765,44 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
 #define BN_FOLD_ROWS 512
 // rpp == 0: "counted" rows part[(k*4 + {0,1,2,3})*C + c] — the fourth plane holds the number of pixel rows the row sums (a
 // persistent conv workgroup's share of the tensor, not a contiguous row range; rows with count 0 are skipped)
-__device__ __forceinline__ void fused_partial(const float* __restrict__ part, int k, int C, int c, long M, int rpp, double& sm, double& sq) {
+// A partial row contributes sum y = s1 + n p and sum y^2 = s2 + 2 p s1 + n p^2 (n = its pixel rows), merged in double.
+// four rows k, k + stride, ... at once: all their loads are issued before the first use (one thread walking 16-64 rows one at a time is
+// a chain of dependent L2 round trips — 13 us for the 512-row finalize, with or without the two double divisions per row of the
+// first formulation n * mean, M2 + n * mean^2); rows >= kend and rows without pixels contribute nothing
+__device__ __forceinline__ void fused_partial4(const float* __restrict__ part, int k, int stride, int kend, int C, int c, long M, int rpp, double& sm, double& sq) {
     const int planes = rpp > 0 ? 3 : 4;
-    long n;
-    if (rpp > 0) {
-        n = M - (long)k * rpp;
-        if (n > rpp) n = rpp;
-    } else {
-        n = (long)part[((long)k * 4 + 3) * C + c];
+    // counts first (counted rows of a wide layer are mostly rows of OTHER channel blocks: count 0, nothing else to read) ...
+    long n[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int kk = k + u * stride;
+        if (rpp > 0) {
+            n[u] = M - (long)kk * rpp;
+            if (n[u] > rpp) n[u] = rpp;
+        } else {
+            n[u] = kk < kend ? (long)part[((long)kk * 4 + 3) * C + c] : 0;
+        }
+        if (kk >= kend) n[u] = 0;
     }
-    if (n <= 0) return;
-    const double s1 = (double)part[((long)k * planes + 0) * C + c], s2 = (double)part[((long)k * planes + 1) * C + c];
-    const double pv = (double)part[((long)k * planes + 2) * C + c];
-    // sum y = s1 + n p and sum y^2 = s2 + 2 p s1 + n p^2 (the same numbers as n * mean and M2 + n * mean^2 of the partial, without the
-    // two double-precision divisions per row that made the 512-row finalize as slow as fold + finalize: 14.1 us)
-    sm += s1 + (double)n * pv;
-    sq += s2 + 2.0 * pv * s1 + (double)n * pv * pv;
+    // ... then the three sums of the rows that have pixels, again all loads before the first use
+    float s1[4], s2[4], pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long row = (long)(k + u * stride) * planes;
+        s1[u] = s2[u] = pv[u] = 0.f;
+        if (n[u] > 0) {
+            s1[u] = part[(row + 0) * C + c];
+            s2[u] = part[(row + 1) * C + c];
+            pv[u] = part[(row + 2) * C + c];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (n[u] > 0) {
+            const double a = (double)s1[u], b = (double)s2[u], p0 = (double)pv[u];
+            sm += a + (double)n[u] * p0;
+            sq += b + 2.0 * p0 * a + (double)n[u] * p0 * p0;
+        }
 }
 // stage 1 (only for many partials): groups of rpg partial rows -> fold[(g*2 + {0,1})*C + c] (double)
 __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ part, double* __restrict__ fold, int nparts, int C, long M, int rpp,
@@ -794,7 +816,7 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __re
     const int r0 = blockIdx.y * rpg, r1 = min(nparts, r0 + rpg);
     double sm = 0.0, sq = 0.0;
     if (c < C)
-        for (int r = r0 + ty; r < r1; r += TY) fused_partial(part, r, C, c, M, rpp, sm, sq);
+        for (int r = r0 + ty; r < r1; r += 4 * TY) fused_partial4(part, r, TY, r1, C, c, M, rpp, sm, sq);
     red[threadIdx.x * 2] = sm;
     red[threadIdx.x * 2 + 1] = sq;
     __syncthreads();
@@ -820,13 +842,13 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kern
     const int lane = threadIdx.x / FIN_CH;
     double sm = 0.0, sq = 0.0;
     if (c < C) {
-        for (int k = lane; k < nrows; k += FIN_LANES) {
-            if (FOLDED) {
+        if (FOLDED) {
+            for (int k = lane; k < nrows; k += FIN_LANES) {
                 sm += fold[((long)k * 2 + 0) * C + c];
                 sq += fold[((long)k * 2 + 1) * C + c];
-            } else {
-                fused_partial(part, k, C, c, M, rpp, sm, sq);
             }
+        } else {
+            for (int k = lane; k < nrows; k += 4 * FIN_LANES) fused_partial4(part, k, FIN_LANES, nrows, C, c, M, rpp, sm, sq);
         }
     }
     sh[(lane * FIN_CH + cl) * 2 + 0] = sm;
