@@ -47,7 +47,8 @@ class Lowering(object):
         # of a bottleneck).  Measured on one box, B=256: the BN backward's kernels lose 0.6 ms (bf16) / 1.0 ms (fp32) and the dgrads gain
         # nothing, yet with the wgrad on its side stream the step is 68.83 vs 68.92 ms in fp32 and 22.35 vs 22.25 ms in bf16 — the reduction
         # pass is HBM-bound and was already running under the MFMA-bound wgrad (serial launch order: 71.28 vs 71.79 ms fp32, 22.44 vs
-        # 22.55 ms bf16).  On for fp32, off for the 2-byte types.
+        # 22.55 ms bf16).  Re-measured on the round's final tree (streaming BN loads, XCD-aware wgrad order): fp32 68.42-68.46 vs 68.97-69.28 ms,
+        # bf16 21.41-21.48 vs 21.32-21.35 ms.  On for fp32, off for the 2-byte types.
         self.fuse_bn_bwd_red = bool(model._parameters.get('fuse_bn_bwd_red', _env_flag('MCN_FUSE_BN_BWD_RED', graph.dtype == 'float32')))
         self.scratch = {}
 
