@@ -103,6 +103,13 @@ def pmc_traffic(kernel, dtype, batch):
     k = d.get('kernels', {}).get(kernel)
     if not k or d.get('batch') != batch:
         return {}
+    # the summary must come from THIS build of the kernels: a csrc/ change without a re-run of profiles/collect.sh would otherwise
+    # report the previous build's traffic without a word
+    from myconvnet_amd._ffi import lib
+    have = lib.mcn_build_id().decode()
+    if d.get('build_id') != have:
+        return {'traffic': None, 'traffic_note': 'profiles/pmc_traffic_%s.json was collected from build %s, this library is %s: re-run profiles/collect.sh'
+                % (dtype, str(d.get('build_id'))[:12], have[:12])}
     return {'traffic': k['bytes_per_launch'], 'traffic_unit': 'bytes/launch', 'traffic_source': 'profiles/pmc_traffic_%s.json' % dtype}
 
 

@@ -163,7 +163,21 @@ def _ensure_fresh():
     if os.environ.get('MCN_NO_AUTOBUILD') == '1' or not os.path.exists(mod.HIPCC):
         raise ImportError('libmcn_hip.so is {}: built from sources {}, the tree has {}... — rebuild with '
                           '`python myconvnet_amd/build.py`'.format('stale' if have else 'missing', (have or 'none')[:12], want[:12]))
-    mod.build(verbose=False)
+    # N ranks of one node import this module at the same time (bench.py under torch.distributed.run): ONE of them rebuilds, the others
+    # wait on the lock and find the fresh library when they get it (before any GPU call: nothing here touches the device)
+    import fcntl
+    with open(LIB_PATH + '.lock', 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            try:
+                with open(LIB_PATH + '.id') as f:
+                    have = f.read().strip()
+            except OSError:
+                have = None
+            if not (have == want and os.path.exists(LIB_PATH)):
+                mod.build(verbose=False)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return want
 
 

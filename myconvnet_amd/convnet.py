@@ -158,7 +158,7 @@ class ConvNet(object):
     moving_average_decay = property(lambda self: self._moving_average_decay)
     batch_norm_decay = property(lambda self: self._batch_norm_decay)
     block_list = property(lambda self: self._block_list)
-    num_blocks = property(lambda self: len(self._block_list))
+    num_blocks = property(lambda self: self.__dict__.get('_num_blocks', len(self._block_list)))
     flops = property(lambda self: self._flops)
     params = property(lambda self: self._params)
     nodes = property(lambda self: self._nodes)
@@ -188,8 +188,9 @@ class ConvNet(object):
         parts = list(self._scope) + ([leaf] if leaf else [])
         return '/'.join(parts)
 
-    def add_to_collection(self, key, value):
-        self._collections.setdefault(key, []).append(value)
+    def add_to_collection(self, name, tensor):
+        """reference convnet.py (add_to_collection(name, tensor)): named lists of variables."""
+        self._collections.setdefault(name, []).append(tensor)
 
     def get_collection(self, key):
         return list(self._collections.get(key, []))
@@ -297,15 +298,36 @@ class ConvNet(object):
         g = self.graph
         shape = tuple(self.logits.shape)                    # [B, C] (classification) or [B, H, W, C] (SegNet: per-pixel loss)
         seg = len(shape) == 4
-        if seg and float(kwargs.get('label_smoothing', 0.0)) > 0.0:
-            raise NotImplementedError('SegNet label smoothing (5x5 average of the labels, segnet.py:117-122) is not built')
         self._label_shape = shape[:-1]
         self.Y = g.tensor(shape, 'float32', 'Y_onehot')
         g.node('labels', [], [self.Y], seg=seg)
+        labels = self.Y
+        ls_factor = float(kwargs.get('label_smoothing', 0.0))
+        if ls_factor > 0.0:
+            labels = self._label_smoothing(labels, ls_factor)
+        self._loss_fn(labels, self.logits, **kwargs)
+
+    def _loss_fn(self, labels, logits, **kwargs):
+        """reference convnet.py:599-601 (softmax cross-entropy over the last axis; the hook a model overrides for another loss).
+        Here it records ONE fused node: softmax, cross-entropy against the (smoothed) labels, valid mask and the L2 term of
+        _build_loss (mcn_softmax_xent_fwd_bwd / _rows_fwd_bwd + mcn_l2_loss)."""
+        g = self.graph
+        shape = tuple(logits.shape)
         self.pred = g.tensor(shape, 'float32', 'pred')
         self.d['pred'] = self.pred
-        self._loss_node = g.node('loss', [self.logits, self.Y], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
-                                 label_smoothing=float(kwargs.get('label_smoothing', 0.0)), rows=int(np.prod(shape[:-1])), per_pixel=seg)
+        self._loss_node = g.node('loss', [logits, labels], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
+                                 label_smoothing=float(getattr(labels, 'ls_factor', 0.0)), rows=int(np.prod(shape[:-1])), per_pixel=len(shape) == 4)
+        return self._loss_node
+
+    def _label_smoothing(self, labels, ls_factor, name='label_smoothing'):
+        """reference convnet.py:603-607: labels * (1 - f) + f / num_classes — applied inside the loss kernel, so the factor rides
+        on the label tensor."""
+        labels.ls_factor = float(ls_factor)
+        return labels
+
+    def _set_num_blocks(self, num_blocks):
+        """reference convnet.py:350-351 (models set the number of variable blocks explicitly)."""
+        self.__dict__['_num_blocks'] = num_blocks
 
     # ---- compile: storage + launch lists -----------------------------------------------------------------------------------
     def compile(self, loss_scale=1.0):

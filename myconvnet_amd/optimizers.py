@@ -187,7 +187,7 @@ class Optimizer(object):
         self._graph = g
         self._graph_low = m._train_low                   # a re-lowering (compile, autotune) invalidates the capture
 
-    def _step(self, handles=None, merged=None, writer=None, summary=False, log_trace=False, fetch=True):
+    def _step(self, handles, merged=None, writer=None, summary=False, log_trace=False, fetch=True):
         """reference optimizers.py:565-606: one optimisation step on the batch currently in the model's input buffers.
         Returns (loss, Y_true, Y_pred) as numpy when fetch=True (the reference's behaviour), else device tensors
         without synchronising."""

@@ -40,3 +40,7 @@ class SegNet(ConvNet):
     @abstractmethod
     def _build_model_seg(self, d_backbone):
         """Must return a dict of tensors including 'logits' [N, H, W, classes] (segnet.py:99-106)."""
+
+    def _label_smoothing(self, labels, ls_factor, name='label_smoothing'):
+        """reference segnet.py:117-122: the smoothed labels are a 5x5 SAME average of the one-hot label map, not the uniform mix."""
+        raise NotImplementedError('SegNet label smoothing (5x5 average of the labels, segnet.py:117-122) is not built')

@@ -64,6 +64,16 @@ def counter_rows(d):
     return acc
 
 
+def build_id():
+    """digest of the kernel sources of THIS tree (= mcn_build_id() of the library the profiled run loaded: _ffi refuses a stale one);
+    bench.py reports `traffic: null` when the committed summary was taken from another build"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_mcn_build', os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'myconvnet_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_digest()
+
+
 def main(root, rnd='round2'):
     here = os.path.dirname(os.path.abspath(__file__))
     for dt in ('fp32', 'bf16'):
@@ -94,7 +104,7 @@ def main(root, rnd='round2'):
             write = wr[k][1] / n * 1024.0
             kernels[k] = {'launches_profiled': n, 'fetch_size_bytes_raw': round(fetch), 'write_size_bytes': round(write),
                           'bytes_per_launch': round(2.0 * fetch + write)}
-        out = {'batch': 256, 'dtype': dt, 'command': 'python3 bench.py --steps 1 --warmup 1 --dtype %s --no-secondary --no-cpu-baseline' % dt,
+        out = {'batch': 256, 'dtype': dt, 'build_id': build_id(), 'command': 'python3 bench.py --steps 1 --warmup 1 --dtype %s --no-secondary --no-cpu-baseline' % dt,
                'formula': 'bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged over every launch of the kernel in the run',
                'kernels': kernels}
         with open(os.path.join(here, 'pmc_traffic_%s.json' % dt), 'w') as fh:
