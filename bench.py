@@ -51,6 +51,7 @@ def parse():
                     help='resnet50 = the headline workload (BASELINE configs[1]/[2]); efficientnet_b0 = configs[3], deeplabv3plus = configs[4] on one GPU (secondary, SURVEY 8f-2 / 8f-3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='A/B runs: timed steps only (no instrumented pass, no roofline object)')
     ap.add_argument('--no-ema', action='store_true', help='disable the EMA shadows (on by default in the reference)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per layer at start-up (untimed) instead of the library heuristic')
     ap.add_argument('--no-overlap', action='store_true', help='run wgrad on the main stream (serial kernels: the rocprofv3 per-kernel averages then equal the roofline object)')
@@ -118,13 +119,22 @@ def timed(opt, steps, warmup, world, autotune=False):
     if autotune:                                       # untimed start-up: two steps to fill the buffers, then time the tile candidates
         run_steps(opt, 2)
         opt.model.autotune()
-    run_steps(opt, warmup)
+    main_cus = int(os.environ.get('MCN_MAIN_CUS', '0'))       # experiment ("CU masks"): the main stream on a subset of the CUs
+    if main_cus > 0:
+        from myconvnet_amd.graph import masked_stream
+        ctx = torch.cuda.stream(masked_stream(torch.device('cuda', local_device()), main_cus, int(os.environ.get('MCN_MAIN_CU0', '0'))))
+    else:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        run_steps(opt, warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(opt, steps)
+    with ctx:
+        run_steps(opt, steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -393,7 +403,7 @@ def main():
         'train_flop_per_image': TRAIN_FLOP_PER_IMAGE,
         'e2e_mfma_frac': round(ips / world * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
     }
-    if world == 1:
+    if world == 1 and not args.no_roofline:
         table = instrumented_pass(model, args.dtype, layers=args.layers)
         bracket_us = table.pop('_bracket_us')[1] * 1e3
         convs = {k: v for k, v in table.items() if k.startswith('conv_gemm')}

@@ -181,10 +181,12 @@ int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const
  * sum((y-p)^2) and the shift p over rows_per_partial consecutive pixels each (0 rows = geometry not eligible, use the
  * plain calls); mcn_bn_fwd_train_fused merges them in double precision and skips the statistics pass over x (one read
  * of the layer output less per BN; same tf.nn.fused_batch_norm semantics, convnet.py:1883-1914).  Caller-owned buffer.
- * *rows_per_partial == 0 on return announces COUNTED rows: [rows][4][Cout] fp32 — sum(y-p), sum((y-p)^2), p and the number of
- * pixel rows summed (the launch runs as persistent workgroups, each keeps its sums across all the tiles it walks and writes
- * one row at the end; a row's pixels are not a contiguous range).  Size the buffer for 4 planes per row and
- * hand rows_per_partial through to mcn_bn_fwd_train_fused unchanged. */
+ * *rows_per_partial < 0 on return announces COUNTED rows of BN = -*rows_per_partial output channels (BN <= Cout): the launch runs as persistent
+ * workgroups, each walks tiles of ONE block of BN output channels, keeps its sums across them and writes one row at the end (a
+ * row's pixels are not a contiguous range): [Cout/BN blocks][rows/blocks][4][BN] fp32 — sum(y-p), sum((y-p)^2), p and the number of
+ * pixel rows summed, keyed by the channel block, so a channel's partials are the rows/blocks rows of its block.
+ * (*rows_per_partial == 0, accepted by the BN entry points: the same four planes as [rows][4][Cout] with count 0 for foreign
+ * blocks.)  Size the buffer for rows x 4 x Cout floats and hand rows_per_partial through to mcn_bn_fwd_train_fused unchanged. */
 int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* geom, mcn_dtype dtype, int32_t* rows_per_partial);
 int mcn_conv2d_fwd_bnstats(const void* x, const float* w_hwio, const void* w_packed, const float* bias, void* y,
                            float* stats_partials, const mcn_conv_geom* geom, mcn_dtype dtype, mcn_layout layout,

@@ -152,41 +152,60 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 // independent loads in flight per thread), then fold through LDS in double precision.  (A one-thread-per-channel
 // loop over ~2000 partials is a serial chain of dependent L2 round trips: it cost 0.45 ms per layer.)
 #define FIN_CH 8
-#define FIN_LANES 32
+#define FIN_LANES 64
+// fold of per-thread (a, b) over the FIN_LANES lanes of a channel: thread = lane * FIN_CH + channel, so a wave holds 8 lanes x 8 channels —
+// three xor-shuffles (lane bits), then the waves' sums through LDS; fixed order, result in the threads of lane 0 (threadIdx.x < FIN_CH).
+// (round 3: these kernels are pure latency chains — 7-12 us per launch, ~160 launches per step; the serial LDS walk of lane 0 over every
+// lane's pair and the 4-deep load batches were most of it)
+__device__ __forceinline__ void fin_fold(double* sh, double& a, double& b) {
+#pragma unroll
+    for (int o = FIN_CH; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    constexpr int NWAVES = FIN_CH * FIN_LANES / 64;
+    if (wl < FIN_CH) {
+        sh[(wave * FIN_CH + wl) * 2 + 0] = a;
+        sh[(wave * FIN_CH + wl) * 2 + 1] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < FIN_CH) {
+        a = 0.0;
+        b = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            a += sh[(w * FIN_CH + threadIdx.x) * 2 + 0];
+            b += sh[(w * FIN_CH + threadIdx.x) * 2 + 1];
+        }
+    }
+}
 __device__ __forceinline__ void fin_reduce(const float* __restrict__ part, int nparts, int C, int c, int lane, double* sh, double& a, double& b) {
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
-        int k = lane;
-        for (; k + 3 * FIN_LANES < nparts; k += 4 * FIN_LANES) {
-            float v0[4], v1[4];
+        // U rows per trip, all 2U loads issued before the first use (rows past the end re-read the lane's first row and are zeroed:
+        // an `if` per row makes every load its own basic block with its own wait)
+        constexpr int U = 8;
+        for (int k = lane; k < nparts; k += U * FIN_LANES) {
+            float v0[U], v1[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v0[u] = part[((long)(k + u * FIN_LANES) * 2 + 0) * C + c];
-                v1[u] = part[((long)(k + u * FIN_LANES) * 2 + 1) * C + c];
+            for (int u = 0; u < U; ++u) {
+                const int kk = k + u * FIN_LANES;
+                const long row = kk < nparts ? kk : k;
+                v0[u] = part[(row * 2 + 0) * C + c];
+                v1[u] = part[(row * 2 + 1) * C + c];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s0 += (double)v0[u];
-                s1 += (double)v1[u];
+            for (int u = 0; u < U; ++u) {
+                const bool ok = k + u * FIN_LANES < nparts;
+                s0 += ok ? (double)v0[u] : 0.0;
+                s1 += ok ? (double)v1[u] : 0.0;
             }
         }
-        for (; k < nparts; k += FIN_LANES) {
-            s0 += (double)part[((long)k * 2 + 0) * C + c];
-            s1 += (double)part[((long)k * 2 + 1) * C + c];
-        }
     }
-    const int cl = threadIdx.x % FIN_CH;
-    sh[(lane * FIN_CH + cl) * 2 + 0] = s0;
-    sh[(lane * FIN_CH + cl) * 2 + 1] = s1;
-    __syncthreads();
-    a = 0.0;
-    b = 0.0;
-    if (lane == 0) {
-        for (int l = 0; l < FIN_LANES; ++l) {
-            a += sh[(l * FIN_CH + cl) * 2 + 0];
-            b += sh[(l * FIN_CH + cl) * 2 + 1];
-        }
-    }
+    a = s0;
+    b = s1;
+    fin_fold(sh, a, b);
 }
 
 // scale/shift for the apply pass + saved statistics + running-statistics update
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_kernel(
     const float* __restrict__ beta, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
     float* __restrict__ batch_mean, float* __restrict__ batch_var, float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh[FIN_CH * FIN_LANES * 2];
+    __shared__ double sh[FIN_CH * FIN_LANES / 64 * FIN_CH * 2];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const int lane = threadIdx.x / FIN_CH;
     double a, b;
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_bwd_finalize_kernel(con
                                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                              float grad_scale, float* __restrict__ coef, int frozen,
                                                                              const float* __restrict__ raw_mean = nullptr) {
-    __shared__ double sh[FIN_CH * FIN_LANES * 2];
+    __shared__ double sh[FIN_CH * FIN_LANES / 64 * FIN_CH * 2];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const int lane = threadIdx.x / FIN_CH;
     double a, b;
@@ -829,6 +848,35 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __re
     fold[((long)blockIdx.y * 2 + 0) * C + c] = a;
     fold[((long)blockIdx.y * 2 + 1) * C + c] = b;
 }
+// COMPACT counted rows (rpp < 0, round 3): a persistent conv workgroup owns ONE block of BNB = -rpp output channels, so its row is keyed by
+// that block — part[((nb * RPB + j) * 4 + {0,1,2,3}) * BNB + cl], nb = c / BNB, cl = c % BNB, j < RPB = nparts / blocks — and a channel's rows
+// are exactly the RPB rows of its block: no scan over the other blocks' rows (and no zero counts written for them), all four planes of
+// U rows in flight at once, no fold launch.
+__device__ __forceinline__ void compact_partials(const float* __restrict__ part, int nparts, int BNB, int C, int c, int lane, double& sm, double& sq) {
+    const int nblk = (C + BNB - 1) / BNB, RPB = nparts / nblk;
+    const int nb = c / BNB, cl = c - nb * BNB;
+    const float* base = part + (size_t)nb * RPB * 4 * BNB + cl;
+    constexpr int U = 4;
+    for (int j = lane; j < RPB; j += U * FIN_LANES) {
+        float s1[U], s2[U], pv[U], n[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = j + u * FIN_LANES;
+            const float* r = base + (size_t)(jj < RPB ? jj : j) * 4 * BNB;
+            s1[u] = r[0];
+            s2[u] = r[BNB];
+            pv[u] = r[2 * BNB];
+            n[u] = r[3 * BNB];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = j + u * FIN_LANES < RPB && n[u] > 0.f;
+            const double a = (double)s1[u], b = (double)s2[u], p0 = (double)pv[u], nn = (double)n[u];
+            sm += ok ? a + nn * p0 : 0.0;
+            sq += ok ? b + 2.0 * p0 * a + nn * p0 * p0 : 0.0;
+        }
+    }
+}
 // stage 2: FOLDED reads the doubles of stage 1, otherwise the raw partials
 template <bool FOLDED>
 __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kernel(
@@ -836,7 +884,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kern
     const float* __restrict__ beta, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ batch_mean,
     float* __restrict__ batch_var, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float* __restrict__ scale,
     float* __restrict__ shift) {
-    __shared__ double sh[FIN_CH * FIN_LANES * 2];
+    __shared__ double sh[FIN_CH * FIN_LANES / 64 * FIN_CH * 2];
     const int cl = threadIdx.x % FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
     const int lane = threadIdx.x / FIN_CH;
@@ -847,19 +895,15 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kern
                 sm += fold[((long)k * 2 + 0) * C + c];
                 sq += fold[((long)k * 2 + 1) * C + c];
             }
+        } else if (rpp < 0) {
+            compact_partials(part, nrows, -rpp, C, c, lane, sm, sq);
         } else {
             for (int k = lane; k < nrows; k += 4 * FIN_LANES) fused_partial4(part, k, FIN_LANES, nrows, C, c, M, rpp, sm, sq);
         }
     }
-    sh[(lane * FIN_CH + cl) * 2 + 0] = sm;
-    sh[(lane * FIN_CH + cl) * 2 + 1] = sq;
-    __syncthreads();
+    double a = sm, b = sq;
+    fin_fold(sh, a, b);
     if (lane != 0 || c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int l = 0; l < FIN_LANES; ++l) {
-        a += sh[(l * FIN_CH + cl) * 2 + 0];
-        b += sh[(l * FIN_CH + cl) * 2 + 1];
-    }
     const double inv_m = 1.0 / (double)M;
     const double mean = a * inv_m;
     double var = b * inv_m - mean * mean;
@@ -889,7 +933,7 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
     float* shift = scale + C;
     const dim3 grid(L.gx, L.gy), block(256);
     const dim3 fgrid((C + FIN_CH - 1) / FIN_CH), fblock(FIN_CH * FIN_LANES);
-    if (nparts > BN_FOLD_ROWS) {
+    if (nparts > BN_FOLD_ROWS && rpp >= 0) {
         const int rpg = (nparts + BN_FOLD_ROWS - 1) / BN_FOLD_ROWS;
         const int n = (nparts + rpg - 1) / rpg;
         int TX = 8;
@@ -913,6 +957,14 @@ static int bn_fwd_fused_t(const void* x, const float* parts, int nparts, int rpp
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
+// rows_per_partial of mcn_conv2d_bnstats_rows: > 0 pixel rows per partial (they must cover M), 0 counted rows, < 0 compact counted rows of
+// -rows_per_partial channels per block (a multiple of 4 that divides the row count into whole blocks)
+static bool bad_rpp(int rpp, int nparts, int64_t M, int C) {
+    if (rpp > 0) return (int64_t)nparts * rpp < M;
+    if (rpp == 0) return false;
+    const int bnb = -rpp, nblk = (C + bnb - 1) / bnb;
+    return bnb % 4 != 0 || nblk <= 0 || nparts % nblk != 0;
+}
 // statistics from the conv-epilogue partials + (scale, shift) in the workspace; returns them through the out-pointers
 static int bn_fused_finalize(const float* parts, int nparts, int rpp, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* batch_mean,
                              float* batch_var, float* running_mean, float* running_var, float momentum, long M, int C, float eps, void* ws, hipStream_t st,
@@ -921,7 +973,7 @@ static int bn_fused_finalize(const float* parts, int nparts, int rpp, const floa
     float* scale = dst ? dst : (float*)((char*)ws + bn_parts_bytes(M, C));         // dst: caller-owned [2][C] that outlives the workspace's next user
     float* shift = scale + C;
     const dim3 fgrid((C + FIN_CH - 1) / FIN_CH), fblock(FIN_CH * FIN_LANES);
-    if (nparts > BN_FOLD_ROWS) {
+    if (nparts > BN_FOLD_ROWS && rpp >= 0) {
         const int rpg = (nparts + BN_FOLD_ROWS - 1) / BN_FOLD_ROWS;
         const int n = (nparts + rpg - 1) / rpg;
         int TX = 8;
@@ -951,7 +1003,7 @@ extern "C" int mcn_bn_fwd_train_fused_maxpool(const void* x, const float* stats_
                                               int32_t C, float eps, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH,
                                               int32_t OW, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     const int64_t M = (int64_t)N * H * W;
-    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_maxpool: partials do not cover M rows");
+    if (bad_rpp(rows_per_partial, nparts, M, C)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_maxpool: partials do not cover M rows");
     if (!x || !pooled || !argmax || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 4) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_maxpool: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused_maxpool: workspace too small");
     float *scale, *shift;
@@ -967,7 +1019,7 @@ extern "C" int mcn_bn_fwd_train_fused_maxpool(const void* x, const float* stats_
 extern "C" int mcn_bn_fwd_train_fused_stats(const float* stats_partials, int32_t nparts, int32_t rows_per_partial, const float* gamma, const float* beta, float* save_mean,
                                             float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum,
                                             int64_t M, int32_t C, float eps, float* scale_shift, void* ws, size_t ws_bytes, void* stream) {
-    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_stats: partials do not cover M rows");
+    if (bad_rpp(rows_per_partial, nparts, M, C)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_stats: partials do not cover M rows");
     if (!stats_partials || nparts <= 0 || !save_mean || !save_invstd || !scale_shift || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_stats: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused_stats: workspace too small");
     float *sc, *sh;
@@ -981,7 +1033,7 @@ extern "C" int mcn_bn_fwd_train_fused_affskip(const void* x, const float* stats_
                                               const void* skip_x, const float* skip_scale_shift, void* y, uint8_t* relu_mask, float* save_mean, float* save_invstd,
                                               float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum, int64_t M, int32_t C,
                                               float eps, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
-    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_affskip: partials do not cover M rows");
+    if (bad_rpp(rows_per_partial, nparts, M, C)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_affskip: partials do not cover M rows");
     if (!x || !y || !skip_x || !skip_scale_shift || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused_affskip: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused_affskip: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1007,7 +1059,7 @@ extern "C" int mcn_bn_fwd_train_fused(const void* x, const float* stats_partials
                                       const void* skip, void* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, float* batch_mean,
                                       float* batch_var, float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
                                       mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
-    if (rows_per_partial < 0 || (rows_per_partial > 0 && (int64_t)nparts * rows_per_partial < M)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: partials do not cover M rows");
+    if (bad_rpp(rows_per_partial, nparts, M, C)) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: partials do not cover M rows");
     if (!x || !y || !stats_partials || nparts <= 0 || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 4) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_fused: bad argument");
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_fused: workspace too small");
     hipStream_t st = (hipStream_t)stream;

@@ -135,6 +135,15 @@ static bool tn_ring(size_t es, int BR, int BN, bool linear) {
     if (BR == 128 && BN == 128) return (v & (linear ? 2 : 1)) != 0;
     return BR == 64 && BN == 64 && (v & 4) != 0;
 }
+// ring of 3 / 4 LDS buffers for the 128 x 128 wgrad tile of the 2-byte types (conv_gemm_tn3 / conv_gemm_tn4 on 8 waves, one workgroup per CU):
+// MCN_TN_RING2 = stages (3 or 4) for the 1x1 wgrads, 10 + stages for the gathered (3x3 / strided) ones too; 0 = two buffers
+static int tn_ring2(size_t es, int BR, int BN, bool linear) {
+    static const int v = [] { const char* e = getenv("MCN_TN_RING2"); return e ? atoi(e) : 0; }();
+    if (es != 2 || BR != 128 || BN != 128 || v <= 0) return 0;
+    const int st = v % 10;
+    if (st != 3 && st != 4) return 0;
+    return (linear || v >= 10) ? st : 0;
+}
 static inline bool conv_is_linear(const Geo& g) {
     return g.KH * g.KW == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
 }
@@ -157,7 +166,8 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
     if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
     static const int model = [] { const char* e = getenv("MCN_TN_SPLITS"); return e ? atoi(e) : 1; }();
-    if (model > 1 || (model == 1 && BR == 128 && BN == 128 && !conv_is_linear(g))) {
+    const int ring2 = tn_ring2(mcn_dtype_size(dt), BR, BN, conv_is_linear(g));
+    if (model > 1 || (model == 1 && BR == 128 && BN == 128 && (!conv_is_linear(g) || ring2))) {
         // Whole rounds: a CU holds occ = 2 workgroups of the 128 x 128 tile (64 KB of LDS), the chip 512; a launch of W = tiles x splits
         // workgroups runs W / slots full rounds and a tail.  A full round costs occ x (steps + c0) MFMA-bound step times per CU, a tail
         // round ceil(rem / 256) of them (one workgroup alone on a CU does not fill its pipes: at least 1.3); c0 = slab write + read
@@ -165,7 +175,7 @@ static int wgrad_splits(const Geo& g, mcn_dtype dt, int* nsteps_out, int* sps_ou
         // with 256+ channels 1044-1152 workgroups = two rounds + a nearly empty third: 14x14 256ch 547 -> 389 us (bf16) / 545 -> 493
         // (fp32), 28x28 256ch / 2 127 -> 85, 7x7 512ch 112 -> 93 (serial launches, B = 256).  The smaller tiles keep the target: their
         // 3-5 workgroups per CU are not priced well by this model (64 x 64 fp32 1x1 layers +8 %, MCN_TN_SPLITS=2 to see it).
-        int occ = (160 * 1024) / ((tn_ring(mcn_dtype_size(dt), BR, BN, conv_is_linear(g)) ? 3 : 2) * KP * (BR + BN) * (int)mcn_dtype_size(dt));
+        int occ = (160 * 1024) / ((ring2 ? ring2 : (tn_ring(mcn_dtype_size(dt), BR, BN, conv_is_linear(g)) ? 3 : 2)) * KP * (BR + BN) * (int)mcn_dtype_size(dt));
         if (occ > 4) occ = 4;
         const int slots = 256 * (occ < 1 ? 1 : occ);
         const double c0 = 4.0;
@@ -514,6 +524,9 @@ static bool nt_stats_counted(int mode, long M, int Nn, int nchunks, int tile, in
 template <typename T>
 static int launch_nt_pers(const GemmNTParams& p, int tile, long W, hipStream_t st, int epi) {
     const NtTile t = kNtCand[tile];
+    // (round 3, measured and dropped: a one-time start offset of 1.7 / 3.4 / 5.1 us between the residency slots of a CU, so that some
+    // workgroups sit in their K loop while the others store — bf16 21.55 -> 21.60-21.64 ms, fp32 68.4-68.8 -> 68.7-69.0 ms per step, two
+    // rounds each: the workgroups of a CU do not stay in lockstep long enough for a deliberate stagger to matter)
     const int lds = 2 * (t.bm + t.bn) * 128;
     const long cap = nt_pers_cap<T>(tile, epi);
     const dim3 grid((unsigned)(W < cap ? W : cap)), block(256);
@@ -620,7 +633,21 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
     do {                                                             \
         if (linear) MCN_LAUNCH_TN(BRV, BNV, true, NWV); else MCN_LAUNCH_TN(BRV, BNV, false, NWV); \
     } while (0)
-    if (ring && BR == 64) {
+    const int ring2 = tn_ring2(sizeof(T), BR, BN, linear);
+    if (ring2) {
+        if constexpr (sizeof(T) == 2) {
+            const int lds = ring2 * KP * (128 + 128) * (int)sizeof(T);
+#define MCN_LAUNCH_TNR(KERN, LINV)                                                          \
+    do {                                                                                    \
+        static bool once = (allow_lds(KERN<T, 128, 128, LINV, 8>, 160 * 1024), true);       \
+        (void)once;                                                                         \
+        hipLaunchKernelGGL((KERN<T, 128, 128, LINV, 8>), grid, dim3(512), lds, st, p);      \
+    } while (0)
+            if (ring2 == 3) { if (linear) MCN_LAUNCH_TNR(conv_gemm_tn3, true); else MCN_LAUNCH_TNR(conv_gemm_tn3, false); }
+            else { if (linear) MCN_LAUNCH_TNR(conv_gemm_tn4, true); else MCN_LAUNCH_TNR(conv_gemm_tn4, false); }
+#undef MCN_LAUNCH_TNR
+        }
+    } else if (ring && BR == 64) {
         if constexpr (sizeof(T) == 4) {
             const int lds = 3 * KP * (64 + 64) * (int)sizeof(T);
             if (linear) hipLaunchKernelGGL((conv_gemm_tn3<T, 64, 64, true, 4>), grid, dim3(256), lds, st, p);
@@ -770,14 +797,18 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     const NtTile* cand = kNtCand;
     const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
     const int wrows = cand[t].nw / 2;
-    // counted rows (rows_per_partial = 0): one row per persistent workgroup (its wave rows are merged in the flush), [4][Cout] floats each
+    // counted rows (rows_per_partial = -BN): one row per persistent workgroup (its wave rows are merged in the flush), [4][BN] floats each
     const int ce = ce_of(dtype), cpt = round_up(g.Cin, ce) / ce;
     const int mode = conv_is_linear(g) ? NT_LINEAR : NT_UNIFORM;
     long grid = 0;
     const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
                          : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
                                             : nt_stats_counted<bf16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid);
-    if (counted) return (int32_t)grid;
+    if (counted) {
+        // compact counted rows: keyed by the channel block of the persistent workgroup (conv_kernels.h, nt_stats_flush)
+        if (rows_per_partial) *rows_per_partial = -(g.Cout < cand[t].bn ? g.Cout : cand[t].bn);      // (a layer narrower than the tile: one block of Cout channels)
+        return (int32_t)grid;
+    }
     if (rows_per_partial) *rows_per_partial = cand[t].bm / wrows;
     return (int32_t)(wrows * ((M + cand[t].bm - 1) / cand[t].bm));
 }

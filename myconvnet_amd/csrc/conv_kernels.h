@@ -632,7 +632,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 }
 
 // end of a persistent workgroup with carried statistics: fold the lanes once, merge the wave rows through LDS and write ONE counted
-// partial row per workgroup: stats[(prow * 4 + {0,1,2,3}) * Nn + n] = sum(y - p), sum((y - p)^2), p, pixel rows summed; prow = workgroup.
+// partial row per workgroup: sum(y - p), sum((y - p)^2), p, pixel rows summed (layout: "COMPACT counted rows" below); prow = workgroup.
 // Wave row w > 0 summed around its own pivot p_w: with d = p_w - p_0, sum(y - p_0) = s1_w + n_w d and
 // sum((y - p_0)^2) = s2_w + 2 d s1_w + n_w d^2 (d is of the order of the standard deviation: no cancellation added).
 template <typename T, int BM, int BN, int NW>
@@ -684,26 +684,42 @@ __device__ __forceinline__ void nt_stats_flush(const GemmNTParams& p, NtStatsCar
             count += n1;
         }
     }
-    // a row spans all Nn channels but this workgroup owns only [n0, n0 + BN): the others get count 0 (the merge skips them)
-    if (wn == 0)
-        for (int c = lane; c < p.Nn; c += 64)
-            if (c < n0 || c >= n0 + BN) p.stats[((long)prow * 4 + 3) * p.Nn + c] = 0.f;
+    // COMPACT counted rows (round 3): the row is keyed by the workgroup's channel block — stats[((nb * RPB + j) * 4 + plane) * BW + cl], nb = n0 / BN,
+    // BW = min(BN, Nn) channels per block (a layer narrower than the tile is one block of Nn channels: the buffer holds rows x 4 x Nn floats),
+    // j = this workgroup's rank among the workgroups of its block (all of them walk tiles of one channel block: nt_stats_counted), RPB rows
+    // per block.  With grid < total tiles the workgroups b = xcd + 8 idx start at tile base(xcd) + idx and the host guarantees
+    // (grid / 8) % ntn == 0: per XCD, idx / ntn counts the ones that share a block.  Otherwise every workgroup has exactly one tile L and
+    // j is its M tile.  (Before: rows of Nn channels with zero counts for the other blocks, up to 3.9 MB of zeros per launch and
+    // 512-1024 rows scanned per channel by the finalize.)
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int total = ((p.m_end - p.m_begin + BM - 1) / BM) * ntn, grid = (int)gridDim.x;
+    int jrow, RPB;
+    if (grid < total) {
+        const int per = grid / 8 / ntn;
+        jrow = (prow & 7) * per + (prow >> 3) / ntn;
+        RPB = grid / ntn;
+    } else {
+        jrow = xcd_remap(prow, total) / ntn;
+        RPB = total / ntn;
+    }
+    const int BW = p.Nn < BN ? p.Nn : BN;
+    float* const row = p.stats + ((size_t)(n0 / BN) * RPB + jrow) * 4 * BW;
     const int e = base & 3, gj = base >> 2, g = gj % NG, j = gj / NG;
     const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
-    const int n = n0 + wn * WTN + j * MM::MT + nl + e;
-    if (writer && n < p.Nn) {
-        p.stats[((long)prow * 4 + 0) * p.Nn + n] = a[0];
-        p.stats[((long)prow * 4 + 1) * p.Nn + n] = b[0];
+    const int cl = wn * WTN + j * MM::MT + nl + e;                    // channel within the block
+    if (writer && n0 + cl < p.Nn) {
+        row[0 * BW + cl] = a[0];
+        row[1 * BW + cl] = b[0];
     }
     if (fr == 0) {
 #pragma unroll
         for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
             for (int gg = 0; gg < NG; ++gg) {
-                const int n2 = n0 + wn * WTN + jj * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * gg + 4 * (lane >> 5));
-                if (n2 < p.Nn) {
-                    *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 2) * p.Nn + n2) = f32x4{st.piv[jj][gg][0], st.piv[jj][gg][1], st.piv[jj][gg][2], st.piv[jj][gg][3]};
-                    *reinterpret_cast<f32x4*>(p.stats + ((long)prow * 4 + 3) * p.Nn + n2) = f32x4{count, count, count, count};
+                const int c2 = wn * WTN + jj * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * gg + 4 * (lane >> 5));
+                if (n0 + c2 < p.Nn) {
+                    *reinterpret_cast<f32x4*>(row + 2 * BW + c2) = f32x4{st.piv[jj][gg][0], st.piv[jj][gg][1], st.piv[jj][gg][2], st.piv[jj][gg][3]};
+                    *reinterpret_cast<f32x4*>(row + 3 * BW + c2) = f32x4{count, count, count, count};
                 }
             }
     }
@@ -1502,13 +1518,17 @@ __device__ __forceinline__ void tn_body(const GemmTNParams& p) {
     // one K-step (KP pixels) from LDS buffer `buf`; the DMA of the next step goes to the other buffer right after the
     // barrier that retires its readers and flies under this step's MFMAs
     auto kstep = [&](int ks, auto cur, auto nxt) {
-        if constexpr (STAGES == 3) {
-            // `nxt` is the buffer of step ks + 2 (read last in step ks - 1: every wave is past that once it reaches this barrier);
-            // step ks + 1's DMAs, issued one step ago, may stay in flight (loads retire in issue order)
-            if (ks + 1 < ks1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XN + DN) : "memory");
+        if constexpr (STAGES >= 3) {
+            // ring of STAGES buffers: `nxt` is the buffer of step ks + STAGES - 1 (read last in step ks - 1: every wave is past that once it
+            // reaches this barrier); the DMAs of steps ks + 1 .. ks + STAGES - 2, issued earlier, may stay in flight (loads retire in issue order)
+            constexpr int PER = XN + DN;
+            const int ahead = min(STAGES - 2, ks1 - 1 - ks);                       // later steps whose DMAs are already issued (uniform)
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            static_assert(STAGES <= 4 && 2 * PER < 64, "vmcnt immediates of the ring");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (ks + 2 < ks1) issue(ks + 2, nxt);
+            if (ks + STAGES - 1 < ks1) issue(ks + STAGES - 1, nxt);
         } else if (p.dbg & 32) {
             // early issue: the next step's DMAs do not wait for THIS step's data — barrier (everybody has finished reading `nxt`), issue,
             // then wait for this step's DMAs only (the ones just issued stay in flight) and a second barrier to see the other threads' data
@@ -1594,6 +1614,18 @@ __device__ __forceinline__ void tn_body(const GemmTNParams& p) {
             if (ks + 1 < ks1) kstep(ks + 1, B1{}, B0{});
             if (ks + 2 < ks1) kstep(ks + 2, B2{}, B1{});
         }
+    } else if constexpr (STAGES == 4) {
+        typedef std::integral_constant<int, 2> B2;
+        typedef std::integral_constant<int, 3> B3;
+        if (ks0 < ks1) issue(ks0, B0{});
+        if (ks0 + 1 < ks1) issue(ks0 + 1, B1{});
+        if (ks0 + 2 < ks1) issue(ks0 + 2, B2{});
+        for (int ks = ks0; ks < ks1; ks += 4) {
+            kstep(ks, B0{}, B3{});
+            if (ks + 1 < ks1) kstep(ks + 1, B1{}, B0{});
+            if (ks + 2 < ks1) kstep(ks + 2, B2{}, B1{});
+            if (ks + 3 < ks1) kstep(ks + 3, B3{}, B2{});
+        }
     } else {
         if (ks0 < ks1) issue(ks0, B0{});
         for (int ks = ks0; ks < ks1; ks += 2) {
@@ -1631,6 +1663,13 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_tn(const GemmTNParams p) {
 template <typename T, int BR, int BN, bool LINEAR, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_tn3(const GemmTNParams p) {
     tn_body<T, BR, BN, LINEAR, NW, 3>(p);
+}
+// four-stage ring (round 3): the DMAs of K-steps k+1 .. k+3 are in flight while step k multiplies.  For the 1x1 wgrads of the 2-byte types:
+// all tiles of a split walk the same pixel rows in lockstep, so every K-step's operands come from HBM (the XCD's L2 only merges the
+// tiles' requests) and a two-buffer loop runs one K-step per HBM round trip.
+template <typename T, int BR, int BN, bool LINEAR, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_tn4(const GemmTNParams p) {
+    tn_body<T, BR, BN, LINEAR, NW, 4>(p);
 }
 
 // dw[t][c][n] = scale * sum_split slab[split][t*Cp + c][n]   (c < Cin).  16 outputs x 16 split lanes per block (the stem: 9408
@@ -1680,12 +1719,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_linear_kernel(const float* _
         const long i = i0 + v;
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
         if (i < total4) {
+            // four slabs per trip, all loads before the first add (a lane walking 12-64 slabs two at a time is a chain of dependent L2 /
+            // Infinity Cache round trips: these launches ran 6-9 us for a few hundred KB)
             int k = l;
-            for (; k + SL < splits; k += 2 * SL) {
+            for (; k + 3 * SL < splits; k += 4 * SL) {
                 const f32x4 v0 = s4[(long)k * total4 + i], v1 = s4[(long)(k + SL) * total4 + i];
+                const f32x4 v2 = s4[(long)(k + 2 * SL) * total4 + i], v3 = s4[(long)(k + 3 * SL) * total4 + i];
                 a0 += v0; a1 += v1;
+                a0 += v2; a1 += v3;
             }
-            if (k < splits) a0 += s4[(long)k * total4 + i];
+            for (; k < splits; k += SL) a0 += s4[(long)k * total4 + i];
         }
         a0 += a1;
         if (SL == 1) {

@@ -153,6 +153,31 @@ class DataParallel(object):
         else:                                                    # gloo has no all_gather_into_tensor for device tensors
             dist.all_gather([self.gathered_stats[r] for r in range(self.world)], self.model.batch_stats)
 
+    def gather_bn_stats_async(self, chain):
+        """The all-gather of the ranks' batch statistics and the chained running update (`chain`: a Program) on a stream of their
+        own, behind the forward pass: nothing in the backward pass reads the running statistics, so the collective's latency (a
+        small message: one round trip over xGMI) stays off the main stream's critical path.  join_bn_stats() orders the main
+        stream behind it — the optimizer step does that before its update, i.e. before anything of the next step."""
+        if self.model.device.type != 'cuda':
+            self.gather_bn_stats()
+            chain.run(0)
+            return
+        if getattr(self, 'stats_stream', None) is None:
+            self.stats_stream = torch.cuda.Stream(device=self.model.device)
+            self._stats_fwd, self._stats_done = torch.cuda.Event(), torch.cuda.Event()
+        self._stats_fwd.record(torch.cuda.current_stream())
+        self.stats_stream.wait_event(self._stats_fwd)
+        with torch.cuda.stream(self.stats_stream):
+            self.gather_bn_stats()
+            chain.run(self.stats_stream.cuda_stream)
+            self._stats_done.record(self.stats_stream)
+        self._stats_pending = True
+
+    def join_bn_stats(self):
+        if getattr(self, '_stats_pending', False):
+            torch.cuda.current_stream().wait_event(self._stats_done)
+            self._stats_pending = False
+
     def mean_scalar(self, t):
         self._loss_tmp.copy_(t.reshape(1))
         dist.all_reduce(self._loss_tmp, op=dist.ReduceOp.SUM)

@@ -131,7 +131,12 @@ class Lowering(object):
         self.overlap_wgrad = self.train and bool(self.model._parameters.get('overlap_wgrad', True)) and self.g.device.type == 'cuda'
         if self.overlap_wgrad:
             self.ws2 = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=self.g.device)
-            self.bwd.side_stream = torch.cuda.Stream(device=self.g.device)      # (stream priorities were measured: no effect)
+            side_cus = int(os.environ.get('MCN_SIDE_CUS', '0'))                 # experiment: the wgrad stream on a subset of the CUs
+            if side_cus > 0:
+                from .graph import masked_stream
+                self.bwd.side_stream = masked_stream(self.g.device, side_cus, int(os.environ.get('MCN_SIDE_CU0', '0')))
+            else:
+                self.bwd.side_stream = torch.cuda.Stream(device=self.g.device)      # (stream priorities were measured: no effect)
         self.plan_packed_weights()
         for n in self.g.nodes:
             getattr(self, 'fwd_' + n.op)(n)

@@ -198,6 +198,25 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def masked_stream(device, ncu, first=0, total=256):
+    """A HIP stream whose kernels may only use `ncu` of the chip's CUs (hipExtStreamCreateWithCUMask; mask bits first .. first + ncu - 1,
+    which the driver deals round-robin over the XCDs), wrapped as a torch stream.  Experiment switch of the two-stream backward
+    (MCN_SIDE_CUS / MCN_MAIN_CUS, DESIGN.md section 3 "CU masks"): the default streams are unmasked."""
+    import ctypes
+    import os
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for b in range(first, min(total, first + ncu)):
+        mask[b // 32] |= 1 << (b % 32)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError('hipExtStreamCreateWithCUMask failed: {}'.format(rc))
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class Graph(object):
     def __init__(self, device, dtype):
         self.device = device

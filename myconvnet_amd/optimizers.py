@@ -210,8 +210,8 @@ class Optimizer(object):
             self._pre.run(sp)
             m.forward(train=True)
             clip = len(self._clip) > 0
-            self.dp.gather_bn_stats()
-            self._post_fwd.run(sp)
+            # batch statistics of all ranks -> chained running update, on a stream of its own (joined before the update below)
+            self.dp.gather_bn_stats_async(self._post_fwd)
             if clip:                                     # towers clip their own gradient before the mean
                 m.backward()
                 self._clip.run(sp)
@@ -219,6 +219,7 @@ class Optimizer(object):
             else:
                 m.backward(self.dp.hooks())
                 self.dp.finish()
+            self.dp.join_bn_stats()
             self.optimization_operation.run(sp)
         else:
             self._step_body()

@@ -63,6 +63,14 @@ class Tape(object):
         self.bw = []                  # backward closures
         self.batch_stats = {}         # bn scope -> (batch_mean, batch_var_unbiased)
         self.d = {}
+        # ReLU decisions at near-ties (test infrastructure for the fp32 device comparison, tests/flip_util.py): a pre-activation within
+        # rounding of zero may fall on the other side of the ReLU on the device (fp32 sums) than here (float64).  `tie_tol` > 0 records the
+        # elements with |z| <= tie_tol * rms(z) as (ReLU ordinal, flat index) in `near_ties`; `relu_flips` {ordinal: flat indices} inverts
+        # the decision of those elements (forward value and gradient mask).
+        self.tie_tol = 0.0
+        self.near_ties = []
+        self.relu_flips = {}
+        self.relu_count = 0
 
     def p(self, name):
         if name not in self.pv:
@@ -131,8 +139,21 @@ class Tape(object):
         return V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant)
 
     def relu(self, x):
-        y = V(ops.relu_fwd(x.a), self.quant)
-        self.bw.append(lambda: x.acc(ops.relu_bwd(y.g, y.a)))
+        k = self.relu_count
+        self.relu_count += 1
+        if self.tie_tol > 0.0:
+            z = np.abs(np.asarray(x.a, np.float64)).ravel()
+            rms = float(np.sqrt(np.mean(z * z))) or 1.0
+            self.near_ties += [(k, int(i)) for i in np.flatnonzero(z <= self.tie_tol * rms)]
+        flips = self.relu_flips.get(k)
+        if flips is None:
+            y = V(ops.relu_fwd(x.a), self.quant)
+            self.bw.append(lambda: x.acc(ops.relu_bwd(y.g, y.a)))
+            return y
+        mask = (x.a > 0)
+        mask.reshape(-1)[np.asarray(flips, dtype=np.int64)] ^= True
+        y = V(x.a * mask, self.quant)
+        self.bw.append(lambda: x.acc(y.g * mask))
         return y
 
     def add(self, x, skip):
@@ -655,12 +676,14 @@ class TrainState(object):
         self.step = 0
 
 
-def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False, quant=None):
+def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False, quant=None, tie_tol=0.0, relu_flips=None):
     hp = dict(DEFAULT_HP, **(hp or {}))
     params = state.ema if use_ema else state.params
     stats = state.ema_stats if use_ema else state.stats
     t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'], quant=quant, blocks_to_train=hp.get('blocks_to_train'),
              update_batch_norm=hp.get('update_batch_norm'))
+    t.tie_tol = float(tie_tol)
+    t.relu_flips = dict(relu_flips or {})
     dt = next(iter(params.values())).dtype
     x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']), quant)
     x.g = False
@@ -690,18 +713,35 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
     return t, out, pred, loss, onehot
 
 
+def copy_state(state):
+    """independent copy of a TrainState (to replay a step from the same starting point)"""
+    c = TrainState(state.params, state.stats)
+    c.accum = {k: v.copy() for k, v in state.accum.items()}
+    c.ema = {k: v.copy() for k, v in state.ema.items()}
+    c.ema_stats = {k: v.copy() for k, v in state.ema_stats.items()}
+    c.step = state.step
+    return c
+
+
 def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=None,
-               tower_batches=None, quant=None):
+               tower_batches=None, quant=None, probe=None):
     """One optimisation step.  `tower_batches` (list of (x,y)) restates the multi-tower path:
     gradients averaged over towers (optimizers.py:125-142), BN running stats chained
-    (convnet.py:1899-1909), loss = mean of tower losses (convnet.py:510)."""
+    (convnet.py:1899-1909), loss = mean of tower losses (convnet.py:510).
+    `probe` (test infrastructure, tests/flip_util.py): dict with 'tie_tol' and / or 'relu_flips' {(tower, ReLU ordinal): flat indices};
+    on return probe['near_ties'] lists the (tower, ordinal, flat index) of the ReLU inputs within tie_tol * rms of zero."""
     hp = dict(DEFAULT_HP, **(hp or {}))
     towers = tower_batches if tower_batches is not None else [(x_raw, y_float)]
     btot = batch_total if batch_total is not None else sum(len(t_[0]) for t_ in towers)
     lr = hp['base_learning_rate'] * btot / 256.0 * lr_mult          # optimizers.py:46,57
     grads_sum, losses, preds, bstats = None, [], [], []
-    for (xr, yf) in towers:
-        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant)
+    if probe is not None:
+        probe['near_ties'] = []
+    for ti, (xr, yf) in enumerate(towers):
+        flips = {k[1]: v for k, v in (probe or {}).get('relu_flips', {}).items() if k[0] == ti}
+        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant, tie_tol=(probe or {}).get('tie_tol', 0.0), relu_flips=flips)
+        if probe is not None:
+            probe['near_ties'] += [(ti, k, i) for k, i in t.near_ties]
         g = t.backward()
         if t.loss_scale != 1.0:
             g = {k: v / t.loss_scale for k, v in g.items()}

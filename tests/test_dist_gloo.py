@@ -59,8 +59,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_and_bn_chain_world2():
-    world = 2
+def _run_world(world):
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -71,6 +70,11 @@ def test_bucketed_allreduce_and_bn_chain_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    return res
+
+
+def test_bucketed_allreduce_and_bn_chain_world2():
+    res = _run_world(2)
     total = sum(np.concatenate(r[2]) for r in res)
     for r in res:
         np.testing.assert_allclose(r[1], total, rtol=1e-6)              # every rank holds the SUM (1/N is applied by the optimizer kernel)
@@ -80,4 +84,26 @@ def test_bucketed_allreduce_and_bn_chain_world2():
     run = np.zeros(50)
     mu, _ = O.bn_running_update_chain(run, run, [res[0][4], res[1][4]], [res[0][4], res[1][4]], 0.99)
     manual = 0.99 * (0.99 * run + 0.01 * res[0][4]) + 0.01 * res[1][4]
+    np.testing.assert_allclose(mu, manual)
+
+
+def test_bucketed_allreduce_and_bn_chain_world8():
+    """The N = 8 leg of BASELINE configs[2] / [4] on CPU (gloo): eight ranks, every rank ends with the sum of the eight gradients in
+    every bucket, identical gathered statistics in rank order, and the reference's chained running update over eight towers
+    (convnet.py:1899-1909) — the arithmetic mcn_bn_running_chain implements."""
+    world = 8
+    res = _run_world(world)
+    total = sum(np.concatenate(r[2]) for r in res)
+    for r in res:
+        np.testing.assert_allclose(r[1], total, rtol=1e-5, atol=1e-6)
+        assert r[5] >= 2
+        np.testing.assert_array_equal(r[3], res[0][3])
+    for k in range(world):
+        np.testing.assert_array_equal(res[0][3][k], res[k][4])          # row k of the gathered buffer is rank k's statistics
+    run = np.zeros(50)
+    stats = [r[4] for r in res]
+    mu, _ = O.bn_running_update_chain(run, run, stats, stats, 0.99)
+    manual = run
+    for k in range(world):
+        manual = 0.99 * manual + 0.01 * stats[k]
     np.testing.assert_allclose(mu, manual)

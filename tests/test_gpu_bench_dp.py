@@ -14,23 +14,26 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_prints_one_json_line():
+@pytest.mark.parametrize('ranks,batch', [(2, 64), (4, 16)])
+def test_bench_n_ranks_prints_one_json_line(ranks, batch):
+    """(4 ranks: the driver's N = 4 command line on the one GPU; six GPU processes are the box's limit, so N = 8 is rehearsed on the CPU
+    only — tests/test_dist_gloo.py)"""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MCN_BENCH_DEVICE='0', MCN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dtype', 'bf16',
-           '--batch', '64']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '3', '--warmup', '1', '--dtype', 'bf16',
+           '--batch', str(batch)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
-    assert out['config']['global_batch'] == 128 and out['config']['parallelism'] == 'dp2'
-    assert out['value'] > 0 and abs(out['value'] - 128 * 3 / (out['ms_per_step'] * 3e-3)) <= 0.01 * out['value']
+    assert out['n_gpus'] == ranks and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == ranks * batch and out['config']['parallelism'] == 'dp{}'.format(ranks)
+    assert out['value'] > 0 and abs(out['value'] - ranks * batch * 3 / (out['ms_per_step'] * 3e-3)) <= 0.01 * out['value']
     assert 'roofline' not in out and 'cpu_baseline' not in out            # N=1-only objects
 
 

@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
+sys.path.insert(0, HERE)
 
 
 def _free_port():
@@ -57,15 +58,18 @@ def _worker(rank, world, port, q, kind='resnet'):
         y = rng.integers(0, 10, B * world).astype(np.float32)
         model.feed(x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B])       # rank r owns images [r*B, (r+1)*B) (dataset.py:113-129)
         loss, _, pred = opt._step(None)
-        out.append((loss, pred))
+        # (rank 0 also hands back the all-reduced gradient SUM of the step, for the flip-aware comparison below)
+        out.append((loss, pred, model.get_variables('grad') if (rank == 0 and kind == 'resnet') else None))
     q.put((rank, out, model.get_variables('data'), model.get_variables('ema'), len(opt.dp.reducer.plan)))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['resnet', 'efficientnet_clip'])
-def test_two_rank_step_matches_multi_tower_oracle(kind):
+@pytest.mark.parametrize('kind,world', [('resnet', 2), ('efficientnet_clip', 2), ('resnet', 4)])
+def test_two_rank_step_matches_multi_tower_oracle(kind, world):
+    """(world 4: the largest rehearsal the one-GPU box allows beside the test runner — its process guard admits six GPU processes;
+    the N = 8 exchange arithmetic is covered on the CPU by tests/test_dist_gloo.py)"""
     from oracle import net as ON
-    world = 2
+    from flip_util import flip_aware_step
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -84,9 +88,15 @@ def test_two_rank_step_matches_multi_tower_oracle(kind):
         x = rng.random((B * world, 64, 64, 3)).astype(np.float32)
         y = rng.integers(0, 10, B * world).astype(np.float32)
         towers = [(x[r * B:(r + 1) * B].astype(np.float64), y[r * B:(r + 1) * B].astype(np.float64)) for r in range(world)]
-        rloss, rpred, _ = ON.train_step(spec, state, None, None, batch_total=B * world, tower_batches=towers, hp=hp or None)
+        if kind == 'resnet':
+            # fp32 device vs float64 oracle, every gradient tensor within 1e-3 — ReLU decisions at near-ties follow the device (flip_util)
+            dev = {k: v / world for k, v in res[0][1][step][2].items()}
+            rloss, rpred, _, flips = flip_aware_step(spec, state, towers, dev, hp=hp or None, batch_total=B * world)
+            print('step {}: {} ReLU near-tie decision(s) taken from the device'.format(step, len(flips)))
+        else:
+            rloss, rpred, _ = ON.train_step(spec, state, None, None, batch_total=B * world, tower_batches=towers, hp=hp or None)
         for r in range(world):
-            loss, pred = res[r][1][step]
+            loss, pred = res[r][1][step][:2]
             assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, r, loss, rloss)        # mean of tower losses on every rank
             np.testing.assert_allclose(pred, rpred, rtol=0, atol=2e-4)       # pred over ALL towers on every rank (convnet.py:508)
 
@@ -94,19 +104,19 @@ def test_two_rank_step_matches_multi_tower_oracle(kind):
         return np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30)
     for r in range(world):
         data, ema = res[r][2], res[r][3]
-        # (3e-4, not 1e-4: the second step sits behind an lr = 0.1 update, and one ReLU / max-pool decision that falls the other way
-        # in fp32 than in the float64 oracle moves a whole gradient tensor by ~1e-3 — see test_resnet_frozen_blocks...; which
-        # elements flip depends on the summation order of the conv kernels, e.g. block_0/conv_0/weights is within 1e-4 with the
-        # tap-outer 3x3 kernels (MCN_NT_WINDOW=0) and at 1.24e-4 with the window (channel-chunk-outer) kernels.  Loss and predictions above keep 1e-4 / 2e-4.)
+        # (resnet: the oracle followed the device at the ReLU near-ties, so the parameters agree as at step 0; the clipped EfficientNet
+        # run has no flip search — per-tower clipping is not linear in one decision — and keeps the 3e-4 allowance)
+        ptol = 1e-4 if kind == 'resnet' else 3e-4
         worst = max((rel(data[k], v), k) for k, v in state.params.items())
-        assert worst[0] <= 3e-4, worst
+        assert worst[0] <= ptol, worst
         worst = max((rel(data[k], v), k) for k, v in state.stats.items())             # chained running statistics
         assert worst[0] <= 1e-4, worst
         worst = max((rel(ema[k], v), k) for k, v in state.ema.items())
-        assert worst[0] <= 3e-4, worst
+        assert worst[0] <= ptol, worst
         assert res[r][4] >= 2                                                         # several buckets => overlap points
     for k in res[0][2]:                                                               # replicas stay bit-identical
-        np.testing.assert_array_equal(res[0][2][k], res[1][2][k])
+        for r in range(1, world):
+            np.testing.assert_array_equal(res[0][2][k], res[r][2][k])
 
 
 def _nccl_worker(port, q):

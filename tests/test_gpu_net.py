@@ -10,6 +10,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import os     # noqa: E402
+import sys    # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from flip_util import flip_aware_step  # noqa: E402
 from oracle import net as ON  # noqa: E402
 from oracle import ops as O   # noqa: E402
 
@@ -142,11 +147,18 @@ def test_resnet_frozen_blocks_and_frozen_batch_norm(freeze, dtype):
         x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
         model.feed(x, LABELS)
         loss, _, y_pred = opt._step(None)
-        rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=hp, batch_total=BATCH, quant=quant)
+        grads = model.get_variables('grad')
+        if bf:
+            rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=hp, batch_total=BATCH, quant=quant)
+        else:
+            # fp32 against float64: every gradient tensor within 1e-3 (north_star's bar), with the ReLU decisions at the oracle's own
+            # near-ties (|z| <= 4e-6 rms) taken from the device where that is what separates the two — tests/flip_util.py.  (Round 2 had a
+            # blanket 1e-2 here for the second step: one such decision moves a 16-channel beta gradient by 3e-3.)
+            rloss, rpred, rgrads, flips = flip_aware_step(spec, state, [(x.astype(np.float64), LABELS.astype(np.float64))], grads, hp=hp, batch_total=BATCH, tol=1e-3)
+            print('step {}: {} ReLU near-tie decision(s) taken from the device'.format(step, len(flips)))
         assert abs(loss - rloss) <= (3e-2 if bf else 1e-4) * abs(rloss), (step, loss, rloss)
         trainable = set(v.name for v in model.store.variables if v.trainable)
         assert trainable == set(rgrads), (sorted(trainable ^ set(rgrads))[:4])
-        grads = model.get_variables('grad')
         if bf:
             # (bf16 storage: small gamma / beta gradients are noisy tensor by tensor; test_resnet_step_bf16 has the calibration)
             worst = min((cosine(grads[k], rgrads[k]), k) for k in rgrads if np.linalg.norm(rgrads[k]) > 1e-6)
@@ -154,12 +166,10 @@ def test_resnet_frozen_blocks_and_frozen_batch_norm(freeze, dtype):
             flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in sorted(rgrads)])
             assert cosine(flat(grads), flat(rgrads)) >= 0.98
         else:
-            # step 0 differs from the float64 oracle by rounding alone (measured <= 2e-6 per tensor).  After one lr = 0.1 update
-            # a pre-activation within fp32 rounding of zero may fall on the other side of the ReLU than in float64: ONE such
-            # element moves a 16-channel beta gradient by 3e-3 (seen: 15 channels at 2e-8, one at 1.4e-4), so the per-tensor
-            # bound of the second step allows for single flips and the whole gradient keeps the tight one.
-            worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
-            assert worst[0] <= (1e-5 if step == 0 else 1e-2), 'step {}: worst gradient {}'.format(step, worst)
+            worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads if np.linalg.norm(rgrads[k]) > 1e-9)
+            assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+            if step == 0 and not flips:
+                assert worst[0] <= 1e-5, 'step 0 differs from the float64 oracle by rounding alone: {}'.format(worst)
             flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in sorted(rgrads)])
             assert rel_l2(flat(grads), flat(rgrads)) <= 1e-3
         got, ema = model.get_variables('data'), model.get_variables('ema')

@@ -581,7 +581,7 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         g.tile = tile
         rpp = ctypes.c_int32(0)
         rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT[dtype], ctypes.byref(rpp))
-        counted = rpp.value == 0                   # one row per persistent workgroup and wave row, [4][C]: the count is explicit
+        counted = rpp.value <= 0                   # one row per persistent workgroup, four planes: the count is explicit
         assert rows > 0 and (counted or rows * rpp.value >= y_plain.size // cout)
         xd, wd = u.dev(x, dtype), u.dev(w)
         y = torch.full(y_plain.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
@@ -600,8 +600,15 @@ def test_conv_epilogue_bn_statistics(case, dtype):
         yq = ys.astype(np.float64).reshape(-1, cout)                            # the partials describe the values THIS launch stored
         m = yq.shape[0]
         if counted:
-            # per channel the rows partition the pixels (a row counts 0 for the channels its workgroup does not own; whatever else
-            # it holds there is ignored) and merge to the tensor's moments
+            if rpp.value < 0:
+                # compact rows keyed by the channel block: [blocks][rows / blocks][4][BN] (include/mcn.h) -> per channel its block's rows
+                bnb = -rpp.value
+                nblk = -(-cout // bnb)
+                assert rows % nblk == 0
+                rpb = rows // nblk
+                flat = p.reshape(-1)[:nblk * rpb * 4 * bnb].reshape(nblk, rpb, 4, bnb)
+                p = np.stack([flat[c // bnb, :, :, c % bnb] for c in range(cout)], axis=-1)       # [rpb][4][cout]
+            # per channel the rows partition the pixels and merge to the tensor's moments
             cnt = p[:, 3, :]
             assert not np.isnan(cnt).any() and np.all(cnt >= 0) and np.all(cnt.sum(0) == m)
             live = cnt > 0
