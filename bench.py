@@ -90,18 +90,37 @@ def run_steps(opt, n):
         opt.curr_step += 1
 
 
-def pmc_traffic(kernel, dtype, batch):
+# kernel symbols (prefixes) behind the streaming C-ABI calls whose PMC bytes are summed per call (only calls that own their symbols in the
+# profiled model: EfficientNet's BN + swish passes, squeeze-excite BN backward, depthwise convolutions)
+CALL_KERNELS = {
+    'mcn_bn_bwd': ['bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel'],
+    'mcn_bn_bwd_se': ['bn_bwd_reduce_se_kernel', 'bn_bwd_apply_se_kernel'],
+    'mcn_bn_fwd_train_fused': ['bn_apply_kernel', 'bn_fwd_finalize_fused_kernel', 'bn_fold_partials_kernel'],
+    'mcn_dwconv2d_fwd': ['dw_band_kernel', 'dw_strip_kernel'],
+    'mcn_dwconv2d_dgrad': ['dw_dgrad', 'dw_band_kernel', 'dw_strip_kernel'],
+    'mcn_dwconv2d_wgrad': ['dw_wgrad'],
+}
+
+
+def pmc_traffic(kernel, dtype, batch, model='resnet50'):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/collect.sh: separate FETCH_SIZE and
     WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes: KiB units, FETCH_SIZE doubled on
     gfx950).  PMC counters cannot be collected from inside the process, so this reads the summary; null when absent or
     when it was taken for another kernel / batch."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_%s.json' % dtype)
+    tag = dtype if model == 'resnet50' else '%s_%s' % (model, dtype)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_%s.json' % tag)
     try:
         with open(path) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return {}
     k = d.get('kernels', {}).get(kernel)
+    if not k and kernel in CALL_KERNELS and d.get('steps_profiled'):
+        # a streaming C-ABI call = several kernel symbols (reduce + finalize + apply ...): HBM bytes of all of them per call
+        mine = [v for name, v in d.get('kernels', {}).items() if any(name.startswith(pfx) for pfx in CALL_KERNELS[kernel])]
+        calls = d.get('calls_per_step', {}).get(kernel)
+        if mine and calls:
+            k = {'bytes_per_launch': int(sum(v['bytes_per_launch'] * v['launches_profiled'] for v in mine) / d['steps_profiled'] / calls)}
     if not k or d.get('batch') != batch:
         return {}
     # the summary must come from THIS build of the kernels: a csrc/ change without a re-run of profiles/collect.sh would otherwise
@@ -157,6 +176,43 @@ def _not_persistent(sym):
         return sym
     t, bm, bn, nw, e = m.groups()
     return 'conv_gemm_nt<{}, {}, {}, 0, {}, {}>'.format(t, bm, bn, nw, 0 if e == '3' else e)      # (3 = counted statistics: persistent only)
+
+
+def _hbm_call_bytes(name, a, es):
+    """Algorithmic HBM bytes of the streaming (non-GEMM) C-ABI calls: every tensor the call must read or write, once per pass that
+    needs it (DESIGN.md section 3, table of kernels).  a = the call's argument list (executor.py), es = bytes per element.
+    Returns 0 for calls without a figure (they still show up with their time)."""
+    def mc(i):
+        return float(a[i]) * float(a[i + 1])
+    if name == 'mcn_bn_fwd_train_fused':                 # apply pass: x -> y (+ residual)
+        return es * mc(16) * (2 + (1 if a[6] else 0))
+    if name == 'mcn_bn_fwd_train_fused_affskip':         # x, shortcut conv output -> y
+        return es * mc(17) * 3
+    if name == 'mcn_bn_fwd_train':                       # statistics pass + apply pass
+        return es * mc(13) * (3 + (1 if a[3] else 0))
+    if name == 'mcn_bn_fwd_train_fused_maxpool':         # x -> pooled + arg-max
+        n, h, w, c, oh, ow = a[15], a[16], a[17], a[18], a[-6], a[-5]
+        return es * n * h * w * c + (es + 1) * n * oh * ow * c
+    if name == 'mcn_bn_bwd':                             # reduce (dy, x [, y]) + apply (dy, x [, y] -> dx [, dskip])
+        return es * mc(13) * (5 + (2 if a[2] else 0) + (1 if a[9] else 0))
+    if name == 'mcn_bn_bwd_from_partials':               # apply pass only
+        return es * mc(13) * 3
+    if name == 'mcn_bn_bwd_se':                          # both passes read dy and x, the apply pass writes dx
+        return es * float(a[12]) * float(a[13]) * float(a[14]) * 5
+    if name == 'mcn_bn_bwd_maxpool':                     # both passes read x and the pooled gradient + arg-max, one writes dx
+        n, h, w, c, oh, ow = a[11], a[12], a[13], a[14], a[-6], a[-5]
+        return es * n * h * w * c * 3 + 2 * (es + 1) * n * oh * ow * c
+    if name == 'mcn_bn_bwd_frozen':
+        return es * mc(13) * 3
+    if name.startswith('mcn_dwconv2d_'):
+        gm = [x for x in a if hasattr(x, '_obj')][0]._obj
+        oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
+        ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
+        return es * gm.N * gm.Cin * (gm.H * gm.W + oh * ow)
+    if name in ('mcn_channel_scale_fwd', 'mcn_channel_scale_bwd', 'mcn_channel_scale_bwd_dm'):
+        n, hw, c = a[-5], a[-4], a[-3]
+        return es * float(n) * hw * c * (2 if name != 'mcn_channel_scale_bwd' else 4)
+    return 0.0
 
 
 def instrumented_pass(model, dtype, reps=3, layers=False):
@@ -216,6 +272,10 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                 byt = es * B_ * (In_ + Out_) + (4 if op == _ffi.CONV_WGRAD else es) * In_ * Out_
             elif name not in ops:
                 key, flop, nl, byt = name, 0.0, 1, 0.0
+                try:
+                    byt = float(_hbm_call_bytes(name, a, 4 if dtype == 'fp32' else 2))
+                except (IndexError, TypeError, ValueError):
+                    byt = 0.0
                 if layers and name.startswith('mcn_dwconv2d_'):           # depthwise rows of the per-layer table (HBM-bound: GB/s is the figure)
                     gm = [x for x in a if hasattr(x, '_obj')][0]._obj
                     oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
@@ -287,6 +347,47 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
         t[2] /= (reps - 1)
         t[3] /= (reps - 1)
     return table
+
+
+def streaming_roofline(model, dtype, batch, model_name, layers=False, all_kernels=False):
+    """roofline object of an HBM-bound workload (EfficientNet-B0, DeepLabv3+): the entry — conv kernel symbol or streaming C-ABI call — with the
+    most time per step among those with a byte / FLOP figure.  These networks are HBM-bound (2.3 GFLOP per image
+    against ResNet-50's activation volume), so the figure is algorithmic bytes / time against the HBM peak unless the entry's arithmetic
+    intensity says otherwise."""
+    out = {}
+    table = instrumented_pass(model, dtype, layers=layers)
+    bracket_us = table.pop('_bracket_us')[1] * 1e3
+    out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if all_kernels else 14)]}
+    out['kernel_ms_total'] = round(sum(v[1] for v in table.values()), 3)
+    ridge = PEAK_TFLOPS[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+
+    def entry(k, v):
+        cnt, ms_k, flop, byt = v
+        e = {'launches_per_step': cnt, 'ms_per_step': round(ms_k, 3), 'gbs': round(byt / (ms_k * 1e-3) / 1e9, 0) if ms_k > 0 else 0.0,
+             'hbm_frac': round(byt / (ms_k * 1e-3) / 1e9 / PEAK_HBM_GBS, 3) if ms_k > 0 else 0.0, 'algorithmic_bytes_per_launch': int(byt / max(cnt, 1))}
+        if flop > 0:
+            e['tflops'] = round(flop / (ms_k * 1e-3) / 1e12, 1)
+            e['bound'] = 'hbm' if flop / max(byt, 1.0) < ridge else 'mfma'
+        else:
+            e['bound'] = 'hbm'
+        t = pmc_traffic(k, dtype, batch, model_name).get('traffic')
+        if t is not None:
+            e['traffic'] = t
+        return e
+    rated = {k: v for k, v in table.items() if v[3] > 0 and v[1] > 0}
+    if rated:
+        name, v = max(rated.items(), key=lambda kv: kv[1][1])
+        e = entry(name, v)
+        hbm = e['bound'] == 'hbm'
+        ach = e['gbs'] if hbm else e.get('tflops', 0.0)
+        peak = PEAK_HBM_GBS if hbm else PEAK_TFLOPS[dtype]
+        out['roofline'] = {'bound': e['bound'], 'kernel': name, 'launches_per_step': v[0], 'avg_launch_us': round(v[1] / max(v[0], 1) * 1e3, 2), 'achieved': ach,
+                           'peak': peak, 'unit': 'GB/s' if hbm else 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': e.get('traffic'),
+                           'algorithmic_bytes_per_launch': e['algorithmic_bytes_per_launch'], 'event_bracket_overhead_us': round(bracket_us, 2),
+                           'note': 'entry = one C-ABI call (a BN call is its reduce / finalize / apply launches together); bytes = every tensor once per pass that needs it'}
+        out['roofline_by_kernel'] = {k: entry(k, vv) for k, vv in sorted(rated.items(), key=lambda kv: -kv[1][1])[:10]}
+    out['calls_per_step'] = {k: int(v[0]) for k, v in table.items() if v[0] > 0}
+    return out
 
 
 def host_threads():
@@ -384,11 +485,8 @@ def main():
                'config': {'workload': '{} {} {}x{} synthetic training step (BASELINE {}), batch={}/GPU'.format(title[0], args.dtype, title[1], title[1], title[2], args.batch),
                           'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world), 'ema': not args.no_ema, 'fetch': False},
                'conv_macs_per_image': int(model.conv_macs), 'params': int(model.params)}
-        if world == 1:
-            table = instrumented_pass(model, args.dtype, layers=args.layers)
-            table.pop('_bracket_us')
-            out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 14)]}
-            out['kernel_ms_total'] = round(sum(v[1] for v in table.values()), 3)
+        if world == 1 and not args.no_roofline:
+            out.update(streaming_roofline(model, args.dtype, args.batch, args.model, layers=args.layers, all_kernels=args.all_kernels))
         if rank == 0:
             print(json.dumps(out))
         return
@@ -463,6 +561,9 @@ def main():
                 dt3 = timed(o3, args.steps, args.warmup, 1, False)
                 out[key] = {'value': round(bsz * args.steps / dt3, 2), 'unit': 'images/sec', 'ms_per_step': round(dt3 / args.steps * 1e3, 3), 'batch': bsz,
                             'config': 'BASELINE configs[3] (EfficientNet-B0, 224x224)' if mdl == 'efficientnet_b0' else 'BASELINE configs[4] on one GPU (DeepLabv3+, 513x513)'}
+                sr = streaming_roofline(m3, 'bf16', bsz, mdl)                # (`bench.py --model ...` prints the full table)
+                if 'roofline' in sr:
+                    out[key]['roofline'] = sr['roofline']
                 del m3, o3
                 torch.cuda.empty_cache()
         if not args.no_cpu_baseline:

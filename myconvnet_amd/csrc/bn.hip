@@ -891,9 +891,21 @@ __global__ __launch_bounds__(FIN_CH * FIN_LANES) void bn_fwd_finalize_fused_kern
     double sm = 0.0, sq = 0.0;
     if (c < C) {
         if (FOLDED) {
-            for (int k = lane; k < nrows; k += FIN_LANES) {
-                sm += fold[((long)k * 2 + 0) * C + c];
-                sq += fold[((long)k * 2 + 1) * C + c];
+            constexpr int U = 4;                            // (all 2U loads of a trip before the first add, as fin_reduce)
+            for (int k = lane; k < nrows; k += U * FIN_LANES) {
+                double v0[U], v1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long row = k + u * FIN_LANES < nrows ? k + u * FIN_LANES : k;
+                    v0[u] = fold[(row * 2 + 0) * C + c];
+                    v1[u] = fold[(row * 2 + 1) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = k + u * FIN_LANES < nrows;
+                    sm += ok ? v0[u] : 0.0;
+                    sq += ok ? v1[u] : 0.0;
+                }
             }
         } else if (rpp < 0) {
             compact_partials(part, nrows, -rpp, C, c, lane, sm, sq);
@@ -1233,12 +1245,205 @@ extern "C" int mcn_bn_bwd(const void* dy, const void* x, const void* y, const ui
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd: dtype %d unsupported", (int)dtype);
 }
 
+// ---- the same two passes in BLOCK form (round 3) for the stem geometry: H, W even, no leading pad (TF SAME on an even map) ----------------
+// A thread owns one 16-byte chunk of the 2 x 2 input pixels (2a + dy, 2b + dx): the only windows that see them are (a, b), (a-1, b),
+// (a, b-1), (a-1, b-1), so their pooled gradients and arg-max codes are loaded ONCE for the four pixels (the per-pixel form gathers
+// four windows per pixel — 96 bytes of L1 / L2 traffic per 16-byte chunk of x — and pays two integer divisions per pixel: 2.1-3.5 TB/s
+// on the largest tensor of the network).  Contributions are summed in the per-pixel form's order: the routed gradient is bit-identical.
+// raw form: the four windows' chunks stay packed (16 + 8 bytes each) and a pixel's gradient is unpacked when that pixel is processed — the
+// first build unpacked everything up front (2 x 2 x 8 floats each of x, the routed gradient and the window gradients): 175 VGPRs in
+// the 2-byte apply kernel = two waves per SIMD, slower than the per-pixel form.
+template <typename T, int VEC>
+struct PoolBlock {
+    Chunk<T> gp[2][2];
+    unsigned long long ac[2][2];          // arg-max codes, one byte per channel (all 0xff: window outside the map)
+    long xoff[2][2];
+};
+template <typename T, int VEC>
+__device__ __forceinline__ void pool_block_load(const T* __restrict__ dp, const int8_t* __restrict__ arg, const PoolRoute& P, unsigned q, int C, int col, PoolBlock<T, VEC>& B) {
+    const unsigned W2 = (unsigned)P.W >> 1, H2 = (unsigned)P.H >> 1;
+    const unsigned q2 = q / W2;
+    const int b = (int)(q - q2 * W2);
+    const int n = (int)(q2 / H2), a = (int)(q2 - (unsigned)n * H2);
+#pragma unroll
+    for (int al = 0; al < 2; ++al)
+#pragma unroll
+        for (int be = 0; be < 2; ++be) {
+            const int oy = a - al, ox = b - be;
+            const bool ok = oy >= 0 && ox >= 0 && oy < P.OH && ox < P.OW;
+            const long o = (((long)n * P.OH + (ok ? oy : 0)) * P.OW + (ok ? ox : 0)) * C + (long)col * VEC;
+            B.gp[al][be] = load_chunk<T>(dp + o);
+            unsigned long long c8;
+            if constexpr (VEC == 8) c8 = *reinterpret_cast<const unsigned long long*>(arg + o);
+            else c8 = *reinterpret_cast<const unsigned*>(arg + o);
+            B.ac[al][be] = ok ? c8 : ~0ull;
+        }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) B.xoff[dy][dx] = (((long)n * P.H + 2 * a + dy) * P.W + 2 * b + dx) * C + (long)col * VEC;
+}
+// routed gradient of pixel (dy, dx) of the block, contributions summed in the per-pixel form's order, rounded to the storage type
+template <typename T, int VEC>
+__device__ __forceinline__ void pool_block_pixel(const PoolBlock<T, VEC>& B, int dy, int dx, float (&g)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+#pragma unroll
+    for (int al = 0; al < 2; ++al)
+#pragma unroll
+        for (int be = 0; be < 2; ++be) {
+            if (dy + 2 * al > 2 || dx + 2 * be > 2) continue;      // window (a - al, b - be) holds the pixel at filter position (dy + 2 al, dx + 2 be)
+            const unsigned code = (unsigned)((dy + 2 * al) * 3 + (dx + 2 * be));
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (((unsigned)(B.ac[al][be] >> (8 * i)) & 0xffu) == code) g[i] += B.gp[al][be].get(i);
+        }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = to_f32(from_f32<T>(g[i]));
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_poolblk_kernel(const T* __restrict__ dp, const int8_t* __restrict__ arg, const PoolRoute P, const T* __restrict__ x,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ part, long MB, int C, int TX, int TY, long rpb) {
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const bool active = ty < TY && col * VEC < C;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+        ldc<VEC>(mean + col * VEC, mu);
+        ldc<VEC>(invstd + col * VEC, is);
+        ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+        ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] *= is[i];
+            sh[i] -= mu[i] * sc[i];
+        }
+        const long q0 = (long)blockIdx.y * rpb, q1 = min(MB, q0 + rpb);
+        for (long q = q0 + ty; q < q1; q += TY) {
+            PoolBlock<T, VEC> B;
+            pool_block_load<T, VEC>(dp, arg, P, (unsigned)q, C, col, B);
+            Chunk<T> xr[2][2];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) xr[dy][dx] = load_chunk<T>(x + B.xoff[dy][dx]);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float g[VEC];
+                    pool_block_pixel<T, VEC>(B, dy, dx, g);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float v = xr[dy][dx].get(i);
+                        const float gg = fmaf(v, sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+                        s1[i] += gg;
+                        s2[i] = fmaf(gg, (v - mu[i]) * is[i], s2[i]);
+                    }
+                }
+        }
+    }
+    float* r1p = red;
+    float* r2p = red + 256 * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            r1p[(ty * TX + tx) * VEC + i] = s1[i];
+            r2p[(ty * TX + tx) * VEC + i] = s2[i];
+        }
+    }
+    __syncthreads();
+    if (ty == 0 && col * VEC < C) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < TY; ++k) {
+                a += r1p[(k * TX + tx) * VEC + i];
+                b += r2p[(k * TX + tx) * VEC + i];
+            }
+            part[((long)blockIdx.y * 2 + 0) * C + col * VEC + i] = a;
+            part[((long)blockIdx.y * 2 + 1) * C + col * VEC + i] = b;
+        }
+    }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256, 4) void bn_bwd_apply_poolblk_kernel(const T* __restrict__ dp, const int8_t* __restrict__ arg, const PoolRoute P, const T* __restrict__ x,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float* __restrict__ coef, T* __restrict__ dx, long MB, int C,
+                                                                   int TX, int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float mu[VEC], is[VEC], ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
+    ldc<VEC>(mean + col * VEC, mu);
+    ldc<VEC>(invstd + col * VEC, is);
+    ldc<VEC>(coef + col * VEC, ca);
+    ldc<VEC>(coef + C + col * VEC, cb);
+    ldc<VEC>(coef + 2 * C + col * VEC, cc);
+    ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+    ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sc[i] *= is[i];
+        sh[i] -= mu[i] * sc[i];
+    }
+    const long q0 = (long)blockIdx.y * rpb, q1 = min(MB, q0 + rpb);
+    for (long q = q0 + ty; q < q1; q += TY) {
+        PoolBlock<T, VEC> B;
+        pool_block_load<T, VEC>(dp, arg, P, (unsigned)q, C, col, B);
+        Chunk<T> xr[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) xr[dy][dxx] = load_chunk<T>(x + B.xoff[dy][dxx]);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) {
+                float g[VEC];
+                pool_block_pixel<T, VEC>(B, dy, dxx, g);
+                Chunk<T> o;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float v = xr[dy][dxx].get(i);
+                    const float gg = fmaf(v, sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+                    const float xh = (v - mu[i]) * is[i];
+                    o.set(i, ca[i] * (gg - cb[i] - xh * cc[i]));
+                }
+                store_chunk<T>(dx + B.xoff[dy][dxx], o);
+                __builtin_amdgcn_sched_barrier(0);          // one pixel at a time: the scheduler would otherwise unpack all four up front
+            }
+    }
+}
+
 template <typename T, int VEC>
 static int bn_bwd_pool_t(const void* dp, const int8_t* arg, const PoolRoute& P, const void* x, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, long M, int C, void* ws, hipStream_t st) {
-    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
+    // MCN_BN_POOL_BLOCK=0: the per-pixel form everywhere
+    static const int blk = [] { const char* e = getenv("MCN_BN_POOL_BLOCK"); return e ? atoi(e) : 1; }();
+    if (blk && P.padT == 0 && P.padL == 0 && P.H % 2 == 0 && P.W % 2 == 0 && 2 * P.OH == P.H && 2 * P.OW == P.W) {
+        const long MB = M / 4;                                       // 2 x 2 pixel blocks
+        const ColLayout L = make_layout(MB, C, VEC, bn_target<T>());
+        const dim3 grid(L.gx, L.gy), block(256);
+        hipLaunchKernelGGL((bn_bwd_reduce_poolblk_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dp, arg, P, (const T*)x, save_mean, save_invstd, gamma,
+                           beta, part, MB, C, L.TX, L.TY, L.rpb);
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
+                           dbeta, grad_scale, coef, 0);
+        MCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL((bn_bwd_apply_poolblk_kernel<T, VEC>), grid, block, 0, st, (const T*)dp, arg, P, (const T*)x, save_mean, save_invstd, gamma, beta, (const float*)coef,
+                           (T*)dx, MB, C, L.TX, L.TY, L.rpb);
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     const dim3 grid(L.gx, L.gy), block(256);
     hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dp, arg, P, (const T*)x, save_mean, save_invstd, gamma, beta,
                        part, M, C, L.TX, L.TY, L.rpb);
@@ -1253,7 +1458,8 @@ static int bn_bwd_pool_t(const void* dp, const int8_t* arg, const PoolRoute& P, 
 }
 // mcn_bn_bwd(act = ReLU, mask recomputed from x) for a BN whose output feeds ONLY a 3x3 / stride-2 max-pool: takes the POOLED
 // gradient dy_pooled [N,OH,OW,C] and the pool's arg-max instead of the full-resolution dy (same result as mcn_maxpool_bwd
-// followed by mcn_bn_bwd, bit for bit in dx; dgamma / dbeta up to fp32 summation order — the same order here).
+// followed by mcn_bn_bwd: the routed gradient itself is bit-identical; dgamma / dbeta and with them dx agree up to the order of the fp32 sums —
+// the 2 x 2 block form used for even maps without a leading pad sums the pixels in another order than mcn_bn_bwd).
 extern "C" int mcn_bn_bwd_maxpool(const void* dy_pooled, const int8_t* argmax, const void* x, const float* gamma, const float* beta, const float* save_mean,
                                   const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int32_t H, int32_t W, int32_t C,
                                   int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t padT, int32_t padL, int32_t OH, int32_t OW, mcn_dtype dtype, void* ws,

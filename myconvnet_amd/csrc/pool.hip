@@ -35,9 +35,12 @@ static inline unsigned pool_blocks(long n) {
 // AFF: the input is read through y0 = relu(x * scale[c] + shift[c]) rounded to the storage type — the batch-norm apply pass of the
 // layer in front (the ResNet stem: conv -> BN -> ReLU -> 3x3/2 pool) folded into the pool's loads, so that the normalised
 // tensor is never written or read.  Rounding before the comparison keeps value, ties and arg-max those of the unfused pair.
-template <typename T, int VEC, bool AFF = false>
+// KK / SS: compile-time window / stride (0 = run time).  With the stem's 3x3 / 2 as constants the tap loops unroll and the nine loads of a
+// window are issued back to back (run-time bounds made every tap a load -> wait -> compare round trip: 3.2 TB/s on the stem).
+template <typename T, int VEC, bool AFF = false, int KK = 0, int SS = 0>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, PoolParams p,
                                                           const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
+    const int KH = KK ? KK : p.KH, KW = KK ? KK : p.KW, SH = SS ? SS : p.SH, SW = SS ? SS : p.SW;
     const unsigned cv = (unsigned)(p.C / VEC);
     const unsigned total = (unsigned)((long)p.N * p.OH * p.OW * cv);       // (host: < 2^32 — 32-bit index arithmetic: four 64-bit divisions per item cost more than the window)
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -55,11 +58,39 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
         }
-        for (int kr = 0; kr < p.KH; ++kr) {
-            const int iy = oy * p.SH + kr - p.padT;
+        if constexpr (KK > 0) {
+            // all KK x KK loads first (clamped addresses, no branches), then the affine / compare chain
+            float v[KK][KK][VEC];
+            bool okk[KK][KK];
+#pragma unroll
+            for (int kr = 0; kr < KK; ++kr) {
+                const int iy = oy * SH + kr - p.padT;
+                const bool yok = (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+                for (int ks = 0; ks < KK; ++ks) {
+                    const int ix = ox * SW + ks - p.padL;
+                    okk[kr][ks] = yok && (unsigned)ix < (unsigned)p.W;
+                    pld<T, VEC>(x + (((long)n * p.H + (okk[kr][ks] ? iy : 0)) * p.W + (okk[kr][ks] ? ix : 0)) * p.C + c, v[kr][ks]);
+                }
+            }
+#pragma unroll
+            for (int kr = 0; kr < KK; ++kr)
+#pragma unroll
+                for (int ks = 0; ks < KK; ++ks) {
+                    if constexpr (AFF) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[kr][ks][i] = to_f32(from_f32<T>(fmaxf(fmaf(v[kr][ks][i], sc[i], sh[i]), 0.f)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (okk[kr][ks] && v[kr][ks][i] > best[i]) { best[i] = v[kr][ks][i]; bi[i] = kr * KK + ks; }
+                }
+        } else
+        for (int kr = 0; kr < KH; ++kr) {
+            const int iy = oy * SH + kr - p.padT;
             const bool yok = (unsigned)iy < (unsigned)p.H;
-            for (int ks = 0; ks < p.KW; ++ks) {
-                const int ix = ox * p.SW + ks - p.padL;
+            for (int ks = 0; ks < KW; ++ks) {
+                const int ix = ox * SW + ks - p.padL;
                 const bool ok = yok && (unsigned)ix < (unsigned)p.W;     // clamped address + select: no branch per load
                 float v[VEC];
                 pld<T, VEC>(x + (((long)n * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * p.C + c, v);
@@ -69,7 +100,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    if (ok && v[i] > best[i]) { best[i] = v[i]; bi[i] = kr * p.KW + ks; }   // strict '>' : first maximum wins
+                    if (ok && v[i] > best[i]) { best[i] = v[i]; bi[i] = kr * KW + ks; }   // strict '>' : first maximum wins
             }
         }
         const long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
@@ -126,13 +157,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
             pst<T, VEC>(dx + (((long)n * p.H + iy) * p.W + ix) * p.C + c, acc);
             continue;
         }
-#pragma unroll
+        // (no unroll request here: with a run-time window the optimizer cannot honour it — nine -Wpass-failed notes per build — and the
+        // instantiations with a constant window unroll by themselves)
         for (int kr = 0; kr < KH; ++kr) {
             const int ty = iy + p.padT - kr;
             if (ty < 0 || ty % SH) continue;
             const int oy = ty / SH;
             if (oy >= p.OH) continue;
-#pragma unroll
             for (int ks = 0; ks < KW; ++ks) {
                 const int tx = ix + p.padL - ks;
                 if (tx < 0 || tx % SW) continue;
@@ -354,14 +385,18 @@ extern "C" int mcn_maxpool_fwd_affine_relu(const void* x, const float* scale, co
     const PoolParams p = {N, H, W, C, KH, KW, SH, SW, padT, padL, OH, OW};
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * OH * OW * C;
+    const bool k3s2 = KH == 3 && KW == 3 && SH == 2 && SW == 2;      // the stem: window and stride as compile-time constants
     if (dtype == MCN_F32) {
-        if (C % 4 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4, true>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p, scale, shift);
+        if (C % 4 == 0 && k3s2) hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4, true, 3, 2>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p, scale, shift);
+        else if (C % 4 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4, true>), dim3(pool_blocks(total / 4)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p, scale, shift);
         else hipLaunchKernelGGL((maxpool_fwd_kernel<float, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, p, scale, shift);
     } else if (dtype == MCN_BF16) {
-        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p, scale, shift);
+        if (C % 8 == 0 && k3s2) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8, true, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p, scale, shift);
+        else if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p, scale, shift);
         else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, p, scale, shift);
     } else if (dtype == MCN_F16) {
-        if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p, scale, shift);
+        if (C % 8 == 0 && k3s2) hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 8, true, 3, 2>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p, scale, shift);
+        else if (C % 8 == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 8, true>), dim3(pool_blocks(total / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p, scale, shift);
         else hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t, 1, true>), dim3(pool_blocks(total)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, p, scale, shift);
     } else MCN_FAIL(MCN_E_UNSUPPORTED, "maxpool_fwd_affine_relu: dtype %d unsupported", (int)dtype);
     MCN_CHECK_LAUNCH();

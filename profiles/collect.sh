@@ -20,4 +20,13 @@ for dt in fp32 bf16; do
     echo "pmc $c $dt done"
   done
 done
-cd $R && python3 profiles/summarize.py $O ${ROUND:-round2}
+# the other single-GPU configurations of BASELINE.json (configs[3] EfficientNet-B0 B=512, configs[4] DeepLabv3+ 513x513 B=16): serial kernel
+# table + the two PMC passes, so that their bench lines carry a roofline object with measured traffic as the headline does
+for m in efficientnet_b0 deeplabv3plus; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_${m}_bf16 -o s -- python3 $R/bench.py --model $m --dtype bf16 --steps 10 --warmup 3 --no-overlap > $O/serial_${m}_bf16.json 2> $O/serial_${m}_bf16.err
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_${m}_bf16 -o p -- python3 $R/bench.py --model $m --dtype bf16 --steps 1 --warmup 1 > $O/pmc_${c}_${m}_bf16.json 2> $O/pmc_${c}_${m}_bf16.err
+  done
+  echo "$m done"
+done
+cd $R && python3 profiles/summarize.py $O ${ROUND:-round3}

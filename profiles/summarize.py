@@ -76,21 +76,31 @@ def build_id():
 
 def main(root, rnd='round2'):
     here = os.path.dirname(os.path.abspath(__file__))
-    for dt in ('fp32', 'bf16'):
+    # (tag of the raw directories / output files, --dtype, batch, PMC command)
+    configs = [('fp32', 'fp32', 256, 'python3 bench.py --steps 1 --warmup 1 --dtype fp32 --no-secondary --no-cpu-baseline'),
+               ('bf16', 'bf16', 256, 'python3 bench.py --steps 1 --warmup 1 --dtype bf16 --no-secondary --no-cpu-baseline'),
+               ('efficientnet_b0_bf16', 'bf16', 512, 'python3 bench.py --model efficientnet_b0 --dtype bf16 --steps 1 --warmup 1'),
+               ('deeplabv3plus_bf16', 'bf16', 16, 'python3 bench.py --model deeplabv3plus --dtype bf16 --steps 1 --warmup 1')]
+    for dt, dtype, batch, cmd in configs:
         for src, tag in (('stats_', ''), ('serial_', 'serial_')):
             st = glob.glob(os.path.join(root, src + dt, '**', '*kernel_stats.csv'), recursive=True)
             if st:
-                with open(st[0]) as fh, open(os.path.join(here, '%s_%s_b256_%skernel_stats.csv' % (rnd, dt, tag)), 'w') as out:
+                with open(st[0]) as fh, open(os.path.join(here, '%s_%s_b%d_%skernel_stats.csv' % (rnd, dt, batch, tag)), 'w') as out:
                     rd = csv.reader(fh)
                     wr = csv.writer(out, quoting=csv.QUOTE_MINIMAL)
                     for i, row in enumerate(rd):
                         if i and row:
                             row[0] = short(row[0]) if row[0].startswith('_Z') else row[0]
                         wr.writerow(row)
+        bench_line = None
         for src, tag in (('bench_', ''), ('serial_', 'serial_')):
             bj = os.path.join(root, '%s%s.json' % (src, dt))
             if os.path.exists(bj) and os.path.getsize(bj):
-                shutil.copy(bj, os.path.join(here, '%s_%s_b256_%sbench.json' % (rnd, dt, tag)))
+                shutil.copy(bj, os.path.join(here, '%s_%s_b%d_%sbench.json' % (rnd, dt, batch, tag)))
+                try:
+                    bench_line = json.load(open(bj))
+                except ValueError:
+                    pass
         fe = counter_rows(os.path.join(root, 'pmc_FETCH_SIZE_' + dt))
         wr = counter_rows(os.path.join(root, 'pmc_WRITE_SIZE_' + dt))
         if not fe or not wr:
@@ -104,9 +114,13 @@ def main(root, rnd='round2'):
             write = wr[k][1] / n * 1024.0
             kernels[k] = {'launches_profiled': n, 'fetch_size_bytes_raw': round(fetch), 'write_size_bytes': round(write),
                           'bytes_per_launch': round(2.0 * fetch + write)}
-        out = {'batch': 256, 'dtype': dt, 'build_id': build_id(), 'command': 'python3 bench.py --steps 1 --warmup 1 --dtype %s --no-secondary --no-cpu-baseline' % dt,
+        out = {'batch': batch, 'dtype': dtype, 'build_id': build_id(), 'command': cmd,
+               # the profiled command runs 1 warm-up + 1 timed step + the 3 repetitions of bench.py's instrumented pass
+               'steps_profiled': 5,
                'formula': 'bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged over every launch of the kernel in the run',
                'kernels': kernels}
+        if bench_line and 'calls_per_step' in bench_line:
+            out['calls_per_step'] = bench_line['calls_per_step']          # C-ABI calls per step (bench.py sums a call's kernels: CALL_KERNELS)
         with open(os.path.join(here, 'pmc_traffic_%s.json' % dt), 'w') as fh:
             json.dump(out, fh, indent=1, sort_keys=True)
         top = sorted(kernels.items(), key=lambda kv: -kv[1]['bytes_per_launch'] * kv[1]['launches_profiled'])[:6]

@@ -904,7 +904,9 @@ def test_bn_relu_maxpool_in_one_pass(case, dtype):
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 'SAME'), (3, 9, 11, 16, 'SAME'), (2, 13, 12, 8, 'VALID'), (4, 32, 32, 32, 'SAME')])
 def test_bn_backward_routes_maxpool_gradient(case, dtype):
     """mcn_bn_bwd_maxpool (BN + ReLU in front of a 3x3 / 2 max-pool: the pooled gradient is routed by arg-max inside the two BN
-    passes) against mcn_maxpool_bwd followed by mcn_bn_bwd: dx, dgamma and dbeta bit for bit."""
+    passes) against mcn_maxpool_bwd followed by mcn_bn_bwd: dx, dgamma and dbeta bit for bit in the per-pixel form; the 2 x 2 block
+    form (even maps without a leading pad: the stem) sums the pixels in another order — dgamma / dbeta to fp32 summation accuracy, dx
+    to one rounding of the storage type around them."""
     from myconvnet_amd import _ffi
     u = _u()
     lib = _ffi.lib
@@ -936,9 +938,18 @@ def test_bn_backward_routes_maxpool_gradient(case, dtype):
     dg, db = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
     _ffi.check(lib.mcn_bn_bwd_maxpool(dp.data_ptr(), arg.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                       0.5, n, h, w_, c, 3, 3, 2, 2, pads[0], pads[2], oh, ow, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, u.stream()))
-    np.testing.assert_array_equal(u.host(dx), u.host(dx_ref))
-    np.testing.assert_array_equal(u.host(dg), u.host(dg_ref))
-    np.testing.assert_array_equal(u.host(db), u.host(db_ref))
+    block_form = pads[0] == 0 and pads[2] == 0 and h % 2 == 0 and w_ % 2 == 0
+    if not block_form:
+        np.testing.assert_array_equal(u.host(dx), u.host(dx_ref))
+        np.testing.assert_array_equal(u.host(dg), u.host(dg_ref))
+        np.testing.assert_array_equal(u.host(db), u.host(db_ref))
+    else:
+        np.testing.assert_allclose(u.host(dg), u.host(dg_ref), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(u.host(db), u.host(db_ref), rtol=2e-5, atol=1e-6)
+        a, b = u.host(dx).astype(np.float64), u.host(dx_ref).astype(np.float64)
+        ulp = {'float32': 2.0 ** -23, 'bfloat16': 2.0 ** -8, 'float16': 2.0 ** -11}[dtype]
+        assert np.abs(a - b).max() <= 2 * ulp * np.abs(b).max() + 1e-7            # the coefficients moved by ~1e-7: at most a rounding step
+        assert np.mean(a != b) <= (0.02 if dtype != 'float32' else 1.0)         # ... and in a 2-byte type for few elements
     assert np.abs(u.host(dx)).max() > 0
 
 
