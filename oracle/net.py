@@ -21,19 +21,28 @@ from . import ops
 class V(object):
     """A value on the oracle's tape: array + accumulated gradient.  `q` (optional) rounds activations and their
     gradients to the storage precision of the low-precision mode (see Tape.quant)."""
-    __slots__ = ('a', 'g', 'q')
+    __slots__ = ('a', 'g', 'q', 'lazy', 'fused')
 
-    def __init__(self, a, q=None):
+    def __init__(self, a, q=None, lazy=None, fused=False):
+        """lazy (fused rounding mode): the rounding function of a value that is NOT stored yet — the output of a BN (or residual add)
+        that the device keeps in registers until the activation behind it: relu / swish / add consume it unrounded, any other reader
+        rounds it first (Tape._mat).  Such a value has no stored gradient either."""
         self.q = q
+        self.lazy = lazy
+        self.fused = fused
         self.a = a if q is None else q(a)
         self.g = None
 
     def acc(self, g):
-        if self.q is not None:
+        if self.q is None:
+            self.g = g if self.g is None else self.g + g
+        elif self.fused:
+            # the device adds a contribution to the stored gradient inside the producing kernel's epilogue: the fp32 result is added to
+            # the stored value and the SUM is rounded (mcn_conv2d_dgrad accumulate / _addmasked) — one rounding per contribution
+            self.g = self.q(g if self.g is None else self.g + g)
+        else:
             g = self.q(g)
-        self.g = g if self.g is None else self.g + g
-        if self.q is not None:
-            self.g = self.q(self.g)
+            self.g = g if self.g is None else self.q(self.g + g)
 
 
 def trainable_name(name, blocks_to_train):
@@ -48,11 +57,15 @@ def trainable_name(name, blocks_to_train):
 
 
 class Tape(object):
-    def __init__(self, params, train=True, bn_stats=None, eps=1e-3, quant=None, blocks_to_train=None, update_batch_norm=None):
+    def __init__(self, params, train=True, bn_stats=None, eps=1e-3, quant=None, blocks_to_train=None, update_batch_norm=None, fused_rounding=False):
         """quant: optional rounding function emulating low-precision STORAGE of activations / activation gradients and
         the per-use cast of the weights (reference half_precision structure, convnet.py:63,1421-1422,1878-1879: fp32
-        master weights, BN statistics and all accumulation in fp32).  Used to compare the bf16 device path like with like."""
+        master weights, BN statistics and all accumulation in fp32).  Used to compare the bf16 device path like with like.
+        fused_rounding: round where the DEVICE rounds: BN + activation, BN + residual add + ReLU and the
+        shortcut-affine + add form are one pass with ONE rounding of the result (the op-by-op mode rounds after BN, after the add and
+        after the activation), and a gradient contribution is added to the stored gradient unrounded (see V.acc)."""
         self.quant = quant
+        self.fused = bool(fused_rounding) and quant is not None
         self.params = params          # name -> ndarray
         self.pv = {}                  # name -> V (created on first use)
         self.train = train
@@ -67,6 +80,11 @@ class Tape(object):
         # rounding of zero may fall on the other side of the ReLU on the device (fp32 sums) than here (float64).  `tie_tol` > 0 records the
         # elements with |z| <= tie_tol * rms(z) as (ReLU ordinal, flat index) in `near_ties`; `relu_flips` {ordinal: flat indices} inverts
         # the decision of those elements (forward value and gradient mask).
+        # teacher forcing at residual-unit boundaries (test infrastructure for the low-precision device comparison): `force_act[name]` replaces
+        # the activation at barrier `name`, `force_grad[name]` the gradient that flows back through it — with the device's stored tensors
+        # there, rounding differences cannot cascade beyond one residual unit (the tiny test nets amplify one bf16 ulp 20-50x over their depth)
+        self.force_act = {}
+        self.force_grad = {}
         self.tie_tol = 0.0
         self.near_ties = []
         self.relu_flips = {}
@@ -77,12 +95,26 @@ class Tape(object):
             self.pv[name] = V(self.params[name])
         return self.pv[name]
 
+    def _v(self, a):
+        """a stored activation: rounded to the storage type"""
+        return V(a, self.quant, fused=self.fused)
+
+    def _mat(self, x):
+        """fused rounding mode: a value the device has not stored yet is stored (rounded) for this reader"""
+        if getattr(x, 'lazy', None) is not None:
+            x.a = x.lazy(x.a)
+            x.q, x.lazy, x.fused = self.quant, None, self.fused
+            if x.g is not None:
+                x.g = x.q(x.g)
+        return x
+
     # ---- ops ---------------------------------------------------------------------------
     def conv(self, x, scope, stride, padding='SAME', dilation=1, biased=False):
+        self._mat(x)
         w = self.p(scope + '/weights')
         q = self.quant
         wq = w.a if q is None else q(w.a)
-        y = V(ops.conv2d_fwd(x.a, wq, stride, padding, dilation), q)
+        y = V(ops.conv2d_fwd(x.a, wq, stride, padding, dilation), q, fused=self.fused)
 
         def bw():
             w.acc(ops.conv2d_wgrad(x.a, y.g, w.a.shape, stride, padding, dilation))
@@ -91,7 +123,7 @@ class Tape(object):
         self.bw.append(bw)
         if biased:
             b = self.p(scope + '/biases')
-            y2 = V(ops.bias_add_fwd(y.a, b.a), q)
+            y2 = V(ops.bias_add_fwd(y.a, b.a), q, fused=self.fused)
 
             def bwb():
                 b.acc(ops.bias_add_bwd(y2.g))
@@ -107,13 +139,14 @@ class Tape(object):
         return trainable_name(scope, self.blocks_to_train)
 
     def bn(self, x, scope):
+        self._mat(x)
         gamma = self.p(scope + '/gamma')
         beta = self.p(scope + '/beta')
         if self.train and not self.bn_updates(scope):
             # frozen statistics (convnet.py:1915-1923): fused_batch_norm(is_training=False) on the running mean / variance
             # also while training; its gradient is the plain affine one
             mu, sigma = self.bn_stats[scope + '/mu'], self.bn_stats[scope + '/sigma']
-            y = V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant)
+            y = V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant, fused=self.fused)
 
             def bwf():
                 dx, dg, db = ops.bn_bwd_frozen(y.g, x.a, gamma.a, mu, sigma, self.eps)
@@ -125,7 +158,7 @@ class Tape(object):
         if self.train:
             ya, bm, bv, sm, si = ops.bn_fwd_train(x.a, gamma.a, beta.a, self.eps)
             self.batch_stats[scope] = (bm, bv)
-            y = V(ya, self.quant)
+            y = V(ya, None, lazy=self.quant) if self.fused else V(ya, self.quant)
 
             def bw():
                 dx, dg, db = ops.bn_bwd(y.g, x.a, gamma.a, sm, si)
@@ -136,7 +169,7 @@ class Tape(object):
             return y
         mu = self.bn_stats[scope + '/mu']
         sigma = self.bn_stats[scope + '/sigma']
-        return V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant)
+        return V(ops.bn_fwd_infer(x.a, gamma.a, beta.a, mu, sigma, self.eps), self.quant, fused=self.fused)
 
     def relu(self, x):
         k = self.relu_count
@@ -147,17 +180,33 @@ class Tape(object):
             self.near_ties += [(k, int(i)) for i in np.flatnonzero(z <= self.tie_tol * rms)]
         flips = self.relu_flips.get(k)
         if flips is None:
-            y = V(ops.relu_fwd(x.a), self.quant)
+            y = V(ops.relu_fwd(x.a), self.quant, fused=self.fused)
             self.bw.append(lambda: x.acc(ops.relu_bwd(y.g, y.a)))
             return y
         mask = (x.a > 0)
         mask.reshape(-1)[np.asarray(flips, dtype=np.int64)] ^= True
-        y = V(x.a * mask, self.quant)
+        y = V(x.a * mask, self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(y.g * mask))
         return y
 
+    def barrier(self, x, name):
+        """identity on the value and its gradient unless the tape holds a forced activation / gradient for `name` (see __init__)"""
+        if name not in self.force_act and name not in self.force_grad:
+            return x
+        self._mat(x)
+        y = V(np.asarray(self.force_act.get(name, x.a), dtype=x.a.dtype), None)
+        y.q, y.fused = x.q, x.fused                    # (a forced value is a stored tensor: already in the storage type)
+        self.bw.append(lambda: x.acc(np.asarray(self.force_grad[name], dtype=x.a.dtype) if name in self.force_grad else y.g))
+        return y
+
     def add(self, x, skip):
-        y = V(ops.add_fwd(x.a, skip.a), self.quant)
+        if self.fused:
+            # device: y = act(bn(x) + skip) in one pass — the skip operand is a stored tensor (a shortcut BN's output is rounded to the
+            # storage type where the stored tensor would have been), the sum stays in registers
+            self._mat(skip)
+            y = V(ops.add_fwd(x.a, skip.a), None, lazy=self.quant)
+        else:
+            y = V(ops.add_fwd(x.a, skip.a), self.quant)
 
         def bw():
             x.acc(y.g)
@@ -166,10 +215,11 @@ class Tape(object):
         return y
 
     def dwconv(self, x, scope, stride, padding='SAME', dilation=1):
+        self._mat(x)
         w = self.p(scope + '/weights')
         q = self.quant
         wq = w.a if q is None else q(w.a)
-        y = V(ops.depthwise_conv2d_fwd(x.a, wq, stride, padding, dilation), q)
+        y = V(ops.depthwise_conv2d_fwd(x.a, wq, stride, padding, dilation), q, fused=self.fused)
 
         def bw():
             w.acc(ops.depthwise_conv2d_wgrad(x.a, y.g, w.a.shape, stride, padding, dilation))
@@ -179,18 +229,21 @@ class Tape(object):
         return y
 
     def swish(self, x):
-        y = V(ops.swish_fwd(x.a), self.quant)
+        y = V(ops.swish_fwd(x.a), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.swish_bwd(y.g, x.a)))
         return y
 
     def sigmoid(self, x):
-        y = V(ops.sigmoid_fwd(x.a), self.quant)
+        self._mat(x)
+        y = V(ops.sigmoid_fwd(x.a), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.sigmoid_bwd(y.g, y.a)))
         return y
 
     def scale_channels(self, x, m):
         """x * m, m: [N,1,1,C] (SE mask)."""
-        y = V(ops.channel_scale_fwd(x.a, m.a), self.quant)
+        self._mat(x)
+        self._mat(m)
+        y = V(ops.channel_scale_fwd(x.a, m.a), self.quant, fused=self.fused)
 
         def bw():
             dx, dm = ops.channel_scale_bwd(y.g, x.a, m.a)
@@ -200,32 +253,38 @@ class Tape(object):
         return y
 
     def scale_samples(self, x, s):
+        self._mat(x)
         """x * s[n] with a constant per-sample factor (stochastic depth survival / (1 - rate))."""
-        y = V(ops.sample_scale_fwd(x.a, s.astype(x.a.dtype)), self.quant)
+        y = V(ops.sample_scale_fwd(x.a, s.astype(x.a.dtype)), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.sample_scale_fwd(y.g, s.astype(x.a.dtype))))
         return y
 
     def mul_const(self, x, m):
+        self._mat(x)
         """x * m with a constant mask of x's shape (tf.nn.dropout with the keep mask already scaled by 1/(1-rate))."""
         m = m.astype(x.a.dtype)
-        y = V(x.a * m, self.quant)
+        y = V(x.a * m, self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(y.g * m))
         return y
 
     def mean_keepdims(self, x):
+        self._mat(x)
         """tf.reduce_mean(x, [1,2], keepdims=True) (models/efficientnet.py:183)."""
         n, c = x.a.shape[0], x.a.shape[-1]
-        y = V(ops.global_avgpool_fwd(x.a).reshape(n, 1, 1, c), self.quant)
+        y = V(ops.global_avgpool_fwd(x.a).reshape(n, 1, 1, c), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g.reshape(n, c), x.a.shape)))
         return y
 
     def resize(self, x, out_hw, align_corners=True):
-        y = V(ops.resize_bilinear_fwd(x.a, out_hw, align_corners), self.quant)
+        self._mat(x)
+        y = V(ops.resize_bilinear_fwd(x.a, out_hw, align_corners), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.resize_bilinear_bwd(y.g, x.a.shape, align_corners)))
         return y
 
     def concat(self, xs):
-        y = V(ops.concat_fwd([v.a for v in xs]), self.quant)
+        for v_ in xs:
+            self._mat(v_)
+        y = V(ops.concat_fwd([v.a for v in xs]), self.quant, fused=self.fused)
 
         def bw():
             for v, g in zip(xs, ops.concat_bwd(y.g, [v.a.shape[-1] for v in xs])):
@@ -234,27 +293,31 @@ class Tape(object):
         return y
 
     def max_pool(self, x, k, s, padding='SAME'):
+        self._mat(x)
         ya, arg = ops.maxpool_fwd(x.a, k, s, padding)
-        y = V(ya, self.quant)
+        y = V(ya, self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.maxpool_bwd(y.g, arg, x.a.shape, k, s, padding)))
         return y
 
     def avg_pool(self, x, k, s, padding='SAME'):
-        y = V(ops.avgpool_fwd(x.a, k, s, padding), self.quant)
+        self._mat(x)
+        y = V(ops.avgpool_fwd(x.a, k, s, padding), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.avgpool_bwd(y.g, x.a.shape, k, s, padding)))
         return y
 
     def global_avgpool(self, x):
-        y = V(ops.global_avgpool_fwd(x.a), self.quant)
+        self._mat(x)
+        y = V(ops.global_avgpool_fwd(x.a), self.quant, fused=self.fused)
         self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g, x.a.shape)))
         return y
 
     def fc(self, x, scope):
+        self._mat(x)
         w = self.p(scope + '/weights')
         b = self.p(scope + '/biases')
         q = self.quant
         wq = w.a if q is None else q(w.a)
-        y = V(ops.fc_fwd(x.a, wq, b.a), q)
+        y = V(ops.fc_fwd(x.a, wq, b.a), q, fused=self.fused)
 
         def bw():
             dx, dw, db = ops.fc_bwd(y.g, x.a, wq)
@@ -356,6 +419,7 @@ class ResNetSpec(object):
         d['block_0/conv_0/bn'] = h
         h = t.relu(h)
         h = t.max_pool(h, 3, 2, 'SAME')
+        h = t.barrier(h, 'block_0')
         d['block_0'] = h
         cin = ch[0]
         for i in range(1, len(ch)):
@@ -382,6 +446,7 @@ class ResNetSpec(object):
                     y = t.conv(y, name + '/conv_1', 1)
                     y = t.bn(y, name + '/conv_1/bn')
                 h = t.relu(t.add(y, skip))
+                h = t.barrier(h, name)
                 d[name] = h
                 cin = cout
             d['block_{}'.format(i)] = h
@@ -676,16 +741,18 @@ class TrainState(object):
         self.step = 0
 
 
-def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False, quant=None, tie_tol=0.0, relu_flips=None):
+def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False, quant=None, tie_tol=0.0, relu_flips=None, fused_rounding=False,
+                 force_act=None, force_grad=None):
     hp = dict(DEFAULT_HP, **(hp or {}))
     params = state.ema if use_ema else state.params
     stats = state.ema_stats if use_ema else state.stats
     t = Tape(params, train=train, bn_stats=stats, eps=hp['eps'], quant=quant, blocks_to_train=hp.get('blocks_to_train'),
-             update_batch_norm=hp.get('update_batch_norm'))
+             update_batch_norm=hp.get('update_batch_norm'), fused_rounding=fused_rounding)
     t.tie_tol = float(tie_tol)
     t.relu_flips = dict(relu_flips or {})
+    t.force_act, t.force_grad = dict(force_act or {}), dict(force_grad or {})
     dt = next(iter(params.values())).dtype
-    x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']), quant)
+    x = V(ops.input_prep(x_raw.astype(dt), hp['image_mean'], hp['scale_factor']), quant, fused=t.fused)
     x.g = False
     if isinstance(spec, VGGSpec):
         out = spec.forward(t, x, hp['image_mean'], hp['scale_factor'])
@@ -709,6 +776,7 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
     ls = float(hp.get('loss_scaling_factor', 1.0))
     t.loss_scale = ls if ls > 1.0 else 1.0
     dlogits = dlogits * t.loss_scale
+    t._mat(out)
     out.g = dlogits if quant is None else quant(dlogits)
     return t, out, pred, loss, onehot
 
@@ -724,11 +792,12 @@ def copy_state(state):
 
 
 def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=None,
-               tower_batches=None, quant=None, probe=None):
+               tower_batches=None, quant=None, probe=None, fused_rounding=False):
     """One optimisation step.  `tower_batches` (list of (x,y)) restates the multi-tower path:
     gradients averaged over towers (optimizers.py:125-142), BN running stats chained
     (convnet.py:1899-1909), loss = mean of tower losses (convnet.py:510).
-    `probe` (test infrastructure, tests/flip_util.py): dict with 'tie_tol' and / or 'relu_flips' {(tower, ReLU ordinal): flat indices};
+    `probe` (test infrastructure, tests/flip_util.py): dict with 'tie_tol' and / or 'relu_flips' {(tower, ReLU ordinal): flat indices}, 'force_act' /
+    'force_grad' {barrier name: array} (Tape.barrier: teacher forcing at the residual-unit boundaries, single tower);
     on return probe['near_ties'] lists the (tower, ordinal, flat index) of the ReLU inputs within tie_tol * rms of zero."""
     hp = dict(DEFAULT_HP, **(hp or {}))
     towers = tower_batches if tower_batches is not None else [(x_raw, y_float)]
@@ -739,7 +808,8 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
         probe['near_ties'] = []
     for ti, (xr, yf) in enumerate(towers):
         flips = {k[1]: v for k, v in (probe or {}).get('relu_flips', {}).items() if k[0] == ti}
-        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant, tie_tol=(probe or {}).get('tie_tol', 0.0), relu_flips=flips)
+        t, out, pred, loss, _ = forward_loss(spec, state, xr, yf, hp, train=True, quant=quant, tie_tol=(probe or {}).get('tie_tol', 0.0), relu_flips=flips,
+                                             fused_rounding=fused_rounding, force_act=(probe or {}).get('force_act'), force_grad=(probe or {}).get('force_grad'))
         if probe is not None:
             probe['near_ties'] += [(ti, k, i) for k, i in t.near_ties]
         g = t.backward()

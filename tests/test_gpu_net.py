@@ -254,86 +254,105 @@ def bf16q(a):
     return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
 
 
-def test_resnet_step_bf16():
-    """bf16 storage (8 significant bits) through 53 conv+BN layers.  Compared like with like: the float64 oracle with
-    every activation / activation-gradient / per-use weight rounded to bf16 (oracle.net.Tape(quant=...)), i.e. the
-    reference's half-precision structure (fp32 masters, fp32 BN statistics, fp32 accumulation).  Rounding points differ
-    slightly where the device fuses BN+add+ReLU (one rounding instead of three), hence aggregate criteria; the 1e-3 bar
-    applies to the fp32 path."""
+def _low_precision_step(kind, dtype, quant, seed, **opt_kw):
+    """One training step of the width/8 test network in a 2-byte storage type on the device and in the oracle with the device's
+    rounding points (oracle.net.Tape(fused_rounding=True): BN + add + ReLU round once, gradient contributions are added unrounded):
+      free   — the oracle runs on its own: forward agreement (loss, predictions) and aggregate gradient agreement.  These tiny nets
+               amplify one storage ulp 20-50x over their depth, and fp32-vs-float64 sums put a few roundings per layer on the other side,
+               so tensor-by-tensor agreement of the free run depends on the seed (measured: 1e-3 ... 2e-1);
+      forced — the oracle takes the device's stored activation and activation gradient at every residual-unit boundary
+               (Tape.barrier), so a rounding difference cannot travel further than one unit: EVERY gradient tensor must then agree
+               to 2e-2 (bf16) / 3e-3 (fp16).  A dropped or wrong-sign contribution inside a unit is O(1) there.
+      exact  — float64 without storage rounding."""
     import myconvnet_amd as M
-    model, spec, params, stats = make_resnet(50, 'bfloat16', True)
-    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
-    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
-    x = RNG.random((BATCH, 64, 64, 3)).astype(np.float32)
-    y = LABELS
-    model.feed(x, y)
+    model, spec, params, stats = make_resnet(kind, dtype, True)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, **opt_kw)
+    x = np.random.default_rng(seed).random((BATCH, 64, 64, 3)).astype(np.float32)
+    model.feed(x, LABELS)
     loss, _, y_pred = opt._step(None)
-    state64 = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
-    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH, quant=bf16q)
-    xloss, xpred, xgrads = ON.train_step(spec, state64, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH)
-    assert abs(loss - rloss) <= 2e-2 * abs(rloss), (loss, rloss)
-    assert rel_l2(y_pred, rpred) <= 5e-2
-    grads = model.get_variables('grad')
-    keys = sorted(k for k in rgrads if k.endswith('weights'))
-    g = np.concatenate([grads[k].ravel() for k in keys])
-    r = np.concatenate([rgrads[k].ravel() for k in keys])
-    e = np.concatenate([xgrads[k].ravel() for k in keys])
-    # the device must be as accurate (vs exact arithmetic) as a plain bf16-storage evaluation of the same network
-    err_dev, err_emu = rel_l2(g, e), rel_l2(r, e)
-    print('bf16 gradient error vs float64: device {:.3f}, bf16-emulating oracle {:.3f}; cos(device, emu) {:.3f}'.format(err_dev, err_emu, cosine(g, r)))
+    fresh = lambda: ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})  # noqa: E731
+    hp = dict(opt_kw) or None
+    x64, y64 = x.astype(np.float64), LABELS.astype(np.float64)
+    out = dict(model=model, loss=loss, pred=y_pred, grads=model.get_variables('grad'), state_free=fresh())
+    out['free'] = ON.train_step(spec, out['state_free'], x64, y64, batch_total=BATCH, quant=quant, fused_rounding=True, hp=hp)
+    names = ['block_0'] + ['block_{}/res_{}'.format(i, j) for i in range(1, 5) for j in range(spec.res_units[i])]
+    host = lambda t: t.float().cpu().numpy().astype(np.float64)  # noqa: E731
+    probe = {'force_act': {n: host(model.d[n].buf) for n in names}, 'force_grad': {n: host(model.d[n].grad) for n in names}}
+    out['forced'] = ON.train_step(spec, fresh(), x64, y64, batch_total=BATCH, quant=quant, fused_rounding=True, hp=hp, probe=probe)
+    out['exact'] = ON.train_step(spec, fresh(), x64, y64, batch_total=BATCH)
+    return out
+
+
+def _weights_vector(d):
+    keys = sorted(k for k in d if k.endswith('weights'))
+    return np.concatenate([np.asarray(d[k], np.float64).ravel() for k in keys])
+
+
+@pytest.mark.parametrize('kind', [50, 18])
+@pytest.mark.parametrize('seed', [5, 6])
+def test_resnet_step_bf16(kind, seed):
+    """bf16 storage (8 significant bits), like with like: the float64 oracle with every activation / activation gradient / per-use
+    weight rounded to bf16 at the device's rounding points (fp32 masters, fp32 BN statistics, fp32 accumulation: the reference's
+    half-precision structure).  See _low_precision_step for the oracle runs."""
+    r = _low_precision_step(kind, 'bfloat16', bf16q, seed)
+    loss, grads = r['loss'], r['grads']
+    rloss, rpred, rgrads = r['free']
+    floss, _, fgrads = r['forced']
+    # forward pass, free run: same rounding points => the loss agrees to 5e-3 (measured 0 ... 1.7e-3 over nets and seeds; round 2, op-by-op
+    # rounding in the oracle: 2e-2) and the predictions to 2e-2 (5e-2)
+    assert abs(loss - rloss) <= 5e-3 * abs(rloss), (loss, rloss)
+    assert rel_l2(r['pred'], rpred) <= 2e-2
+    # every gradient tensor, forced run
+    worst = max((rel_l2(grads[k], fgrads[k]), k) for k in fgrads if np.linalg.norm(fgrads[k]) > 1e-6)
+    print('bf16, teacher-forced at the unit boundaries: worst gradient tensor', worst)
+    assert worst[0] <= 2e-2, worst
+    assert abs(loss - floss) <= 1e-5 * abs(floss)
+    # free run, aggregate: the device is as accurate against exact arithmetic as the bf16-emulating oracle
+    g, rr, e = _weights_vector(grads), _weights_vector(rgrads), _weights_vector(r['exact'][2])
+    err_dev, err_emu = rel_l2(g, e), rel_l2(rr, e)
+    print('bf16 gradient error vs float64: device {:.3f}, bf16-emulating oracle {:.3f}; cos(device, emu) {:.3f}'.format(err_dev, err_emu, cosine(g, rr)))
     assert err_dev <= 1.5 * err_emu + 0.02, (err_dev, err_emu)
     assert cosine(g, e) >= 0.9
     assert abs(np.linalg.norm(g) / np.linalg.norm(e) - 1.0) <= 0.1
     # running statistics come from fp32 sums of the bf16 activations
-    got = model.get_variables('data')
-    assert rel_l2(got['block_0/conv_0/bn/mu'], state.stats['block_0/conv_0/bn/mu']) <= 1e-2
+    got = r['model'].get_variables('data')
+    assert rel_l2(got['block_0/conv_0/bn/mu'], r['state_free'].stats['block_0/conv_0/bn/mu']) <= 1e-3
 
 
 def fp16q(a):
     return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.float16).float().numpy().astype(np.float64)
 
 
-def test_resnet_step_fp16_with_loss_scaling():
-    """fp16 storage + loss_scaling_factor = 128: the reference's own low-precision recipe (convnet.py:63,
-    optimizers.py:102-111).  Like with like: the float64 oracle with fp16 rounding of every activation / activation
-    gradient / per-use weight and the same scale on the loss gradient (oracle.net: loss_scaling_factor).  fp16 keeps 11
-    significant bits, so the bounds are ~8x tighter than the bf16 test's; integer arg-max of the prediction must agree
-    with the fp16-emulating oracle wherever its top-2 margin exceeds the storage resolution."""
-    import myconvnet_amd as M
-    model, spec, params, stats = make_resnet(50, 'float16', True)
-    assert model.dtype == 'float16'
-    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, loss_scaling_factor=128.0)
-    assert model.loss_scale == 128.0
-    x = RNG.random((BATCH, 64, 64, 3)).astype(np.float32)
-    y = LABELS
-    model.feed(x, y)
-    loss, _, y_pred = opt._step(None)
-    st = lambda: ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})  # noqa: E731
-    state, state64 = st(), st()
-    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH, quant=fp16q,
-                                         hp=dict(loss_scaling_factor=128.0))
-    xloss, xpred, xgrads = ON.train_step(spec, state64, x.astype(np.float64), y.astype(np.float64), batch_total=BATCH)
-    assert abs(loss - rloss) <= 3e-3 * abs(rloss), (loss, rloss)
-    assert rel_l2(y_pred, rpred) <= 8e-3
+@pytest.mark.parametrize('kind', [50, 18])
+def test_resnet_step_fp16_with_loss_scaling(kind):
+    """fp16 storage + loss_scaling_factor = 128: the reference's own low-precision recipe (convnet.py:63, optimizers.py:102-111).
+    Like with like: the float64 oracle with fp16 rounding at the device's rounding points and the same scale on the loss gradient.
+    fp16 keeps 11 significant bits: every gradient tensor of the teacher-forced run within 3e-3; integer arg-max of the prediction
+    agrees with the fp16-emulating oracle wherever its top-2 margin exceeds the storage resolution."""
+    r = _low_precision_step(kind, 'float16', fp16q, 5, loss_scaling_factor=128.0)
+    model = r['model']
+    assert model.dtype == 'float16' and model.loss_scale == 128.0
+    loss, y_pred, grads = r['loss'], r['pred'], r['grads']
+    rloss, rpred, rgrads = r['free']
+    floss, _, fgrads = r['forced']
+    assert abs(loss - rloss) <= 2e-3 * abs(rloss), (loss, rloss)
+    assert rel_l2(y_pred, rpred) <= 5e-3
     top2 = np.sort(rpred, axis=-1)
     sure = (top2[:, -1] - top2[:, -2]) > 2e-2
     np.testing.assert_array_equal(y_pred.argmax(-1)[sure], rpred.argmax(-1)[sure])
-    grads = model.get_variables('grad')
-    keys = sorted(k for k in rgrads if k.endswith('weights'))
-    g = np.concatenate([grads[k].ravel() for k in keys])
-    r = np.concatenate([rgrads[k].ravel() for k in keys])
-    e = np.concatenate([xgrads[k].ravel() for k in keys])
-    err_dev, err_emu = rel_l2(g, e), rel_l2(r, e)
-    print('fp16 gradient error vs float64: device {:.4f}, fp16-emulating oracle {:.4f}; cos(device, emu) {:.5f}'.format(err_dev, err_emu, cosine(g, r)))
-    # (the 16-unit width/8 net amplifies storage rounding ~100x: the fp16-emulating oracle itself is 0.17 away from float64;
-    # the device must be no further, and aligned with both)
+    worst = max((rel_l2(grads[k], fgrads[k]), k) for k in fgrads if np.linalg.norm(fgrads[k]) > 1e-6)
+    print('fp16, teacher-forced at the unit boundaries: worst gradient tensor', worst)
+    assert worst[0] <= 3e-3, worst
+    g, rr, e = _weights_vector(grads), _weights_vector(rgrads), _weights_vector(r['exact'][2])
+    err_dev, err_emu = rel_l2(g, e), rel_l2(rr, e)
+    print('fp16 gradient error vs float64: device {:.4f}, fp16-emulating oracle {:.4f}; cos(device, emu) {:.5f}'.format(err_dev, err_emu, cosine(g, rr)))
     assert err_dev <= 1.5 * err_emu + 0.004, (err_dev, err_emu)
-    assert cosine(g, e) >= 0.98 and cosine(g, r) >= 0.98
+    assert cosine(g, e) >= 0.98 and cosine(g, rr) >= 0.98
     assert abs(np.linalg.norm(g) / np.linalg.norm(e) - 1.0) <= 0.05
     got = model.get_variables('data')
-    assert rel_l2(got['block_0/conv_0/bn/mu'], state.stats['block_0/conv_0/bn/mu']) <= 2e-3
-    worst = max((rel_l2(got[k], v), k) for k, v in state.params.items() if k.endswith('weights'))
-    assert worst[0] <= 5e-3, worst                                        # one Nesterov step from identical masters (gradients differ by ~0.15, see above)
+    assert rel_l2(got['block_0/conv_0/bn/mu'], r['state_free'].stats['block_0/conv_0/bn/mu']) <= 1e-3
+    worst = max((rel_l2(got[k], v), k) for k, v in r['state_free'].params.items() if k.endswith('weights'))
+    assert worst[0] <= 5e-3, worst                                        # one Nesterov step from identical masters
 
 
 def test_resnet_eval_uses_ema_and_running_stats():
