@@ -451,6 +451,30 @@ def cpu_baseline():
         t2.append(time.perf_counter() - t0)
     out['numpy_port'] = dict(value=round(8 / float(np.median(t2)), 3), unit='images/sec',
                              sample='NumPy(OpenBLAS) oracle of record, same step, B=8, median of 2 steps after 1 warm-up')
+    # third stand-in: the product's own host code (graph, launch lists, optimizer) on libmcn_cpu.so — the C-ABI as plain C++ / OpenMP loops
+    #  — in a child process (this one holds libmcn_hip.so)
+    cpu_lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'myconvnet_amd', 'libmcn_cpu.so')
+    if os.path.exists(cpu_lib):
+        import subprocess
+        code = ('import sys, time, numpy as np; sys.path.insert(0, %r); import myconvnet_amd as M\n'
+                'B = 8\n'
+                'm = M.ResNet50([224, 224, 3], 1000, batch_size=B, num_gpus=1, device="cpu", seed=0)\n'
+                'o = M.MomentumOptimizer(m, None, None, base_learning_rate=0.1, momentum=0.9, steps_per_epoch=5000, num_epochs=90)\n'
+                'r = np.random.default_rng(1234); m.feed(r.random((B, 224, 224, 3), dtype=np.float32), r.integers(0, 1000, B).astype(np.float32))\n'
+                'o._step(None, fetch=False)\n'
+                't = []\n'
+                'for _ in range(2):\n'
+                '    t0 = time.perf_counter(); o._step(None, fetch=False); t.append(time.perf_counter() - t0)\n'
+                'print("IPS", B / float(np.median(t)))\n') % os.path.dirname(os.path.abspath(__file__))
+        try:
+            r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MCN_LIB_PATH=cpu_lib, OMP_NUM_THREADS=str(threads)), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=240)
+            ips = [float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith('IPS')]
+            if ips:
+                out['loops_port'] = dict(value=round(ips[0], 3), unit='images/sec', cores=threads,
+                                         sample='the product\'s host code on libmcn_cpu.so (naive C++ / OpenMP loops behind the same C-ABI), same step, B=8, median of 2 steps after 1 warm-up')
+        except (subprocess.TimeoutExpired, OSError):
+            pass
     return out
 
 

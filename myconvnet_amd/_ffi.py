@@ -11,7 +11,9 @@ import torch  # noqa: F401  MUST precede loading libmcn_hip.so: both then share 
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MCN_LIB_PATH: load another build of the library (A/B runs of compile-time variants; no freshness check then)
+# MCN_LIB_PATH: load another build of the library (A/B runs of compile-time variants; no freshness check then).  This is also the ONLY
+# way libmcn_cpu.so (the C-ABI as plain loops: csrc_cpu/mcn_cpu.cpp, test infrastructure for the host code) gets loaded: there is no
+# fallback to it — without MCN_LIB_PATH a missing or stale libmcn_hip.so is an ImportError.
 LIB_PATH = os.environ.get('MCN_LIB_PATH') or os.path.join(_HERE, 'libmcn_hip.so')
 
 F32, BF16, F16 = 0, 1, 2
@@ -186,6 +188,10 @@ lib = load()
 if _want is not None and lib.mcn_build_id().decode() != _want:
     raise ImportError('libmcn_hip.so reports build id {}..., expected {}... — rebuild with `python myconvnet_amd/build.py --force`'
                       .format(lib.mcn_build_id().decode()[:12], _want[:12]))
+
+
+# the library named by MCN_LIB_PATH is the CPU build: tensors live on the host, the stream argument is ignored
+IS_CPU_LIB = lib.mcn_build_id().decode() == 'cpu'
 
 
 def last_error():

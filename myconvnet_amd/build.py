@@ -78,5 +78,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+CPU_SRC = os.path.join(HERE, 'csrc_cpu', 'mcn_cpu.cpp')
+CPU_LIB = os.path.join(HERE, 'libmcn_cpu.so')
+
+
+def build_cpu(force=False):
+    """libmcn_cpu.so: the same C-ABI as plain C++ / OpenMP loops (csrc_cpu/mcn_cpu.cpp).  Test infrastructure for the host code — the
+    binding loads it only when MCN_LIB_PATH names it (never as a fallback)."""
+    deps = [CPU_SRC, os.path.join(CSRC, '..', '..', 'include', 'mcn.h')]
+    if force or not os.path.exists(CPU_LIB) or os.path.getmtime(CPU_LIB) < _newest(deps):
+        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-fopenmp', '-fPIC', '-shared', '-std=c++17', '-Wall', '-Wno-unused-variable', '-o', CPU_LIB, CPU_SRC]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('g++ failed: {}\n{}'.format(' '.join(cmd), r.stdout))
+    return CPU_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print(build_cpu(force='--force' in sys.argv))

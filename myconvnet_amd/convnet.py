@@ -253,7 +253,8 @@ class ConvNet(object):
             print('\n# computing devices : {} {}(s)'.format(self.num_devices, self.compute_device))
             print('# variable blocks : {} {}'.format(self.num_blocks, self.block_list))
             print('\n# FLOPs : {:-15,}\n# Params: {:-15,}\n# Nodes : {:-15,}\n'.format(self.flops, self.params, self.nodes))
-        if kwargs.get('auto_compile', True) and self.device.type == 'cuda':
+        from . import _ffi
+        if kwargs.get('auto_compile', True) and (self.device.type == 'cuda' or _ffi.IS_CPU_LIB):
             self.compile()
 
     def _init_params(self, **kwargs):
@@ -334,8 +335,11 @@ class ConvNet(object):
         """Allocate storage and initialise the variables (once), then lower the graph to launch lists.  Calling it again
         (e.g. with another loss scale) only re-lowers: variables, EMA shadows, momentum and running statistics are kept."""
         from .executor import Lowering
-        if self.device.type != 'cuda':
+        from . import _ffi
+        if self.device.type != 'cuda' and not _ffi.IS_CPU_LIB:
             raise RuntimeError('ConvNet.compile() needs an MI355X (cuda device); the HIP path has no CPU fallback')
+        if self.device.type == 'cuda' and _ffi.IS_CPU_LIB:
+            raise RuntimeError('MCN_LIB_PATH names libmcn_cpu.so (host tensors only): build the model with device=\'cpu\'')
         g = self.graph
         if not getattr(self, '_allocated', False):
             self._allocate()
@@ -451,6 +455,8 @@ class ConvNet(object):
             self.Y_in.copy_(torch.as_tensor(Y).to(self.Y_in.dtype), non_blocking=True)
 
     def stream_ptr(self):
+        if self.device.type != 'cuda':                       # libmcn_cpu.so (MCN_LIB_PATH): host tensors, no stream
+            return 0
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def autotune(self):
