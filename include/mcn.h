@@ -72,6 +72,9 @@ typedef struct {
                      has room for the partial sums — deterministic, again identical up to fp32 summation order) */
 } mcn_conv_geom;
 #define MCN_TILE_NOSPLIT 0x100
+/* | MCN_TILE_NOWINO: keep an fp32 3x3 / stride 1 / pad 1 convolution on the direct kernels (default: Winograd F(2x2, 3x3)).
+ * The packed operand of such a layer is the transformed filter: pack job and call must agree on this flag. */
+#define MCN_TILE_NOWINO 0x200
 
 typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_conv_op;
 

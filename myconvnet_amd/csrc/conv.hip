@@ -1,6 +1,7 @@
 // conv.hip — host side of mcn_conv2d_{fwd,dgrad,wgrad} and mcn_fc_*: geometry -> tap tables,
 // weight packing into caller workspace, kernel selection and launch.  No device allocation, no sync.
 #include "conv_kernels.h"
+#include "wino_kernels.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -99,10 +100,32 @@ static long skinny_wgrad_slab(long M, int chunks) {      // pixels per slab: a m
     return slab;
 }
 
+// ---- Winograd F(2x2, 3x3) path (wino_kernels.h): fp32, 3x3 / stride 1 / dilation 1 / pad 1 — 16 multiplications per 2x2 outputs
+// instead of 36.  MCN_WINOGRAD=0 or MCN_TILE_NOWINO in mcn_conv_geom.tile keep the direct kernels (the flag must be the same for the
+// pack job and the call: the packed operand of an eligible layer is the transformed filter U).
+static int wino_level() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MCN_WINOGRAD");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+static bool wino_geom(const Geo& g, mcn_dtype dt) {
+    return dt == MCN_F32 && wino_level() > 0 && !(g.tile & MCN_TILE_NOWINO) && g.KH == 3 && g.KW == 3 && g.SH == 1 && g.SW == 1 && g.DH == 1 &&
+           g.DW == 1 && g.pT == 1 && g.pL == 1 && g.pB == 1 && g.pR == 1 && !force_naive();
+}
+static bool wino_fwd_ok(const Geo& g, mcn_dtype dt) { return wino_geom(g, dt) && mfma_path_ok(g, dt) && g.Cin % 32 == 0 && g.Cout % 4 == 0; }
+static bool wino_dgrad_ok(const Geo& g, mcn_dtype dt) { return wino_geom(g, dt) && mfma_dgrad_ok(g, dt) && g.Cout % 32 == 0 && g.Cin % 4 == 0; }
+static size_t wino_u_bytes(int Kin, int Kout) { return (size_t)((Kout + 63) / 64) * (Kin / 32) * 16 * 2048 * sizeof(float); }
+static int wino_rows(const Geo& g) { return (int)(2 * (((long)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) + 63) / 64)); }       // partial rows of its epilogues
+
 static size_t fwd_pack_bytes(const Geo& g, mcn_dtype dt) {
+    if (wino_fwd_ok(g, dt)) return align_up(wino_u_bytes(g.Cin, g.Cout), 256);
     return align_up((size_t)g.Cout * g.KH * g.KW * round_up(g.Cin, ce_of(dt)) * mcn_dtype_size(dt), 256);
 }
 static size_t dgrad_pack_bytes(const Geo& g, mcn_dtype dt) {
+    if (wino_dgrad_ok(g, dt)) return align_up(wino_u_bytes(g.Cout, g.Cin), 256);
     return align_up((size_t)g.Cin * g.KH * g.KW * round_up(g.Cout, ce_of(dt)) * mcn_dtype_size(dt), 256) + 256 * (size_t)g.SH * g.SW;
 }
 // wgrad tile: fp32 runs 64x64 tiles (32 KB of LDS -> 4 workgroups per CU, same finding as conv_gemm_nt); bf16 keeps
@@ -682,6 +705,13 @@ static int launch_tn(const GemmTNParams& p_in, bool linear, int splits, int forc
 
 template <typename T>
 static int launch_pack(const PackParams& p, hipStream_t st) {
+    if (p.mode >= 2) {                                   // Winograd filter transform (fp32 only)
+        const int Kin = p.mode == 3 ? p.Cout : p.Cin, Kout = p.mode == 3 ? p.Cin : p.Cout;
+        const long tot = (long)((Kout + 63) / 64) * (Kin / 32) * 2048;
+        hipLaunchKernelGGL(wino_filter_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, p.w, (float*)p.out, p.Cin, p.Cout, p.mode == 3 ? 1 : 0);
+        MCN_CHECK_LAUNCH();
+        return MCN_OK;
+    }
     const long total = (long)p.rows * p.ntaps * p.Cp;
     if (total <= 0) return MCN_OK;
     long blocks = (total + 255) / 256;
@@ -707,6 +737,37 @@ static inline unsigned nblocks(long total, int cap = 8192) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------
+// Winograd launch: `in` [N][H][W][Cs] (Kin channels) -> `out` [N][H][W][Kout]; exactly one of stats / red_part may be set
+static int launch_wino(const void* in, const void* u, void* out, const float* bias, int N, int H, int W, int Cs, int Kin, int Kout, float* stats,
+                       const void* red_x, const unsigned char* red_mask, float* red_part, hipStream_t st, bool accumulate = false) {
+    WinoParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = (const float*)in; p.u = (const float*)u; p.out = (float*)out; p.bias = bias;
+    p.H = H; p.W = W; p.Cs = Cs; p.Cin = Kin; p.TH = (H + 1) / 2; p.TW = (W + 1) / 2; p.ntiles = N * p.TH * p.TW;
+    p.Nn = Kout; p.ldo = Kout;
+    p.in_bytes = (unsigned)((size_t)N * H * W * Cs * sizeof(float));
+    p.u_bytes = (unsigned)wino_u_bytes(Kin, Kout);
+    p.out_bytes = (unsigned)((size_t)N * H * W * Kout * sizeof(float));
+    p.stats = stats; p.red_x = (const float*)red_x; p.red_mask = red_mask; p.red_part = red_part; p.red_row0 = 0;
+    const int lds = 2 * WINO_STAGE;
+    const dim3 grid((unsigned)(((p.ntiles + 63) / 64) * ((Kout + 63) / 64)));
+    if (stats) {
+        allow_lds(conv_wino_f2k3<NT_EPI_STATS>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3<NT_EPI_STATS>), grid, dim3(256), lds, st, p);
+    } else if (accumulate) {
+        allow_lds(conv_wino_f2k3<NT_EPI_ACC>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3<NT_EPI_ACC>), grid, dim3(256), lds, st, p);
+    } else if (red_part) {
+        allow_lds(conv_wino_f2k3<NT_EPI_BNRED>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3<NT_EPI_BNRED>), grid, dim3(256), lds, st, p);
+    } else {
+        allow_lds(conv_wino_f2k3<NT_EPI_STORE>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3<NT_EPI_STORE>), grid, dim3(256), lds, st, p);
+    }
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
 template <typename T>
 static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const Geo& g, mcn_dtype dt,
                       void* ws, size_t ws_bytes, hipStream_t st, float* stats = nullptr) {
@@ -741,6 +802,16 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
     }
     const size_t need = fwd_pack_bytes(g, dt);
     if (!w_packed && (!ws || ws_bytes < need)) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+    if (wino_fwd_ok(g, dt)) {
+        if (!w_packed) {
+            PackParams wk;
+            memset(&wk, 0, sizeof(wk));
+            wk.w = w; wk.out = ws; wk.Cin = g.Cin; wk.Cout = g.Cout; wk.mode = 2;
+            int rc = launch_pack<T>(wk, st);
+            if (rc) return rc;
+        }
+        return launch_wino(x, w_packed ? w_packed : ws, y, bias, g.N, g.H, g.W, g.xcs, g.Cin, g.Cout, stats, nullptr, nullptr, nullptr, st);
+    }
     const int ce = ce_of(dt), Cp = round_up(g.Cin, ce), ntaps = g.KH * g.KW;
     PackParams pk;
     memset(&pk, 0, sizeof(pk));
@@ -794,6 +865,7 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     if (!mcn_dtype_ok(dtype) || !mfma_path_ok(g, dtype)) return 0;
     const long M = (long)g.N * g.OH * g.OW;
     if (M <= 0) return 0;
+    if (wino_fwd_ok(g, dtype)) return wino_rows(g);      // counted rows [rows][4][Cout] (*rows_per_partial stays 0)
     const NtTile* cand = kNtCand;
     const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
     const int wrows = cand[t].nw / 2;
@@ -881,6 +953,19 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
     }
     const size_t need = dgrad_pack_bytes(g, dt);
     if (!w_packed && (!ws || ws_bytes < need)) MCN_FAIL(MCN_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, need);
+    if (wino_dgrad_ok(g, dt)) {                          // (eligibility depends on the geometry alone: the packed operand is U)
+        if (add_src) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: masked fan-in on a Winograd layer (mcn_conv2d_dgrad_addmasked_ok() == 0)");
+        if (accumulate && red_part) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad: accumulate + BN-backward sums");
+        // the gradient of a 3x3 / stride 1 / pad 1 convolution is the same convolution of dy with the filter rotated by 180 degrees
+        if (!w_packed) {
+            PackParams wk;
+            memset(&wk, 0, sizeof(wk));
+            wk.w = w; wk.out = ws; wk.Cin = g.Cin; wk.Cout = g.Cout; wk.mode = 3;
+            int rc = launch_pack<T>(wk, st);
+            if (rc) return rc;
+        }
+        return launch_wino(dy, w_packed ? w_packed : ws, dx, nullptr, g.N, g.H, g.W, g.Cout, g.Cout, g.Cin, nullptr, red_x, red_mask, red_part, st, accumulate != 0);
+    }
     const int ce = ce_of(dt), Cp = round_up(g.Cout, ce);
 
     // one exact sub-convolution per stride-parity class of dx
@@ -972,6 +1057,7 @@ extern "C" int32_t mcn_conv2d_dgrad_addmasked_ok(const mcn_conv_geom* gg, mcn_dt
     Geo g;
     if (!gg || geo_from(gg, &g)) return 0;
     if (!mcn_dtype_ok(dtype)) return 0;
+    if (wino_dgrad_ok(g, dtype)) return 0;              // (the Winograd dgrad has no masked fan-in epilogue; the block's first conv is 1x1 anyway)
     return (g.SH == 1 && g.SW == 1 && g.xcs == g.Cin && mfma_dgrad_ok(g, dtype) && g.Cin % ce_of(dtype) == 0) ? 1 : 0;
 }
 extern "C" int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w, const void* w_packed, void* dx, const void* add_src,
@@ -996,6 +1082,7 @@ extern "C" int mcn_conv2d_dgrad_addmasked(const void* dy, const float* w, const 
 extern "C" int32_t mcn_conv2d_dgrad_bnred_rows(const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
     if (!gg || geo_from(gg, &g) || !mcn_dtype_ok(dtype) || !mfma_dgrad_ok(g, dtype) || g.xcs != g.Cin) return 0;
+    if (wino_dgrad_ok(g, dtype)) return wino_rows(g);
     long rows = 0;
     for (int py = 0; py < g.SH && py < g.H; ++py)
         for (int px = 0; px < g.SW && px < g.W; ++px) {
@@ -1157,8 +1244,15 @@ extern "C" size_t mcn_conv2d_packed_bytes(mcn_conv_op op, const mcn_conv_geom* g
 #define MCN_PACK_SLICE_TILES 128
 #define MCN_PACK_SLICE_ROWS 512
 // appends pk cut into slices of at most `slice` jobs; returns the number of descriptors written
+static int pack_njobs(const PackParams& pk) {
+    if (pk.mode >= 2) {                                  // Winograd filter transform: 256 elements of U per job
+        const int Kin = pk.mode == 3 ? pk.Cout : pk.Cin, Kout = pk.mode == 3 ? pk.Cin : pk.Cout;
+        return ((Kout + 63) / 64) * (Kin / 32) * 8;
+    }
+    return pk.mode == 0 ? pk.ntaps * ((pk.Cp + 31) / 32) * ((pk.rows + 31) / 32) : pk.rows * pk.ntaps;
+}
 static int pack_emit(const PackParams& pk, PackParams* out) {
-    const int njobs = pk.mode == 0 ? pk.ntaps * ((pk.Cp + 31) / 32) * ((pk.rows + 31) / 32) : pk.rows * pk.ntaps;
+    const int njobs = pack_njobs(pk);
     const int slice = pk.mode == 0 ? MCN_PACK_SLICE_TILES : MCN_PACK_SLICE_ROWS;
     int n = 0;
     for (int j = 0; j < njobs; j += slice) {
@@ -1172,13 +1266,19 @@ static int pack_emit(const PackParams& pk, PackParams* out) {
 // upper bound of the descriptors one job needs (any dtype)
 static size_t pack_desc_bound(const mcn_conv_geom& g, int op) {
     if (op == MCN_CONV_DGRAD)
-        return (size_t)g.SH * g.SW + (size_t)g.Cin * g.KH * g.KW / MCN_PACK_SLICE_ROWS + 1;
+        return (size_t)g.SH * g.SW + (size_t)g.Cin * g.KH * g.KW / MCN_PACK_SLICE_ROWS + 1 + (size_t)((g.Cin + 63) / 64) * (g.Cout / 32 + 1) * 8 / MCN_PACK_SLICE_ROWS;
     return (size_t)g.KH * g.KW * ((g.Cin + 31) / 32) * ((g.Cout + 31) / 32) / MCN_PACK_SLICE_TILES + 1;
 }
 // descriptors for one job; returns how many (0 = the op does not use a packed operand)
 static int pack_descs(const Geo& g, mcn_dtype dt, mcn_conv_op op, const float* w, void* packed, PackParams* out) {
     const int ce = ce_of(dt);
     const size_t es = mcn_dtype_size(dt);
+    if ((op == MCN_CONV_FWD && wino_fwd_ok(g, dt)) || (op == MCN_CONV_DGRAD && wino_dgrad_ok(g, dt))) {
+        PackParams pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.w = w; pk.out = packed; pk.Cin = g.Cin; pk.Cout = g.Cout; pk.mode = op == MCN_CONV_FWD ? 2 : 3;
+        return pack_emit(pk, out);
+    }
     if (op == MCN_CONV_FWD) {
         if (!mfma_path_ok(g, dt)) return 0;
         PackParams& pk = out[0];
@@ -1333,6 +1433,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
             return 1;
         }
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
+        if (wino_fwd_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3<1, 0>"); return 1; }      /* (epilogue 1 = BN statistics; 0 without) */
         const long M = (long)g.N * g.OH * g.OW;
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
@@ -1355,6 +1456,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
             return 1;
         }
         if (!mfma_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_dgrad<%s>", tn); return 1; }
+        if (wino_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3<4, 0>"); return 1; }    /* (epilogue 4 = BN-backward sums; 0 without) */
         int ncls = 0, nt0 = 0;
         for (int py = 0; py < g.SH && py < g.H; ++py)
             for (int px = 0; px < g.SW && px < g.W; ++px) {
@@ -1393,7 +1495,7 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
     int rc = geo_from(gg, &g);
     if (rc) return rc;
     if (!buf || buflen < 96) MCN_FAIL(MCN_E_BADARG, "launch_list: buffer too small");
-    if (op != MCN_CONV_DGRAD || !mfma_dgrad_ok(g, dtype)) {
+    if (op != MCN_CONV_DGRAD || !mfma_dgrad_ok(g, dtype) || wino_dgrad_ok(g, dtype)) {
         char one[96];
         const int n = mcn_conv2d_kernel_name(op, gg, dtype, one, sizeof(one));
         if (n < 0) return n;
@@ -1443,10 +1545,10 @@ extern "C" int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* gg, m
     long M;
     int Nn, nchunks;
     if (op == MCN_CONV_FWD) {
-        if (!mfma_path_ok(g, dtype)) return 1;
+        if (!mfma_path_ok(g, dtype) || wino_fwd_ok(g, dtype)) return 1;
         M = (long)g.N * g.OH * g.OW; Nn = g.Cout; nchunks = g.KH * g.KW * (round_up(g.Cin, ce) / ce);
     } else if (op == MCN_CONV_DGRAD) {
-        if (!mfma_dgrad_ok(g, dtype)) return 1;
+        if (!mfma_dgrad_ok(g, dtype) || wino_dgrad_ok(g, dtype)) return 1;
         int nt0 = 0;                                      // taps of the first non-empty stride-parity class
         for (int py = 0; py < g.SH && py < g.H && !nt0; ++py)
             for (int px = 0; px < g.SW && px < g.W && !nt0; ++px)

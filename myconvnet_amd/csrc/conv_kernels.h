@@ -1752,6 +1752,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_linear_kernel(const float* _
 //   mode 0 (fwd)  : out[n][t*Cp + c] = w[r_t][s_t][c][n]      rows = Cout, per-tap width Cp >= Cin
 //   mode 1 (dgrad): out[c][t*Cp + k] = w[r_t][s_t][c][k]      rows = Cin,  per-tap width Cp >= Cout
 // ------------------------------------------------------------------------------------------------
+//   mode 2 / 3    : U = G g G^T of a 3x3 filter for the Winograd kernels (forward / dgrad = rotated + transposed), fp32
+__device__ __forceinline__ void wino_u_elements(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout, bool transposed, long id);
 struct PackParams {
     const float* w;
     void* out;
@@ -1785,6 +1787,11 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackParam
     const PackParams& p = table[blockIdx.y];
     const long total = (long)p.rows * p.ntaps * p.Cp;
     T* out = reinterpret_cast<T*>(p.out);
+    if (p.mode >= 2) {                                   // Winograd filter transform (wino_kernels.h): one job = 256 elements of U
+        for (int job = p.job0 + blockIdx.x; job < p.job1; job += gridDim.x)
+            wino_u_elements(p.w, reinterpret_cast<float*>(p.out), p.Cin, p.Cout, p.mode == 3, (long)job * 256 + threadIdx.x);
+        return;
+    }
     if (p.mode == 0) {
         // forward operand = per-tap TRANSPOSE of the HWIO filter ([cout][tap][cin] from [tap][cin][cout]): 32x32 tiles through
         // LDS so that both the fp32 reads (along cout) and the packed writes (along cin) are coalesced — the element-wise form

@@ -716,9 +716,9 @@ def test_conv_streamk_tail(case, dtype):
 
     for tile in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_FWD) + 1):
         g = u.geom(x.shape, w.shape, s, 'SAME')
-        g.tile = tile
+        g.tile = tile | 0x200                                                            # MCN_TILE_NOWINO: this test is about the direct kernels' tail
         gn = u.geom(x.shape, w.shape, s, 'SAME')
-        gn.tile = tile | 0x100                                                   # MCN_TILE_NOSPLIT
+        gn.tile = tile | 0x100 | 0x200                                           # MCN_TILE_NOSPLIT
         assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gn), u.MDT[dtype]) == 1
         ws = u.workspace(max(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(g), u.MDT[dtype]),
                              lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype])))
