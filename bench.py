@@ -215,6 +215,9 @@ def _hbm_call_bytes(name, a, es):
     return 0.0
 
 
+WINO_DIRECT_FLOP = {}
+
+
 def instrumented_pass(model, dtype, reps=3, layers=False):
     """Time every C-ABI launch of forward+backward with HIP events on the launch stream (torch's current stream IS the
     launch stream).  Conv calls are keyed by the exact kernel symbol rocprofv3 reports (mcn_conv2d_kernel_name); a call
@@ -318,6 +321,13 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                     r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
                     r[0] += 1
                     r[1] += ms
+                if key.startswith('conv_wino'):
+                    # (the per-layer table above shows direct-equivalent TFLOP/s)  Winograd F(2x2, 3x3): the MFMAs execute 16 multiplications per 2x2 outputs instead of 36 (tiles hanging over an odd map's
+                    # edge included).  The table carries the EXECUTED flop, so that `frac` stays a statement about the MFMA pipe; the
+                    # direct-convolution flop of the same calls are kept beside it (roofline_by_kernel: direct_equivalent_tflops)
+                    cov = (2.0 * ((gm.H + 1) // 2) / gm.H) * (2.0 * ((gm.W + 1) // 2) / gm.W)
+                    WINO_DIRECT_FLOP[key] = WINO_DIRECT_FLOP.get(key, 0.0) + flop / (reps - 1)
+                    flop *= 16.0 / 36.0 * cov
             if name in ops and len(launches) > 1:
                 # the bracket covers all launches of the call: split time, flops and bytes by filter taps (= by flops)
                 taps = float(sum(t for _, t in launches))
@@ -528,7 +538,7 @@ def main():
     if world == 1 and not args.no_roofline:
         table = instrumented_pass(model, args.dtype, layers=args.layers)
         bracket_us = table.pop('_bracket_us')[1] * 1e3
-        convs = {k: v for k, v in table.items() if k.startswith('conv_gemm')}
+        convs = {k: v for k, v in table.items() if k.startswith('conv_gemm') or k.startswith('conv_wino')}
         dom = max(convs.items(), key=lambda kv: kv[1][1])                 # the kernel symbol with the most time per step
         name, (cnt, ms_k, flop, alg_bytes) = dom
         ach = flop / (ms_k * 1e-3) / 1e12
@@ -553,6 +563,9 @@ def main():
                                          'gbs': round(v[3] / (v[1] * 1e-3) / 1e9, 0), 'algorithmic_bytes_per_launch': int(v[3] / max(v[0], 1)),
                                          'traffic': pmc_traffic(k, args.dtype, args.batch).get('traffic')}
                                      for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])[:8] if v[1] > 0}
+        for k, d in WINO_DIRECT_FLOP.items():                            # (tflops / frac above: executed Winograd flop)
+            if k in out['roofline_by_kernel']:
+                out['roofline_by_kernel'][k]['direct_equivalent_tflops'] = round(d / (table[k][1] * 1e-3) / 1e12, 1)
         tot = sum(v[1] for v in table.values())
         out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 12)]}
         out['kernel_ms_total'] = round(tot, 3)

@@ -102,7 +102,8 @@ constexpr int WINO_STAGE = WINO_VBYTES + WINO_UBYTES;
 //   stage q:  MFMAs on LDS buffer q&1  |  U of stage q+1 by LDS-DMA  |  input transform of stage q+1 (registers loaded during stage q-1) ->
 //             ds_write into buffer (q+1)&1  |  global loads of stage q+2 re-issued into the registers the transform has just consumed
 // The 64 MFMAs of a stage go out as 8 groups of 8 (two frequencies x one chunk pair); the fragments of group g+1 are read under group g.
-template <int EPI, int DBG = 0>
+// (template order: the epilogue LAST, as in conv_gemm_nt — bench.py and mcn_conv2d_kernel_name rewrite the trailing parameter)
+template <int DBG, int EPI>
 __global__ __launch_bounds__(256, 1) void conv_wino_f2k3(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
