@@ -101,7 +101,7 @@ static long skinny_wgrad_slab(long M, int chunks) {      // pixels per slab: a m
 }
 
 // ---- Winograd F(2x2, 3x3) path (wino_kernels.h): fp32, 3x3 / stride 1 / dilation 1 / pad 1 — 16 multiplications per 2x2 outputs
-// instead of 36.  MCN_WINOGRAD=0 or MCN_TILE_NOWINO in mcn_conv_geom.tile keep the direct kernels (the flag must be the same for the
+// instead of 36.  MCN_WINOGRAD=0 (2: forward and dgrad only) or MCN_TILE_NOWINO in mcn_conv_geom.tile keep the direct kernels (the flag must be the same for the
 // pack job and the call: the packed operand of an eligible layer is the transformed filter U).
 static int wino_level() {
     static int v = -1;
@@ -118,6 +118,21 @@ static bool wino_geom(const Geo& g, mcn_dtype dt) {
 static bool wino_fwd_ok(const Geo& g, mcn_dtype dt) { return wino_geom(g, dt) && mfma_path_ok(g, dt) && g.Cin % 32 == 0 && g.Cout % 4 == 0; }
 static bool wino_dgrad_ok(const Geo& g, mcn_dtype dt) { return wino_geom(g, dt) && mfma_dgrad_ok(g, dt) && g.Cout % 32 == 0 && g.Cin % 4 == 0; }
 static size_t wino_u_bytes(int Kin, int Kout) { return (size_t)((Kout + 63) / 64) * (Kin / 32) * 16 * 2048 * sizeof(float); }
+static bool wino_wgrad_ok(const Geo& g, mcn_dtype dt) { return wino_geom(g, dt) && mfma_path_ok(g, dt) && g.Cin % 4 == 0 && g.Cout % 4 == 0 && wino_level() == 1; }
+// split of the tiles over workgroups: one round of the chip (1 workgroup per CU) over (channel block, cout block, split); whole 32-tile groups
+static int wino_wgrad_splits(const Geo& g, int* tiles_per_split) {
+    const long ntiles = (long)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2);
+    const int nblk = ((g.Cin + 63) / 64) * ((g.Cout + 63) / 64);
+    long groups = (ntiles + 31) / 32;
+    if (groups < 1) groups = 1;
+    long splits = MCN_NUM_CU / nblk;
+    if (splits < 1) splits = 1;
+    if (splits > groups) splits = groups;
+    const long gps = (groups + splits - 1) / splits;
+    splits = (groups + gps - 1) / gps;
+    if (tiles_per_split) *tiles_per_split = (int)(gps * 32);
+    return (int)splits;
+}
 static int wino_rows(const Geo& g) { return (int)(2 * (((long)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) + 63) / 64)); }       // partial rows of its epilogues
 
 static size_t fwd_pack_bytes(const Geo& g, mcn_dtype dt) {
@@ -256,7 +271,7 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
         if (sl > 1) b += align_up((size_t)sl * g.KH * g.KW * g.Cin * g.Cout * 4, 256);
     }
     if (mfma_path_ok(g, dt)) {
-        const int splits = wgrad_splits(g, dt, nullptr, nullptr);
+        const int splits = wino_wgrad_ok(g, dt) ? wino_wgrad_splits(g, nullptr) : wgrad_splits(g, dt, nullptr, nullptr);
         const size_t rows = (size_t)g.KH * g.KW * round_up(g.Cin, ce_of(dt));
         b += align_up((size_t)splits * rows * g.Cout * 4, 256);
     }
@@ -1176,6 +1191,36 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
             hipLaunchKernelGGL(naive_wgrad_reduce, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)part, dw, total, sl, scale);
             MCN_CHECK_LAUNCH();
         }
+    } else if (wino_wgrad_ok(g, dt)) {
+        // Winograd F(3x3, 2x2): the slab layout is the direct wgrad's ([split][tap * Cin + c][n], Cp == Cin), so is the reduce
+        WinoWgradParams p;
+        memset(&p, 0, sizeof(p));
+        int tps = 0;
+        const int splits = wino_wgrad_splits(g, &tps);
+        p.x = (const float*)x; p.dy = (const float*)dy; p.slab = (float*)wsp;
+        p.H = g.H; p.W = g.W; p.Cs = g.xcs; p.Cin = g.Cin; p.ldy = g.Cout; p.Nn = g.Cout;
+        p.TH = (g.H + 1) / 2; p.TW = (g.W + 1) / 2; p.ntiles = g.N * p.TH * p.TW; p.tiles_per_split = tps;
+        p.nbc = (g.Cin + 63) / 64; p.nbn = (g.Cout + 63) / 64;
+        p.x_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(float));
+        p.dy_bytes = (unsigned)((size_t)M * g.Cout * sizeof(float));
+        if (M > 0) {
+            const int lds = 2 * WINO_WG_STAGE;
+            allow_lds(conv_wino_wgrad_f3k2, lds);
+            hipLaunchKernelGGL(conv_wino_wgrad_f3k2, dim3((unsigned)(p.nbc * p.nbn * splits)), dim3(256), lds, st, p);
+            MCN_CHECK_LAUNCH();
+        }
+        const long total = 9L * g.Cin * g.Cout;
+        const int nsp = M > 0 ? splits : 0;
+        const long t4 = total / 4;
+        const float* sl = (const float*)wsp;
+        if ((((uintptr_t)dw) & 15) == 0) {
+            if (t4 >= 256 * 256 || nsp < 8) hipLaunchKernelGGL((wgrad_reduce_linear_kernel<1>), dim3(nblocks(t4, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
+            else if (t4 >= 64 * 256 || nsp < 32) hipLaunchKernelGGL((wgrad_reduce_linear_kernel<4>), dim3(nblocks(t4 * 4, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
+            else hipLaunchKernelGGL((wgrad_reduce_linear_kernel<16>), dim3(nblocks(t4 * 16, 2048)), dim3(256), 0, st, sl, dw, nsp, t4, scale);
+        } else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, sl, dw, nsp, 9, g.Cin, g.Cin, g.Cout, scale);
+        MCN_CHECK_LAUNCH();
+        wsp += align_up((size_t)splits * total * 4, 256);
     } else {
         int nsteps, sps;
         const int splits = wgrad_splits(g, dt, &nsteps, &sps);
@@ -1480,6 +1525,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_co(g)); return 1; }
     if (!mfma_path_ok(g, dtype) && skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_ci(g)); return 1; }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
+    if (wino_wgrad_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_wgrad_f3k2"); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
     if (tn_ring(mcn_dtype_size(dtype), br, bn, conv_is_linear(g))) snprintf(buf, buflen, "conv_gemm_tn3<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 128 ? 8 : 4);

@@ -187,3 +187,37 @@ def test_wino_dgrad_bn_backward_sums(case):
     xq = xbn.reshape(-1, cin).astype(np.float64)
     np.testing.assert_allclose(p[:, 0].sum(0), dxm.sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm).sum(0).max())
     np.testing.assert_allclose(p[:, 1].sum(0), (dxm * xq).sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm * xq).sum(0).max())
+
+
+@pytest.mark.parametrize('case', [(2, 8, 8, 64, 64), (3, 7, 7, 32, 96), (5, 14, 10, 72, 40), (1, 1, 1, 32, 32), (70, 14, 14, 128, 128), (16, 28, 28, 64, 36)])
+def test_wino_wgrad_matches_oracle_and_direct_kernel(case):
+    """Winograd F(3x3, 2x2) weight gradient (tiles = the GEMM's K dimension, split over workgroups, slabs reduced in a fixed order)"""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout = case
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    dy = RNG.standard_normal((n, h, w_, cout)).astype(np.float32)
+    g = u.geom(x.shape, (3, 3, cin, cout), 1, 'SAME')
+    gd = u.geom(x.shape, (3, 3, cin, cout), 1, 'SAME')
+    gd.tile = NOWINO
+    assert 'wino' in _kernel(g, _ffi.CONV_WGRAD) and 'wino' not in _kernel(gd, _ffi.CONV_WGRAD)
+    xd, dyd = u.dev(x), u.dev(dy)
+
+    def wgrad(gm, scale=1.0, bias=False):
+        dw = torch.full((3, 3, cin, cout), float('nan'), dtype=torch.float32, device=u.DEV)
+        db = torch.full((cout,), float('nan'), dtype=torch.float32, device=u.DEV)
+        ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_WGRAD, ctypes.byref(gm), u.MDT['float32']))
+        _ffi.check(lib.mcn_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr() if bias else 0, ctypes.byref(gm), float(scale), u.MDT['float32'], _ffi.NHWC,
+                                        ws.data_ptr(), ws.numel() * 4, u.stream()))
+        return u.host(dw), u.host(db)
+
+    ref = O.conv2d_wgrad(x, dy, (3, 3, cin, cout), 1, 'SAME', 1)
+    dw, _ = wgrad(g)
+    dwd, _ = wgrad(gd)
+    assert np.isfinite(dw).all()
+    assert rel_l2(dw, ref) <= 2e-5 and rel_l2(dwd, ref) <= 2e-5, (rel_l2(dw, ref), rel_l2(dwd, ref))
+    np.testing.assert_array_equal(wgrad(g)[0], dw)                                       # fixed-order reduce: bit-reproducible
+    dws, db = wgrad(g, scale=0.25, bias=True)
+    assert rel_l2(dws, 0.25 * ref) <= 2e-5
+    assert rel_l2(db, 0.25 * dy.reshape(-1, cout).astype(np.float64).sum(0)) <= 2e-5
