@@ -133,7 +133,7 @@ static int wino_wgrad_splits(const Geo& g, int* tiles_per_split) {
     if (tiles_per_split) *tiles_per_split = (int)(gps * 32);
     return (int)splits;
 }
-static int wino_rows(const Geo& g) { return (int)(2 * (((long)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) + 63) / 64)); }       // partial rows of its epilogues
+static int wino_rows(const Geo& g) { return (int)(4 * (((long)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) + 63) / 64)); }       // partial rows of its epilogues: (tile block, wave column, frequency half)
 
 static size_t fwd_pack_bytes(const Geo& g, mcn_dtype dt) {
     if (wino_fwd_ok(g, dt)) return align_up(wino_u_bytes(g.Cin, g.Cout), 256);
@@ -767,17 +767,17 @@ static int launch_wino(const void* in, const void* u, void* out, const float* bi
     const int lds = 2 * WINO_STAGE;
     const dim3 grid((unsigned)(((p.ntiles + 63) / 64) * ((Kout + 63) / 64)));
     if (stats) {
-        allow_lds(conv_wino_f2k3<0, NT_EPI_STATS>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3<0, NT_EPI_STATS>), grid, dim3(256), lds, st, p);
+        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_STATS>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_STATS>), grid, dim3(512), lds, st, p);
     } else if (accumulate) {
-        allow_lds(conv_wino_f2k3<0, NT_EPI_ACC>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3<0, NT_EPI_ACC>), grid, dim3(256), lds, st, p);
+        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_ACC>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_ACC>), grid, dim3(512), lds, st, p);
     } else if (red_part) {
-        allow_lds(conv_wino_f2k3<0, NT_EPI_BNRED>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3<0, NT_EPI_BNRED>), grid, dim3(256), lds, st, p);
+        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_BNRED>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_BNRED>), grid, dim3(512), lds, st, p);
     } else {
-        allow_lds(conv_wino_f2k3<0, NT_EPI_STORE>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3<0, NT_EPI_STORE>), grid, dim3(256), lds, st, p);
+        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_STORE>, lds);
+        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_STORE>), grid, dim3(512), lds, st, p);
     }
     MCN_CHECK_LAUNCH();
     return MCN_OK;
@@ -1478,7 +1478,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
             return 1;
         }
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
-        if (wino_fwd_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3<0, 0>"); return 1; }      /* (the trailing parameter is the epilogue: 1 = BN statistics) */
+        if (wino_fwd_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3_w8<0, 0>"); return 1; }      /* (the trailing parameter is the epilogue: 1 = BN statistics) */
         const long M = (long)g.N * g.OH * g.OW;
         const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
         const int cpt = round_up(g.Cin, ce) / ce;
@@ -1501,7 +1501,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
             return 1;
         }
         if (!mfma_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_dgrad<%s>", tn); return 1; }
-        if (wino_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3<0, 0>"); return 1; }    /* (... 4 = BN-backward sums, 2 = accumulate) */
+        if (wino_dgrad_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3_w8<0, 0>"); return 1; }    /* (... 4 = BN-backward sums, 2 = accumulate) */
         int ncls = 0, nt0 = 0;
         for (int py = 0; py < g.SH && py < g.H; ++py)
             for (int px = 0; px < g.SW && px < g.W; ++px) {
