@@ -1204,9 +1204,9 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         p.x_bytes = (unsigned)((size_t)g.N * g.H * g.W * g.xcs * sizeof(float));
         p.dy_bytes = (unsigned)((size_t)M * g.Cout * sizeof(float));
         if (M > 0) {
-            const int lds = 2 * WINO_WG_STAGE;
-            allow_lds(conv_wino_wgrad_f3k2, lds);
-            hipLaunchKernelGGL(conv_wino_wgrad_f3k2, dim3((unsigned)(p.nbc * p.nbn * splits)), dim3(256), lds, st, p);
+            const int lds = WINO_WG_LDS_W8;
+            allow_lds(conv_wino_wgrad_f3k2_w8, lds);
+            hipLaunchKernelGGL(conv_wino_wgrad_f3k2_w8, dim3((unsigned)(p.nbc * p.nbn * splits)), dim3(512), lds, st, p);
             MCN_CHECK_LAUNCH();
         }
         const long total = 9L * g.Cin * g.Cout;
@@ -1525,7 +1525,7 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
     if (!mfma_path_ok(g, dtype) && skinny_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_co(g)); return 1; }
     if (!mfma_path_ok(g, dtype) && skinny_in_ok(g, dtype, MCN_SKINNY_MAX_CO_WGRAD)) { snprintf(buf, buflen, "skinny_conv_wgrad<%s, %d>", tn, skinny_ci(g)); return 1; }
     if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_wgrad<%s>", tn); return 1; }
-    if (wino_wgrad_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_wgrad_f3k2"); return 1; }
+    if (wino_wgrad_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_wgrad_f3k2_w8"); return 1; }
     int br, bn;
     tn_tile(g.KH * g.KW * round_up(g.Cin, ce), g.Cout, dtype, conv_is_linear(g), g.tile, &br, &bn);
     if (tn_ring(mcn_dtype_size(dtype), br, bn, conv_is_linear(g))) snprintf(buf, buflen, "conv_gemm_tn3<%s, %d, %d, %s, %d>", tn, br, bn, conv_is_linear(g) ? "true" : "false", br == 128 ? 8 : 4);
