@@ -754,7 +754,8 @@ static inline unsigned nblocks(long total, int cap = 8192) {
 // ---- forward -------------------------------------------------------------------------------------------
 // Winograd launch: `in` [N][H][W][Cs] (Kin channels) -> `out` [N][H][W][Kout]; exactly one of stats / red_part may be set
 static int launch_wino(const void* in, const void* u, void* out, const float* bias, int N, int H, int W, int Cs, int Kin, int Kout, float* stats,
-                       const void* red_x, const unsigned char* red_mask, float* red_part, hipStream_t st, bool accumulate = false) {
+                       const void* red_x, const unsigned char* red_mask, float* red_part, hipStream_t st, bool accumulate = false, void* sk_ws = nullptr,
+                       size_t sk_ws_bytes = 0, bool nosplit = false) {
     WinoParams p;
     memset(&p, 0, sizeof(p));
     p.in = (const float*)in; p.u = (const float*)u; p.out = (float*)out; p.bias = bias;
@@ -765,20 +766,39 @@ static int launch_wino(const void* in, const void* u, void* out, const float* bi
     p.out_bytes = (unsigned)((size_t)N * H * W * Kout * sizeof(float));
     p.stats = stats; p.red_x = (const float*)red_x; p.red_mask = red_mask; p.red_part = red_part; p.red_row0 = 0;
     const int lds = 2 * WINO_STAGE;
-    const dim3 grid((unsigned)(((p.ntiles + 63) / 64) * ((Kout + 63) / 64)));
-    if (stats) {
-        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_STATS>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_STATS>), grid, dim3(512), lds, st, p);
-    } else if (accumulate) {
-        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_ACC>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_ACC>), grid, dim3(512), lds, st, p);
-    } else if (red_part) {
-        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_BNRED>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_BNRED>), grid, dim3(512), lds, st, p);
-    } else {
-        allow_lds(conv_wino_f2k3_w8<0, NT_EPI_STORE>, lds);
-        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, NT_EPI_STORE>), grid, dim3(512), lds, st, p);
+    const int total = ((p.ntiles + 63) / 64) * ((Kout + 63) / 64);
+    // K-sliced tail: one workgroup per CU, so `total` blocks run in ceil(total / 256) rounds; when the last round is short its blocks are cut
+    // along the 32-channel super-steps into slices that fill the chip once more (parked accumulators + a reduce launch that runs the
+    // epilogue: fixed order, deterministic).  14 x 14, 256 -> 256, B = 256: 784 blocks = 3 rounds + 16 blocks -> 64 slices of a quarter block.
+    static const int tail_on = [] { const char* e = getenv("MCN_WINO_TAIL"); return e ? atoi(e) : 1; }();
+    const int ns = Kin / 32, rem = total % MCN_NUM_CU;
+    int slices = 1;
+    if (tail_on && !nosplit && total > MCN_NUM_CU && rem > 0 && rem <= MCN_NUM_CU / 2 && ns >= 2 && sk_ws) {
+        slices = MCN_NUM_CU / rem;
+        if (slices > ns) slices = ns;
+        if (slices > 8) slices = 8;
+        while (slices > 1 && (size_t)rem * slices * 8 * 128 * 64 * sizeof(float) > sk_ws_bytes) --slices;
+        const int per = (ns + slices - 1) / slices;
+        slices = (ns + per - 1) / per;                     // no empty slices
     }
+    p.sk_slices = slices;
+    p.sk_body = slices > 1 ? total - rem : total;
+    p.partial = (float*)sk_ws;
+    const dim3 grid((unsigned)(slices > 1 ? p.sk_body + rem * slices : total)), rgrid((unsigned)rem);
+#define MCN_WINO_LAUNCH(EPIV)                                                                                          \
+    do {                                                                                                               \
+        allow_lds(conv_wino_f2k3_w8<0, EPIV>, lds);                                                                    \
+        hipLaunchKernelGGL((conv_wino_f2k3_w8<0, EPIV>), grid, dim3(512), lds, st, p);                                 \
+        if (slices > 1) {                                                                                              \
+            allow_lds(conv_wino_f2k3_w8<WINO_REDUCE, EPIV>, lds);                                                      \
+            hipLaunchKernelGGL((conv_wino_f2k3_w8<WINO_REDUCE, EPIV>), rgrid, dim3(512), lds, st, p);                  \
+        }                                                                                                              \
+    } while (0)
+    if (stats) MCN_WINO_LAUNCH(NT_EPI_STATS);
+    else if (accumulate) MCN_WINO_LAUNCH(NT_EPI_ACC);
+    else if (red_part) MCN_WINO_LAUNCH(NT_EPI_BNRED);
+    else MCN_WINO_LAUNCH(NT_EPI_STORE);
+#undef MCN_WINO_LAUNCH
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
@@ -825,7 +845,9 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
             int rc = launch_pack<T>(wk, st);
             if (rc) return rc;
         }
-        return launch_wino(x, w_packed ? w_packed : ws, y, bias, g.N, g.H, g.W, g.xcs, g.Cin, g.Cout, stats, nullptr, nullptr, nullptr, st);
+        const size_t used = w_packed ? 0 : need;
+        return launch_wino(x, w_packed ? w_packed : ws, y, bias, g.N, g.H, g.W, g.xcs, g.Cin, g.Cout, stats, nullptr, nullptr, nullptr, st, false,
+                           ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0, (g.tile & MCN_TILE_NOSPLIT) != 0);
     }
     const int ce = ce_of(dt), Cp = round_up(g.Cin, ce), ntaps = g.KH * g.KW;
     PackParams pk;
@@ -979,7 +1001,9 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
             int rc = launch_pack<T>(wk, st);
             if (rc) return rc;
         }
-        return launch_wino(dy, w_packed ? w_packed : ws, dx, nullptr, g.N, g.H, g.W, g.Cout, g.Cout, g.Cin, nullptr, red_x, red_mask, red_part, st, accumulate != 0);
+        const size_t used = w_packed ? 0 : need;
+        return launch_wino(dy, w_packed ? w_packed : ws, dx, nullptr, g.N, g.H, g.W, g.Cout, g.Cout, g.Cin, nullptr, red_x, red_mask, red_part, st, accumulate != 0,
+                           ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0, (g.tile & MCN_TILE_NOSPLIT) != 0);
     }
     const int ce = ce_of(dt), Cp = round_up(g.Cout, ce);
 

@@ -30,10 +30,16 @@ struct WinoParams {
     const unsigned char* red_mask;
     float* red_part;
     int red_row0;
+    // K-sliced tail (as conv_gemm_nt's stream-K tail): workgroups >= sk_body compute one of sk_slices slices of the 32-channel super-steps of a
+    // tail block each and park their accumulators in `partial` ([slice block][wave 8][register 128][lane 64]); a second launch of the kernel
+    // with DBG = WINO_REDUCE sums the slices of each tail block in a fixed order and runs the epilogue
+    float* partial;
+    int sk_body, sk_slices;
     int dbg;                // DEBUG probes (timing only, wrong results): 1 = no staging after the first K-step, 2 = no MFMAs, 4 = no fragment reads
 };
 
 #define WINO_OOB 0x80000000u
+#define WINO_REDUCE 64      // DBG bit of conv_wino_f2k3_w8: no K loop, accumulators = the sum of a tail block's parked slices
 
 template <int N, typename F, int I = 0>
 __device__ __forceinline__ void wino_for(F&& f) {
@@ -119,9 +125,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int ntn = (p.Nn + 63) >> 6, ntm = (p.ntiles + 63) >> 6;
-    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    constexpr bool REDUCE = (DBG & WINO_REDUCE) != 0;
+    const int sk_rel = REDUCE ? (int)blockIdx.x * p.sk_slices : (int)blockIdx.x - p.sk_body;
+    const bool sk_slice = !REDUCE && p.sk_slices > 1 && sk_rel >= 0;
+    const int L = REDUCE ? p.sk_body + (int)blockIdx.x : (sk_slice ? p.sk_body + sk_rel / p.sk_slices : xcd_remap(blockIdx.x, p.sk_slices > 1 ? p.sk_body : ntm * ntn));
     const int t0 = (L / ntn) * 64, nb = L % ntn, n0 = nb * 64;
-    const int ns = p.Cin >> 5;
+    const int ns_all = p.Cin >> 5;
+    // super-step range of this workgroup: everything, or one slice of a tail block
+    int s0 = 0, ns = ns_all;
+    if (sk_slice) {
+        const int per = (ns_all + p.sk_slices - 1) / p.sk_slices, sl = sk_rel % p.sk_slices;
+        s0 = sl * per;
+        ns = min(ns_all, s0 + per);
+    }
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
                 poff[r][c] = ok ? (unsigned)((((img * p.H + y) * p.W + x) * p.Cs + lj * 4) * 4) : WINO_OOB;
             }
     }
-    const unsigned ubase = (unsigned)(((long)nb * ns) * (4 * WINO_UBYTES) + lane * 16);
+    const unsigned ubase = (unsigned)(((long)nb * ns_all) * (4 * WINO_UBYTES) + lane * 16);
     __attribute__((address_space(3))) char* const wbase = (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
 
     f32x4 raw[2][4], tt[4];
@@ -189,14 +205,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 3> I3;
-    dma_u(I0{}, 0);
-    load_raw(I0{}, 0);
-    rows(I0{});
-    cols(0);
-    load_raw(I1{}, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int fragA = (lane >> 5) * 1024 + (wm * 32 + (lane & 31)) * 16 + WINO_VBYTES + fh * 2 * 8192;
     const int fragB = (lane >> 5) * WINO_VCH + (wn * 32 + (lane & 31)) * 16 + fh * 2 * WINO_VF;
     f32x4 fa[2][2], fb[2][2];                                                      // [set][column j]; group g = chunk pair i
@@ -257,17 +265,44 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    read_frags(smem, 0, 0);
-    for (int sidx = 0; sidx < ns - 1; ++sidx) {
-        stage(I0{}, I3{}, sidx);
-        stage(I1{}, I3{}, sidx);
-        stage(I2{}, I3{}, sidx);
-        stage(I3{}, I3{}, sidx);
+    if constexpr (!REDUCE) {
+        if (s0 < ns) {                                             // (a slice past the end of K: nothing to add)
+            dma_u(I0{}, s0 * 4);
+            load_raw(I0{}, s0);
+            rows(I0{});
+            cols(0);
+            load_raw(I1{}, s0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            read_frags(smem, 0, 0);
+            for (int sidx = s0; sidx < ns - 1; ++sidx) {
+                stage(I0{}, I3{}, sidx);
+                stage(I1{}, I3{}, sidx);
+                stage(I2{}, I3{}, sidx);
+                stage(I3{}, I3{}, sidx);
+            }
+            stage(I0{}, I3{}, ns - 1);
+            stage(I1{}, I3{}, ns - 1);
+            stage(I2{}, I1{}, ns - 1);
+            stage(I3{}, I0{}, ns - 1);
+        }
+        if (sk_slice) {                                            // park the accumulators: the reduce launch runs the epilogue
+            float* dst = p.partial + ((size_t)(sk_rel * 8 + wave) * 128) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(f * 16 + r) * 64] = acc[f][r];
+            return;
+        }
+    } else {
+        for (int sl = 0; sl < p.sk_slices; ++sl) {
+            const float* src = p.partial + ((size_t)((sk_rel + sl) * 8 + wave) * 128) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][r] += src[(f * 16 + r) * 64];
+        }
     }
-    stage(I0{}, I3{}, ns - 1);
-    stage(I1{}, I3{}, ns - 1);
-    stage(I2{}, I1{}, ns - 1);
-    stage(I3{}, I0{}, ns - 1);
 
     // ---- output transform: this wave's partial outputs, exchange with the partner, then its output row a = fh
     constexpr bool STATS = EPI == NT_EPI_STATS, BNRED = EPI == NT_EPI_BNRED, ACC = EPI == NT_EPI_ACC;

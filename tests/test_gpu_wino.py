@@ -221,3 +221,42 @@ def test_wino_wgrad_matches_oracle_and_direct_kernel(case):
     dws, db = wgrad(g, scale=0.25, bias=True)
     assert rel_l2(dws, 0.25 * ref) <= 2e-5
     assert rel_l2(db, 0.25 * dy.reshape(-1, cout).astype(np.float64).sum(0)) <= 2e-5
+
+
+def test_wino_k_sliced_tail_matches_unsplit_launch():
+    """More blocks than CUs with a short last round (296 = 256 + 40 here): the tail blocks run K-sliced (parked accumulators + a reduce launch
+    that runs the epilogue); MCN_TILE_NOSPLIT keeps every block whole.  Same results up to fp32 summation order, deterministic, also with the
+    BN-statistics and BN-backward epilogues."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout = 24, 28, 28, 64, 256
+    x = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    w = (RNG.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    g = u.geom(x.shape, w.shape, 1, 'SAME')
+    gn = u.geom(x.shape, w.shape, 1, 'SAME')
+    gn.tile = 0x100                                                                      # MCN_TILE_NOSPLIT
+    xd, wd = u.dev(x), u.dev(w)
+    rows = lib.mcn_conv2d_bnstats_rows(ctypes.byref(g), u.MDT['float32'], None)
+
+    def fwd(gm):
+        y = torch.full((n, h, w_, cout), float('nan'), dtype=torch.float32, device=u.DEV)
+        part = torch.full((rows, 4, cout), float('nan'), dtype=torch.float32, device=u.DEV)
+        ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_FWD, ctypes.byref(gm), u.MDT['float32']))
+        _ffi.check(lib.mcn_conv2d_fwd_bnstats(xd.data_ptr(), wd.data_ptr(), 0, 0, y.data_ptr(), part.data_ptr(), ctypes.byref(gm), u.MDT['float32'], _ffi.NHWC,
+                                              ws.data_ptr(), ws.numel() * 4, u.stream()))
+        return u.host(y), u.host(part)
+
+    (y, p), (yn, pn) = fwd(g), fwd(gn)
+    assert np.isfinite(y).all() and np.isfinite(p).all()
+    assert rel_l2(y, yn) <= 1e-6 and rel_l2(y, O.conv2d_fwd(x, w, 1, 'SAME', 1)) <= 2e-5
+    np.testing.assert_array_equal(p[:, 3], pn[:, 3])
+    assert rel_l2(p[:, 0] + p[:, 3] * p[:, 2], pn[:, 0] + pn[:, 3] * pn[:, 2]) <= 1e-5
+    y2, p2 = fwd(g)
+    np.testing.assert_array_equal(y2, y)
+    np.testing.assert_array_equal(p2, p)
+    # dgrad of the transposed geometry (256 -> 64 as seen from dy): accumulate epilogue through the reduce launch
+    dy = RNG.standard_normal((n, h, w_, cout)).astype(np.float32)
+    prev = RNG.standard_normal(x.shape).astype(np.float32)
+    a = u.conv_dgrad(dy, w, x.shape, 1, 'SAME', 1, 'float32', accumulate_into=prev)
+    assert rel_l2(a, O.conv2d_dgrad(dy, w, x.shape, 1, 'SAME', 1) + prev) <= 2e-5
