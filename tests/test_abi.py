@@ -66,8 +66,12 @@ def test_argument_validation_without_gpu():
     # stream-K plan: small layers run unsplit; MCN_TILE_NOSPLIT turns the split off for a layer that has one
     assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(g), _ffi.F32) == 1
     gb = _ffi.conv_geom(256, 7, 7, 512, 512, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))
+    assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) == 1                     # fp32 3x3 / stride 1: the Winograd kernel (its own tail plan)
+    assert lib.mcn_conv2d_kernel_name(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32, buf, 96) == 1 and buf.value.startswith(b'conv_wino_f2k3_w8<')
+    assert lib.mcn_conv2d_kernel_name(_ffi.CONV_WGRAD, ctypes.byref(gb), _ffi.F32, buf, 96) == 1 and buf.value == b'conv_wino_wgrad_f3k2_w8'
+    gb.tile = 0x200                                                                                      # MCN_TILE_NOWINO: the direct kernels
     assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) > 1 and lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.BF16) == 1
-    gb.tile = 0x100
+    gb.tile = 0x300
     assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) == 1
     assert lib.mcn_decoupled_decay(0, 10, 0.1, 0, 0.0, 0) == _ffi.E_BADARG
     assert lib.mcn_bn_bwd_frozen(0, 0, 0, 0, 0, 0, 0, 1e-3, 0, 0, 0, 0, 1.0, 10, 4, 0, _ffi.F32, 0, 0, 0) == _ffi.E_BADARG
