@@ -768,8 +768,8 @@ static int launch_wino(const void* in, const void* u, void* out, const float* bi
     const int lds = 2 * WINO_STAGE;
     const int total = ((p.ntiles + 63) / 64) * ((Kout + 63) / 64);
     // K-sliced tail: one workgroup per CU, so `total` blocks run in ceil(total / 256) rounds; when the last round is short its blocks are cut
-    // along the 32-channel super-steps into slices that fill the chip once more (parked accumulators + a reduce launch that runs the
-    // epilogue: fixed order, deterministic).  14 x 14, 256 -> 256, B = 256: 784 blocks = 3 rounds + 16 blocks -> 64 slices of a quarter block.
+    // along the 32-channel super-steps into slices that fill the chip once more (a second launch parks their accumulators, a third sums them in a
+    // fixed order and runs the epilogue: deterministic).  14 x 14, 256 -> 256, B = 256: 784 blocks = 3 rounds + 16 blocks -> 64 slices of a quarter block.
     static const int tail_on = [] { const char* e = getenv("MCN_WINO_TAIL"); return e ? atoi(e) : 1; }();
     const int ns = Kin / 32, rem = total % MCN_NUM_CU;
     int slices = 1;
@@ -784,12 +784,14 @@ static int launch_wino(const void* in, const void* u, void* out, const float* bi
     p.sk_slices = slices;
     p.sk_body = slices > 1 ? total - rem : total;
     p.partial = (float*)sk_ws;
-    const dim3 grid((unsigned)(slices > 1 ? p.sk_body + rem * slices : total)), rgrid((unsigned)rem);
+    const dim3 grid((unsigned)p.sk_body), sgrid((unsigned)(rem * slices)), rgrid((unsigned)rem);
 #define MCN_WINO_LAUNCH(EPIV)                                                                                          \
     do {                                                                                                               \
         allow_lds(conv_wino_f2k3_w8<0, EPIV>, lds);                                                                    \
         hipLaunchKernelGGL((conv_wino_f2k3_w8<0, EPIV>), grid, dim3(512), lds, st, p);                                 \
         if (slices > 1) {                                                                                              \
+            allow_lds(conv_wino_f2k3_w8<WINO_SLICE, NT_EPI_STORE>, lds);                                               \
+            hipLaunchKernelGGL((conv_wino_f2k3_w8<WINO_SLICE, NT_EPI_STORE>), sgrid, dim3(512), lds, st, p);           \
             allow_lds(conv_wino_f2k3_w8<WINO_REDUCE, EPIV>, lds);                                                      \
             hipLaunchKernelGGL((conv_wino_f2k3_w8<WINO_REDUCE, EPIV>), rgrid, dim3(512), lds, st, p);                  \
         }                                                                                                              \

@@ -40,6 +40,7 @@ struct WinoParams {
 
 #define WINO_OOB 0x80000000u
 #define WINO_REDUCE 64      // DBG bit of conv_wino_f2k3_w8: no K loop, accumulators = the sum of a tail block's parked slices
+#define WINO_SLICE 128      // DBG bit: the workgroups of this launch are K-slices of the tail blocks (park the accumulators, no epilogue)
 
 template <int N, typename F, int I = 0>
 __device__ __forceinline__ void wino_for(F&& f) {
@@ -100,9 +101,10 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
 
 // LDS stage = the operands of ONE frequency row r (4 frequencies) x 32 input channels:
 //   V [f 4][chunk 8][64 tiles][16 B]   chunk stride 1056 B (bank-conflict-free 16-byte writes with lanes = 8 chunks x 8 tiles)
-//   U [f 4][chunk 8][64 couts][16 B]   linear (LDS-DMA)
-constexpr int WINO_VCH = 1056, WINO_VF = 8 * WINO_VCH, WINO_VBYTES = 4 * WINO_VF, WINO_UBYTES = 32768;
-constexpr int WINO_STAGE = WINO_VBYTES + WINO_UBYTES;
+//   U [f 4][chunk 8][64 couts][16 B]   the same chunk stride: an LDS-DMA instruction writes one chunk (1 KB); with the global image's 1024-byte
+//                                      stride lanes l and l + 32 of a fragment read hit the same banks (PMC: one conflict cycle per MFMA)
+constexpr int WINO_VCH = 1056, WINO_VF = 8 * WINO_VCH, WINO_VBYTES = 4 * WINO_VF, WINO_UBYTES = 32768;      // (UBYTES: bytes of a stage's U in global memory)
+constexpr int WINO_STAGE = 2 * WINO_VBYTES;
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // K loop: stages q = 4 s + r (s = 32-channel super-step, r = frequency row).  A stage reads whole 128-byte lines of the input (8 lanes =
@@ -125,19 +127,21 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int ntn = (p.Nn + 63) >> 6, ntm = (p.ntiles + 63) >> 6;
-    constexpr bool REDUCE = (DBG & WINO_REDUCE) != 0;
-    const int sk_rel = REDUCE ? (int)blockIdx.x * p.sk_slices : (int)blockIdx.x - p.sk_body;
-    const bool sk_slice = !REDUCE && p.sk_slices > 1 && sk_rel >= 0;
-    const int L = REDUCE ? p.sk_body + (int)blockIdx.x : (sk_slice ? p.sk_body + sk_rel / p.sk_slices : xcd_remap(blockIdx.x, p.sk_slices > 1 ? p.sk_body : ntm * ntn));
+    // three instantiations per epilogue (compile-time: the slice bookkeeping in the plain kernel cost 17 spilled registers and 9 % of the
+    // 56 x 56 layer): plain = the whole blocks 0 .. sk_body-1; SLICE = workgroup (tail block, slice) of a second launch; REDUCE = the third
+    constexpr bool REDUCE = (DBG & WINO_REDUCE) != 0, SLICE = (DBG & WINO_SLICE) != 0;
+    const int sk_rel = REDUCE ? (int)blockIdx.x * p.sk_slices : (int)blockIdx.x;
+    const int L = REDUCE ? p.sk_body + (int)blockIdx.x : (SLICE ? p.sk_body + sk_rel / p.sk_slices : xcd_remap(blockIdx.x, p.sk_body));
     const int t0 = (L / ntn) * 64, nb = L % ntn, n0 = nb * 64;
     const int ns_all = p.Cin >> 5;
     // super-step range of this workgroup: everything, or one slice of a tail block
     int s0 = 0, ns = ns_all;
-    if (sk_slice) {
+    if constexpr (SLICE) {
         const int per = (ns_all + p.sk_slices - 1) / p.sk_slices, sl = sk_rel % p.sk_slices;
         s0 = sl * per;
         ns = min(ns_all, s0 + per);
     }
+    (void)ntm;
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
             }
     }
     const unsigned ubase = (unsigned)(((long)nb * ns_all) * (4 * WINO_UBYTES) + lane * 16);
-    __attribute__((address_space(3))) char* const wbase = (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
+    __attribute__((address_space(3))) char* const wbase = (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * WINO_VCH);
 
     f32x4 raw[2][4], tt[4];
     auto load_raw = [&](auto rc, int sidx) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
         const unsigned go = ubase + (unsigned)q * WINO_UBYTES + (unsigned)wave * 1024u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(wbase + (buf * WINO_STAGE + WINO_VBYTES + i * 8192)), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(wbase + (buf * WINO_STAGE + WINO_VBYTES + i * WINO_VF)), 16,
                                                      (int)(go + (unsigned)(i * 8192)), 0, 0, 0);
     };
 
@@ -205,13 +209,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 3> I3;
-    const int fragA = (lane >> 5) * 1024 + (wm * 32 + (lane & 31)) * 16 + WINO_VBYTES + fh * 2 * 8192;
+    const int fragA = (lane >> 5) * WINO_VCH + (wm * 32 + (lane & 31)) * 16 + WINO_VBYTES + fh * 2 * WINO_VF;
     const int fragB = (lane >> 5) * WINO_VCH + (wn * 32 + (lane & 31)) * 16 + fh * 2 * WINO_VF;
     f32x4 fa[2][2], fb[2][2];                                                      // [set][column j]; group g = chunk pair i
     auto read_frags = [&](const char* st, int g, int set) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            fa[set][j] = *reinterpret_cast<const f32x4*>(st + fragA + j * 8192 + g * 2048);
+            fa[set][j] = *reinterpret_cast<const f32x4*>(st + fragA + j * WINO_VF + g * 2 * WINO_VCH);
             fb[set][j] = *reinterpret_cast<const f32x4*>(st + fragB + j * WINO_VF + g * 2 * WINO_VCH);
         }
     };
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
                 acc[R * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][j][e], fb[g & 1][j][e], acc[R * 2 + j], 0, 0, 0);
             if constexpr (g < 3 && w < 4) {
                 constexpr int g1 = g + 1, jj = w >> 1;
-                if constexpr ((w & 1) == 0) fa[g1 & 1][jj] = *reinterpret_cast<const f32x4*>(st + fragA + jj * 8192 + g1 * 2048);
+                if constexpr ((w & 1) == 0) fa[g1 & 1][jj] = *reinterpret_cast<const f32x4*>(st + fragA + jj * WINO_VF + g1 * 2 * WINO_VCH);
                 else fb[g1 & 1][jj] = *reinterpret_cast<const f32x4*>(st + fragB + jj * WINO_VF + g1 * 2 * WINO_VCH);
             }
             if constexpr (next) {
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
                     for (int c = 0; c < 4; ++c) tt[c] = R1 == 1 ? raw[0][c] + raw[1][c] : raw[0][c] - raw[1][c];
                 } else if constexpr (m >= 1 && m < 5) {
                     constexpr int i = m - 1;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(wbase + (((R + 1) & 1) * WINO_STAGE + WINO_VBYTES + i * 8192)),
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(wbase + (((R + 1) & 1) * WINO_STAGE + WINO_VBYTES + i * WINO_VF)),
                                                              16, (int)(go + (unsigned)(i * 8192)), 0, 0, 0);
                 } else if constexpr (m >= 5 && m < 13) {
                     constexpr int l = m - 5, h = l >> 2, c = l & 3;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
                     __builtin_amdgcn_s_barrier();
                 } else if constexpr (m >= 28) {
                     constexpr int jj = (m - 28) >> 1;
-                    if constexpr ((m & 1) == 0) fa[0][jj] = *reinterpret_cast<const f32x4*>(sn + fragA + jj * 8192);
+                    if constexpr ((m & 1) == 0) fa[0][jj] = *reinterpret_cast<const f32x4*>(sn + fragA + jj * WINO_VF);
                     else fb[0][jj] = *reinterpret_cast<const f32x4*>(sn + fragB + jj * WINO_VF);
                 }
             }
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
         });
     };
     if constexpr (!REDUCE) {
-        if (s0 < ns) {                                             // (a slice past the end of K: nothing to add)
+        if (!SLICE || s0 < ns) {                                   // (a slice past the end of K: nothing to add)
             dma_u(I0{}, s0 * 4);
             load_raw(I0{}, s0);
             rows(I0{});
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_f2k3_w8(const WinoParams p) 
             stage(I2{}, I1{}, ns - 1);
             stage(I3{}, I0{}, ns - 1);
         }
-        if (sk_slice) {                                            // park the accumulators: the reduce launch runs the epilogue
+        if constexpr (SLICE) {                                     // park the accumulators: the reduce launch runs the epilogue
             float* dst = p.partial + ((size_t)(sk_rel * 8 + wave) * 128) * 64 + lane;
 #pragma unroll
             for (int f = 0; f < 8; ++f)
