@@ -611,3 +611,50 @@ def accuracy_score(y_true, y_pred):
         nv = int(v.sum())
         scores.append(1.0 if nv == 0 else int(r.sum()) / nv)
     return float(np.mean(scores))
+
+
+# ---- Winograd F(2x2, 3x3) restated (test infrastructure): the identities csrc/wino_kernels.h implements, in float64 -----------------
+# Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 2x2 output tile / 4x4 input patch (Lavin & Gray 2016); the weight gradient is the transpose of the
+# same bilinear map: dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G.  Not used by the reference (TensorFlow picks its algorithm inside
+# cuDNN); used by tests/test_oracle_winograd.py to pin the transform matrices and the tile / padding bookkeeping against conv2d_fwd / _wgrad.
+WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+WINO_AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+
+
+def _wino_patches(x):
+    """[N, TH, TW, 4, 4, C] input patches of the 2x2 output tiles of a 3x3 / stride 1 / pad 1 convolution (zeros outside the image)"""
+    n, h, w, c = x.shape
+    th, tw = (h + 1) // 2, (w + 1) // 2
+    xp = np.zeros((n, 2 * th + 2, 2 * tw + 2, c), np.float64)
+    xp[:, 1:h + 1, 1:w + 1] = x
+    out = np.empty((n, th, tw, 4, 4, c), np.float64)
+    for a in range(4):
+        for b in range(4):
+            out[:, :, :, a, b] = xp[:, a:a + 2 * th:2, b:b + 2 * tw:2]
+    return out
+
+
+def winograd_conv2d_fwd(x, w):
+    """3x3 / stride 1 / SAME convolution through F(2x2, 3x3); x [N,H,W,C], w [3,3,C,K] -> [N,H,W,K] (float64)"""
+    n, h, wd, c = x.shape
+    u = np.einsum('ar,rsck,bs->abck', WINO_G, np.asarray(w, np.float64), WINO_G)
+    v = np.einsum('ar,nijrsc,bs->nijabc', WINO_BT, _wino_patches(np.asarray(x, np.float64)), WINO_BT)
+    m = np.einsum('nijabc,abck->nijabk', v, u)
+    y = np.einsum('pa,nijabk,qb->nijpqk', WINO_AT, m, WINO_AT)
+    th, tw = y.shape[1], y.shape[2]
+    return y.transpose(0, 1, 3, 2, 4, 5).reshape(n, 2 * th, 2 * tw, -1)[:, :h, :wd]
+
+
+def winograd_conv2d_wgrad(x, dy):
+    """weight gradient of the same convolution through F(3x3, 2x2): [3,3,C,K] (float64); outputs outside the image count as zero"""
+    n, h, wd, c = x.shape
+    k = dy.shape[-1]
+    th, tw = (h + 1) // 2, (wd + 1) // 2
+    dyp = np.zeros((n, 2 * th, 2 * tw, k), np.float64)
+    dyp[:, :h, :wd] = dy
+    dyt = dyp.reshape(n, th, 2, tw, 2, k).transpose(0, 1, 3, 2, 4, 5)                  # [n, th, tw, 2, 2, k]
+    z = np.einsum('pa,nijpqk,qb->nijabk', WINO_AT, dyt, WINO_AT)                      # A dY A^T  (A = WINO_AT^T)
+    v = np.einsum('ar,nijrsc,bs->nijabc', WINO_BT, _wino_patches(np.asarray(x, np.float64)), WINO_BT)
+    du = np.einsum('nijabc,nijabk->abck', v, z)
+    return np.einsum('ar,abck,bs->rsck', WINO_G, du, WINO_G)
