@@ -10,7 +10,7 @@
 //
 // The block of a workgroup is 64 tiles x 64 couts x 16 frequencies = 256 accumulator registers per lane of a 32 x 32 wave tile: one
 // workgroup per CU, eight waves (conv_wino_f2k3_w8 below; the first, 4-wave form — all 16 frequencies in one wave, one wave per SIMD — is
-// kept in scratch/wino_w4_kernel.h).
+// kept in profiles/probes/wino_w4_kernel.h).
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -479,7 +479,7 @@ constexpr int WINO_WG_STAGE = 2 * WINO_WG_HALF;
 constexpr int WINO_WG_LDS_W8 = 8 * 72 * 64 * 4;   // conv_wino_wgrad_f3k2_w8: the epilogue's exchange area (> the two stages)
 
 // conv_wino_wgrad_f3k2_w8: eight waves (two per SIMD), each owning two columns of the frequency grid — the first, 4-wave form (all 16
-// frequencies in one wave: scratch/wino_w4_wgrad_kernel.h) was bound by its own instruction issue, 480 instructions per stage in one stream.  Epilogue: a wave applies G^T over
+// frequencies in one wave: profiles/probes/wino_w4_wgrad_kernel.h) was bound by its own instruction issue, 480 instructions per stage in one stream.  Epilogue: a wave applies G^T over
 // the rows and its two columns' share of (.) G, which gives 9 PARTIAL taps per accumulator register; wave fh finishes registers 8 fh ..
 // 8 fh + 7 and hands the other eight to its partner (wave ^ 4) through LDS (72 floats per lane, once per block).
 __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_f3k2_w8(const WinoWgradParams p) {
