@@ -16,7 +16,7 @@ def child():
     import torch
     import myconvnet_amd as M
     model = M.ResNet50([224, 224, 3], 1000, batch_size=B, num_gpus=1, half_precision=False, seed=0, device='cuda:0')
-    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.02, momentum=0.9, steps_per_epoch=5000, num_epochs=90)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.05, momentum=0.9, steps_per_epoch=5000, num_epochs=90, learning_warmup_epochs=0.0)
     rng = np.random.default_rng(99)
     data = [(rng.random((B, 224, 224, 3), dtype=np.float32), rng.integers(0, 1000, B).astype(np.float32)) for _ in range(4)]
     losses = []
@@ -43,7 +43,7 @@ if __name__ == '__main__':
         out = subprocess.run([sys.executable, os.path.abspath(__file__), str(STEPS)], env=env, capture_output=True, text=True, check=True).stdout
         runs[mode] = json.loads(out.strip().splitlines()[-1])
     a, b = np.array(runs['1']['losses']), np.array(runs['0']['losses'])
-    print('# ResNet-v1.5-50 fp32, B = %d, 224x224, four synthetic batches cycled, Nesterov momentum 0.9, lr 0.02, %d steps, same seed' % (B, STEPS))
+    print('# ResNet-v1.5-50 fp32, B = %d, 224x224, four synthetic batches cycled, Nesterov momentum 0.9, lr 0.05 (no warm-up), %d steps, same seed' % (B, STEPS))
     print('# step | loss with the Winograd kernels (MCN_WINOGRAD=1) | loss with the direct kernels (MCN_WINOGRAD=0) | relative difference')
     for s in range(STEPS):
         print('%3d | %.6f | %.6f | %.2e' % (s, a[s], b[s], abs(a[s] - b[s]) / abs(b[s])))
