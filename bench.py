@@ -18,8 +18,11 @@ At N=1 the line also carries:
                  score (optimizers.py:590-594, :410); everything else of `_step` is inside the timed region
   bf16, fp16   — secondary measurements of the same step with bf16 storage (the north-star arithmetic) and with the reference's own
                  half precision (fp16 storage, loss scaling 128), only in the default fp32 run.
-roofline.traffic = HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh; null if absent).
---model efficientnet_b0 | deeplabv3plus: BASELINE configs[3] / configs[4] on one GPU (secondary workloads, no roofline object).
+roofline.traffic = HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh; null if absent or if the
+file's build id is not the loaded library's).  Winograd launches (fp32 3x3 / stride 1) are booked with their EXECUTED flop (16/36 of the
+direct count x tile cover) in roofline / roofline_by_kernel; `direct_equivalent_tflops` carries the direct-convolution rate of the same calls.
+--model efficientnet_b0 | deeplabv3plus: BASELINE configs[3] / configs[4] on one GPU (secondary workloads; roofline = the dominant
+streaming C-ABI call against the HBM peak).
 --no-overlap: wgrad on the main stream (profiling: per-kernel averages are then not stretched by co-running kernels).
 """
 import argparse
