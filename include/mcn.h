@@ -46,7 +46,10 @@ typedef enum {
     MCN_ACT_NONE = 0,
     MCN_ACT_RELU = 1,
     MCN_ACT_SWISH = 2,  /* x*sigmoid(x), convnet.py:2553-2556 */
-    MCN_ACT_SIGMOID = 3 /* convnet.py:2550; element-wise entry points only */
+    MCN_ACT_SIGMOID = 3, /* convnet.py:2550; element-wise entry points only */
+    MCN_ACT_RELU6 = 4,   /* tf.nn.relu6, convnet.py:2539-2540; element-wise entry points only */
+    MCN_ACT_LRELU = 5,   /* tf.nn.leaky_relu(alpha), convnet.py:2542-2545 (alpha = param, reference default 0.2); element-wise only */
+    MCN_ACT_TANH = 6     /* tf.nn.tanh, convnet.py:2547; element-wise entry points only */
 } mcn_act;
 
 int mcn_version(void);
@@ -327,6 +330,13 @@ int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, mcn_act
 int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream);
 int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype,
                 void* stream);
+/* the same with the activation's parameter (ConvNet.activation(x, type, params), convnet.py:2514-2534): every entry of the
+ * reference's dispatcher — relu, relu6, lrelu (param = alpha), tanh, sigmoid, swish.  Backward: relu / relu6 / tanh / sigmoid
+ * differentiate through y (Relu6Grad: 0 < y < 6; TanhGrad: 1 - y^2), swish / lrelu through x (LeakyReluGrad: x > 0 ? dy : alpha*dy).
+ * mcn_act_fwd / mcn_act_bwd are these with param = 0.2 (the reference's default alpha). */
+int mcn_act_fwd_p(const void* x, void* y, int64_t n, mcn_act act, float param, mcn_dtype dtype, void* stream);
+int mcn_act_bwd_p(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, float param, mcn_dtype dtype,
+                  void* stream);
 /* a += b (gradient accumulation at fan-out points) */
 int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void* stream);
 /* dtype conversion (tf.cast, convnet.py:469-471, 477-480) */
@@ -386,6 +396,13 @@ int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels, const flo
 int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce,
                                   float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing,
                                   float loss_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with SegNet's label smoothing (segmentation/segnet.py:117-122): the cross-entropy runs against
+ * (1 - ls) * labels + ls * avg_labels, avg_labels = tf.nn.avg_pool2d(labels, 5x5, stride 1, SAME) of the one-hot map
+ * (mcn_avgpool_fwd), while batch weights and the valid mask keep reading the raw labels (convnet.py:552, 567-573). */
+int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w,
+                                       float* pred, float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C,
+                                       float label_smoothing, float loss_scale, void* workspace, size_t workspace_bytes,
+                                       void* stream);
 
 /* ---- segmentation path -----------------------------------------------------
  * tf.image.resize_bilinear (convnet.py:2396; align_corners=True at models/deeplabv3plus.py:64,74) and its gradient
@@ -435,12 +452,24 @@ int mcn_decoupled_decay_h(float* w, int64_t n, const float* hyper /* wd = hyper[
  * norm_out (device, may be NULL) receives the pre-clip norm.  workspace >= 1028 floats. */
 int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int64_t n_l2, float l2, float threshold, float* norm_out,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* the same over the TRAINABLE runs of the flat buffer only (gradient clipping together with blocks_to_train: the reference
+ * clips the gradients of update_vars = tf.trainable_variables(), optimizers.py:53,106,112-113 — frozen variables are in
+ * neither the norm nor the L2 fold).  runs: HOST array of nruns x {start, end, l2_end} element offsets (start <= l2_end
+ * <= end: [start, l2_end) receives the L2 gradient); one norm over all runs.  workspace >= (nruns * 1024 + 4) floats. */
+int mcn_clip_by_global_norm_runs(float* g, const float* w, const int64_t* runs, int32_t nruns, float l2, float threshold, float* norm_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 /* shadow <- d*shadow + (1-d)*v (EMA of BN running statistics, convnet.py:1812,1826) */
 int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay, void* stream);
 int mcn_ema_update_h(float* shadow, const float* v, int64_t n, const float* hyper /* decay = hyper[2] */, void* stream);
 /* chained running-statistics update over `towers` ranks (convnet.py:1899-1909):
  * running <- m*running + (1-m)*batch[k] for k = 0..towers-1; batch:[towers][n] */
 int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* stream);
+/* the same over a SUB-RANGE of the statistics vector: batch row k starts at batch + k*tower_stride.  The host runs it over
+ * the maximal runs of BNs that update their statistics (update_batch_norm / blocks_to_train, convnet.py:1781-1795,
+ * 1915-1923: a frozen BN has no update op in the reference), so frozen running statistics are never rewritten — nor
+ * touched at all while the backward pass of a frozen BN reads them. */
+int mcn_bn_running_chain_strided(float* running, const float* batch, int32_t towers, int64_t n, int64_t tower_stride, float momentum,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

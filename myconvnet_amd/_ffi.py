@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('MCN_LIB_PATH') or os.path.join(_HERE, 'libmcn_hip.so'
 
 F32, BF16, F16 = 0, 1, 2
 NHWC, NCHW = 0, 1
-ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID, ACT_RELU6, ACT_LRELU, ACT_TANH = 0, 1, 2, 3, 4, 5, 6
 DECAY_L2, DECAY_L1, DECAY_HUBER = 0, 1, 2
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 OK, E_BADARG, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = 0, -1, -2, -3, -4
@@ -89,6 +89,8 @@ SIGNATURES = {
     'mcn_channel_scale_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_act_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'mcn_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mcn_act_fwd_p': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    'mcn_act_bwd_p': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     'mcn_relu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'mcn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'mcn_add_relu_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -115,13 +117,16 @@ SIGNATURES = {
     'mcn_decoupled_decay_h': (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_float, c_void_p]),
     'mcn_ema_update_h': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'mcn_softmax_xent_rows_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    'mcn_softmax_xent_rows_soft_fwd_bwd': (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     'mcn_resize_bilinear_fwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),
     'mcn_resize_bilinear_bwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),
     'mcn_copy_channels': (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_one_hot_seg': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'mcn_clip_by_global_norm': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mcn_clip_by_global_norm_runs': (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int32, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mcn_ema_update': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     'mcn_bn_running_chain': (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_void_p]),
+    'mcn_bn_running_chain_strided': (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_float, c_void_p]),
 }
 
 

@@ -316,7 +316,8 @@ class ConvNet(object):
         shape = tuple(logits.shape)
         self.pred = g.tensor(shape, 'float32', 'pred')
         self.d['pred'] = self.pred
-        self._loss_node = g.node('loss', [logits, labels], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
+        raw = getattr(labels, 'soft_avg_of', None)          # SegNet smoothing: `labels` is the 5x5 average of the raw one-hot map `raw`
+        self._loss_node = g.node('loss', [logits, labels] if raw is None else [logits, raw, labels], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
                                  label_smoothing=float(getattr(labels, 'ls_factor', 0.0)), rows=int(np.prod(shape[:-1])), per_pixel=len(shape) == 4)
         return self._loss_node
 
@@ -857,12 +858,32 @@ class ConvNet(object):
             return self.swish(x, name=activation_type)
         if act == 'sigmoid':
             return self.sigmoid(x, name=activation_type)
-        raise NotImplementedError('activation {} is outside the built path (supported: relu, swish, sigmoid)'.format(activation_type))
+        if act == 'relu6':
+            return self.relu6(x, name=activation_type)
+        if act == 'lrelu' or act == 'leaky_relu':
+            return self.lrelu(x, alpha=params, name=activation_type)
+        if act == 'tanh':
+            return self.tanh(x, name=activation_type)
+        raise ValueError('Activation type of {} is not supported. Supported types: {}'
+                         .format(activation_type, ['relu', 'relu6', 'lrelu', 'tanh', 'sigmoid', 'swish']))
 
-    def _act(self, x, kind, name):
+    def _act(self, x, kind, name, param=None):
         y = self.graph.tensor(x.shape, x.dtype, self.scope_name(name), self._channel_first)
-        self.graph.node('act', [x], [y], scope=self.scope_name(), kind=kind)
+        attrs = dict(kind=kind) if param is None else dict(kind=kind, param=float(param))
+        self.graph.node('act', [x], [y], scope=self.scope_name(), **attrs)
         return y
+
+    def relu6(self, x, name='relu6'):
+        """reference convnet.py:2539-2540 -> tf.nn.relu6."""
+        return self._act(x, _ffi.ACT_RELU6, name)
+
+    def lrelu(self, x, alpha=None, name='lrelu'):
+        """reference convnet.py:2542-2545 -> tf.nn.leaky_relu(x, alpha), alpha defaults to 0.2."""
+        return self._act(x, _ffi.ACT_LRELU, name, param=0.2 if alpha is None else alpha)
+
+    def tanh(self, x, name='tanh'):
+        """reference convnet.py:2547 -> tf.nn.tanh."""
+        return self._act(x, _ffi.ACT_TANH, name)
 
     def sigmoid(self, x, name=None):
         """reference convnet.py:2549-2550 -> tf.nn.sigmoid."""

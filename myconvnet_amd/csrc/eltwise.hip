@@ -10,11 +10,18 @@ static inline unsigned ew_blocks(long nvec) {
     return (unsigned)b;
 }
 
-enum { EW_RELU = 0, EW_RELU_BWD = 1, EW_ADD = 2, EW_ADD_RELU = 3, EW_ACC = 4, EW_SWISH = 5, EW_SIGMOID = 6, EW_SWISH_BWD = 7, EW_SIGMOID_BWD = 8 };
+enum { EW_RELU = 0, EW_RELU_BWD = 1, EW_ADD = 2, EW_ADD_RELU = 3, EW_ACC = 4, EW_SWISH = 5, EW_SIGMOID = 6, EW_SWISH_BWD = 7, EW_SIGMOID_BWD = 8,
+       EW_RELU6 = 9, EW_LRELU = 10, EW_TANH = 11, EW_RELU6_BWD = 12, EW_LRELU_BWD = 13, EW_TANH_BWD = 14 };
 
 template <int OP>
-__device__ __forceinline__ float ew_apply(float va, float vb) {
+__device__ __forceinline__ float ew_apply(float va, float vb, float p = 0.f) {
     if (OP == EW_RELU) return fmaxf(va, 0.f);
+    if (OP == EW_RELU6) return fminf(fmaxf(va, 0.f), 6.f);                   // tf.nn.relu6, convnet.py:2539-2540
+    if (OP == EW_LRELU) return va > 0.f ? va : p * va;                       // tf.nn.leaky_relu(alpha), convnet.py:2542-2545
+    if (OP == EW_TANH) return tanhf(va);                                     // tf.nn.tanh, convnet.py:2547
+    if (OP == EW_RELU6_BWD) return (vb > 0.f && vb < 6.f) ? va : 0.f;        // Relu6Grad: a = dy, b = y (0 < y < 6 <=> 0 < x < 6)
+    if (OP == EW_LRELU_BWD) return vb > 0.f ? va : p * va;                   // LeakyReluGrad: a = dy, b = x
+    if (OP == EW_TANH_BWD) return va * (1.f - vb * vb);                      // TanhGrad: a = dy, b = y
     if (OP == EW_RELU_BWD) return vb > 0.f ? va : 0.f;                       // a = dy, b = y
     if (OP == EW_ADD || OP == EW_ACC) return va + vb;
     if (OP == EW_ADD_RELU) return fmaxf(va + vb, 0.f);
@@ -27,10 +34,10 @@ __device__ __forceinline__ float ew_apply(float va, float vb) {
     return va * vb * (1.f - vb);                                             // EW_SIGMOID_BWD: a = dy, b = y
 }
 template <int OP>
-struct EwUnary { static constexpr bool value = OP == EW_RELU || OP == EW_SWISH || OP == EW_SIGMOID; };
+struct EwUnary { static constexpr bool value = OP == EW_RELU || OP == EW_SWISH || OP == EW_SIGMOID || OP == EW_RELU6 || OP == EW_LRELU || OP == EW_TANH; };
 
 template <typename T, int OP>
-__global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n) {
+__global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n, float p) {
     constexpr int CE = VecTraits<T>::CE;
     const long nvec = n / CE;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -38,25 +45,25 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const 
         Chunk<T> ca = load_chunk<T>(a + i * CE), cb, co;
         if (!EwUnary<OP>::value) cb = load_chunk<T>(b + i * CE);
 #pragma unroll
-        for (int k = 0; k < CE; ++k) co.set(k, ew_apply<OP>(ca.get(k), EwUnary<OP>::value ? 0.f : cb.get(k)));
+        for (int k = 0; k < CE; ++k) co.set(k, ew_apply<OP>(ca.get(k), EwUnary<OP>::value ? 0.f : cb.get(k), p));
         store_chunk<T>(y + i * CE, co);
     }
     // scalar tail
     const long t0 = nvec * CE;
     for (long i = t0 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        y[i] = from_f32<T>(ew_apply<OP>(to_f32(a[i]), EwUnary<OP>::value ? 0.f : to_f32(b[i])));
+        y[i] = from_f32<T>(ew_apply<OP>(to_f32(a[i]), EwUnary<OP>::value ? 0.f : to_f32(b[i]), p));
 }
 
 template <int OP>
-static int ew_dispatch(const void* a, const void* b, void* y, long n, mcn_dtype dt, hipStream_t st, const char* name) {
+static int ew_dispatch(const void* a, const void* b, void* y, long n, mcn_dtype dt, hipStream_t st, const char* name, float p = 0.f) {
     if (n < 0 || !a || !y) MCN_FAIL(MCN_E_BADARG, "%s: bad argument", name);
     if (n == 0) return MCN_OK;
     if (dt == MCN_F32)
-        hipLaunchKernelGGL((ew_kernel<float, OP>), dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, n);
+        hipLaunchKernelGGL((ew_kernel<float, OP>), dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, n, p);
     else if (dt == MCN_BF16)
-        hipLaunchKernelGGL((ew_kernel<bf16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+        hipLaunchKernelGGL((ew_kernel<bf16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n, p);
     else if (dt == MCN_F16)
-        hipLaunchKernelGGL((ew_kernel<f16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)y, n);
+        hipLaunchKernelGGL((ew_kernel<f16_t, OP>), dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)y, n, p);
     else
         MCN_FAIL(MCN_E_UNSUPPORTED, "%s: dtype %d unsupported", name, (int)dt);
     MCN_CHECK_LAUNCH();
@@ -86,30 +93,39 @@ extern "C" int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t
     }
     return MCN_OK;
 }
-/* element-wise activations on small tensors (SE branch): swish / sigmoid / relu */
-extern "C" int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+/* element-wise activations (the reference's dispatcher, convnet.py:2514-2556): relu / relu6 / lrelu(alpha) / tanh / sigmoid / swish */
+extern "C" int mcn_act_fwd_p(const void* x, void* y, int64_t n, mcn_act act, float param, mcn_dtype dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (act == MCN_ACT_RELU) return ew_dispatch<EW_RELU>(x, nullptr, y, n, dtype, st, "act_fwd");
     if (act == MCN_ACT_SWISH) return ew_dispatch<EW_SWISH>(x, nullptr, y, n, dtype, st, "act_fwd");
     if (act == MCN_ACT_SIGMOID) return ew_dispatch<EW_SIGMOID>(x, nullptr, y, n, dtype, st, "act_fwd");
+    if (act == MCN_ACT_RELU6) return ew_dispatch<EW_RELU6>(x, nullptr, y, n, dtype, st, "act_fwd");
+    if (act == MCN_ACT_LRELU) return ew_dispatch<EW_LRELU>(x, nullptr, y, n, dtype, st, "act_fwd", param);
+    if (act == MCN_ACT_TANH) return ew_dispatch<EW_TANH>(x, nullptr, y, n, dtype, st, "act_fwd");
     MCN_FAIL(MCN_E_UNSUPPORTED, "act_fwd: activation %d unsupported", (int)act);
 }
-/* dx = dy * act'(.)  — relu and sigmoid differentiate through the stored output y, swish through the input x */
-extern "C" int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+extern "C" int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+    return mcn_act_fwd_p(x, y, n, act, 0.2f, dtype, stream);                 // alpha = 0.2: the reference's default (convnet.py:2543-2544)
+}
+/* dx = dy * act'(.)  — relu, relu6, tanh and sigmoid differentiate through the stored output y, swish and lrelu through the input x */
+extern "C" int mcn_act_bwd_p(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, float param, mcn_dtype dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (act == MCN_ACT_RELU) {
-        if (!y) MCN_FAIL(MCN_E_BADARG, "act_bwd: relu needs y");
-        return ew_dispatch<EW_RELU_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
-    }
-    if (act == MCN_ACT_SWISH) {
-        if (!x) MCN_FAIL(MCN_E_BADARG, "act_bwd: swish needs x");
-        return ew_dispatch<EW_SWISH_BWD>(dy, x, dx, n, dtype, st, "act_bwd");
-    }
-    if (act == MCN_ACT_SIGMOID) {
-        if (!y) MCN_FAIL(MCN_E_BADARG, "act_bwd: sigmoid needs y");
+    if (act == MCN_ACT_RELU || act == MCN_ACT_RELU6 || act == MCN_ACT_TANH || act == MCN_ACT_SIGMOID) {
+        if (!y) MCN_FAIL(MCN_E_BADARG, "act_bwd: activation %d needs y", (int)act);
+        if (act == MCN_ACT_RELU) return ew_dispatch<EW_RELU_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
+        if (act == MCN_ACT_RELU6) return ew_dispatch<EW_RELU6_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
+        if (act == MCN_ACT_TANH) return ew_dispatch<EW_TANH_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
         return ew_dispatch<EW_SIGMOID_BWD>(dy, y, dx, n, dtype, st, "act_bwd");
     }
+    if (act == MCN_ACT_SWISH || act == MCN_ACT_LRELU) {
+        if (!x) MCN_FAIL(MCN_E_BADARG, "act_bwd: activation %d needs x", (int)act);
+        if (act == MCN_ACT_SWISH) return ew_dispatch<EW_SWISH_BWD>(dy, x, dx, n, dtype, st, "act_bwd");
+        return ew_dispatch<EW_LRELU_BWD>(dy, x, dx, n, dtype, st, "act_bwd", param);
+    }
     MCN_FAIL(MCN_E_UNSUPPORTED, "act_bwd: activation %d unsupported", (int)act);
+}
+extern "C" int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* stream) {
+    return mcn_act_bwd_p(dy, x, y, dx, n, act, 0.2f, dtype, stream);
 }
 extern "C" int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void* stream) {
     if (!b) MCN_FAIL(MCN_E_BADARG, "accumulate: null b");

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
 __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                                     const float* __restrict__ class_w, float* __restrict__ pred,
                                                                     float* __restrict__ ce, float* __restrict__ coef, float* __restrict__ dlogits,
-                                                                    long B, int C, float ls, float loss_scale) {
+                                                                    long B, int C, float ls, float loss_scale, const float* __restrict__ avg) {
     extern __shared__ float xs[];
     const int P = C | 1;
     float* zt = xs;
@@ -97,7 +97,10 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
             // one exponential per class: e = exp(z - max) is kept in the row's LDS slot and pred = e / sum(e) (the second
             // exp(log-softmax) per class made this kernel VALU bound at 21 classes x 4.2 M pixels); the loss uses
             // -sum(lab * lsm) = lse * sum(lab) - sum(lab * (z - max))
-            float se = 0.f, sy = 0.f, bw = 0.f, slz = 0.f;
+            // soft-label target of the smoothing: 1/C (convnet.py:603-607) or the 5x5 average of the label map (segnet.py:117-122;
+            // a rarely used option: the row's averages are read straight from global memory)
+            const float* av = avg ? avg + (b0 + threadIdx.x) * C : nullptr;
+            float se = 0.f, sy = 0.f, bw = 0.f, slz = 0.f, sl = 0.f;
             for (int c = 0; c < C; ++c) {
                 const float d = z[c] - mx;
                 const float e = expf(d);
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
                 const float y = yv[c];
                 sy += y;
                 bw += y * (class_w ? class_w[c] : 1.f);
-                const float lab = ls > 0.f ? y * (1.f - ls) + ls / (float)C : y;
+                const float lab = ls > 0.f ? y * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : y;
+                sl += lab;
                 slz += lab * d;
                 z[c] = e;
             }
@@ -113,12 +117,12 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
             const float inv = 1.f / se;
             const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
             const float cf = bw * valid;
-            const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
+            const float lab_sum = av ? sl : (ls > 0.f ? sy * (1.f - ls) + ls : sy);
             const float gscale = cf * loss_scale / (float)B;
             const float cel = lse * lab_sum - slz;
             for (int c = 0; c < C; ++c) {
                 const float pr = z[c] * inv;
-                const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+                const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : yv[c];
                 z[c] = pr;
                 yv[c] = (pr * lab_sum - lab) * gscale;
             }
@@ -178,9 +182,9 @@ extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels
 
 /* per-pixel variant (segmentation: rows = N*H*W pixels, few classes): one thread per row, two-stage mean through the
  * caller's workspace (>= 1024 floats) */
-extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
-                                             float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void* ws,
-                                             size_t ws_bytes, void* stream) {
+extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred,
+                                                  float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing,
+                                                  float loss_scale, void* ws, size_t ws_bytes, void* stream) {
     if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "softmax_xent_rows: bad argument");
     if (C > 64) MCN_FAIL(MCN_E_UNSUPPORTED, "softmax_xent_rows: C=%d > 64 classes: use mcn_softmax_xent_fwd_bwd", C);
     if (loss && (!ws || ws_bytes < 1024 * sizeof(float))) MCN_FAIL(MCN_E_WORKSPACE, "softmax_xent_rows: workspace needs 4096 bytes");
@@ -191,7 +195,7 @@ extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* l
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XR_ROWS * 65 * 4), true);
     (void)once;
     hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((unsigned)blocks), dim3(XR_ROWS), lds, st, logits, labels, class_w, pred, ce, coef, dlogits, (long)B, C,
-                       label_smoothing, loss_scale);
+                       label_smoothing, loss_scale, label_smoothing > 0.f ? avg_labels : (const float*)nullptr);
     MCN_CHECK_LAUNCH();
     if (loss) {
         hipLaunchKernelGGL(xent_partial_kernel, dim3(1024), dim3(256), 0, st, (const float*)ce, (const float*)coef, (float*)ws, (long)B);
@@ -200,6 +204,12 @@ extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* l
         MCN_CHECK_LAUNCH();
     }
     return MCN_OK;
+}
+extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
+                                             float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void* ws,
+                                             size_t ws_bytes, void* stream) {
+    return mcn_softmax_xent_rows_soft_fwd_bwd(logits, labels, nullptr, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, ws, ws_bytes,
+                                              stream);
 }
 
 // ---- L2 regulariser value ---------------------------------------------------------------------------------
@@ -297,6 +307,35 @@ extern "C" int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int6
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(clip_scale_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, g, (long)n, (const float*)sc, norm_out);
     MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+extern "C" int mcn_clip_by_global_norm_runs(float* g, const float* w, const int64_t* runs, int32_t nruns, float l2, float threshold, float* norm_out,
+                                            void* ws, size_t ws_bytes, void* stream) {
+    if (!g || !runs || nruns < 0 || !(threshold > 0.f)) MCN_FAIL(MCN_E_BADARG, "clip_by_global_norm_runs: bad argument");
+    for (int r = 0; r < nruns; ++r) {
+        const int64_t s = runs[3 * r], e = runs[3 * r + 1], le = runs[3 * r + 2];
+        if (s < 0 || e < s || le < s || le > e || (le > s && l2 != 0.f && !w)) MCN_FAIL(MCN_E_BADARG, "clip_by_global_norm_runs: bad run %d", r);
+    }
+    const size_t need = ((size_t)nruns * L2_BLOCKS + 4) * sizeof(float);
+    if (!ws || ws_bytes < need) MCN_FAIL(MCN_E_WORKSPACE, "clip_by_global_norm_runs: workspace needs %zu bytes", need);
+    if (nruns == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* sc = part + (size_t)nruns * L2_BLOCKS;
+    for (int r = 0; r < nruns; ++r) {                       // every slot of the run's partial row is written (empty blocks write 0)
+        const int64_t s = runs[3 * r], e = runs[3 * r + 1], le = runs[3 * r + 2];
+        hipLaunchKernelGGL(clip_prepare_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, g + s, w ? w + s : w, (long)(e - s), (long)(l2 != 0.f ? le - s : 0), l2,
+                           part + (size_t)r * L2_BLOCKS);
+        MCN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(clip_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nruns * L2_BLOCKS, threshold, sc);
+    MCN_CHECK_LAUNCH();
+    for (int r = 0; r < nruns; ++r) {
+        const int64_t s = runs[3 * r], e = runs[3 * r + 1];
+        hipLaunchKernelGGL(clip_scale_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, g + s, (long)(e - s), (const float*)sc, r == 0 ? norm_out : (float*)nullptr);
+        MCN_CHECK_LAUNCH();
+    }
     return MCN_OK;
 }
 
@@ -426,19 +465,24 @@ static int ema_launch(float* shadow, const float* v, int64_t n, float decay, con
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
-__global__ void bn_chain_kernel(float* __restrict__ run, const float* __restrict__ batch, int towers, long n, float m) {
+__global__ void bn_chain_kernel(float* __restrict__ run, const float* __restrict__ batch, int towers, long n, long stride, float m) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float r = run[i];
-        for (int k = 0; k < towers; ++k) r = m * r + (1.f - m) * batch[(long)k * n + i];
+        for (int k = 0; k < towers; ++k) r = m * r + (1.f - m) * batch[(long)k * stride + i];
         run[i] = r;
     }
 }
-extern "C" int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* stream) {
-    if (!running || !batch || towers < 0 || n < 0) MCN_FAIL(MCN_E_BADARG, "bn_running_chain: bad argument");
+extern "C" int mcn_bn_running_chain_strided(float* running, const float* batch, int32_t towers, int64_t n, int64_t tower_stride, float momentum,
+                                            void* stream) {
+    if (!running || !batch || towers < 0 || n < 0 || tower_stride < n) MCN_FAIL(MCN_E_BADARG, "bn_running_chain: bad argument");
     if (n == 0 || towers == 0) return MCN_OK;
     long blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(bn_chain_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, running, batch, towers, (long)n, momentum);
+    hipLaunchKernelGGL(bn_chain_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, running, batch, towers, (long)n, (long)tower_stride,
+                       momentum);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
+}
+extern "C" int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* stream) {
+    return mcn_bn_running_chain_strided(running, batch, towers, n, n, momentum, stream);
 }

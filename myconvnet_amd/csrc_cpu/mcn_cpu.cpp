@@ -650,7 +650,8 @@ extern "C" int mcn_add_relu_bwd(const void* dy, const void* y, void* dx, int64_t
         return map_n<S>(n, [&](int64_t i) { S::st((T*)dx + i, (act != MCN_ACT_RELU || S::ld((const T*)y + i) > 0.f) ? S::ld((const T*)dy + i) : 0.f); });
     });
 }
-extern "C" int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void*) {
+extern "C" int mcn_act_fwd_p(const void* x, void* y, int64_t n, mcn_act act, float param, mcn_dtype dtype, void*) {
+    if (act < MCN_ACT_RELU || act > MCN_ACT_TANH) return fail(MCN_E_UNSUPPORTED, "act_fwd: activation unsupported");
     return by_dtype(dtype, "act_fwd", [&](auto s) {
         typedef decltype(s) S;
         typedef typename S::T T;
@@ -659,11 +660,18 @@ extern "C" int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_d
             if (act == MCN_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (act == MCN_ACT_SWISH) v = v * sigmoidf(v);
             else if (act == MCN_ACT_SIGMOID) v = sigmoidf(v);
+            else if (act == MCN_ACT_RELU6) v = std::min(std::max(v, 0.f), 6.f);
+            else if (act == MCN_ACT_LRELU) v = v > 0.f ? v : param * v;
+            else if (act == MCN_ACT_TANH) v = std::tanh(v);
             S::st((T*)y + i, v);
         });
     });
 }
-extern "C" int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void*) {
+extern "C" int mcn_act_fwd(const void* x, void* y, int64_t n, mcn_act act, mcn_dtype dtype, void* s) { return mcn_act_fwd_p(x, y, n, act, 0.2f, dtype, s); }
+extern "C" int mcn_act_bwd_p(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, float param, mcn_dtype dtype, void*) {
+    if (act < MCN_ACT_RELU || act > MCN_ACT_TANH) return fail(MCN_E_UNSUPPORTED, "act_bwd: activation unsupported");
+    const bool via_x = act == MCN_ACT_SWISH || act == MCN_ACT_LRELU;
+    if ((via_x && !x) || (!via_x && !y)) return fail(MCN_E_BADARG, "act_bwd: missing x / y");
     return by_dtype(dtype, "act_bwd", [&](auto s) {
         typedef decltype(s) S;
         typedef typename S::T T;
@@ -672,9 +680,15 @@ extern "C" int mcn_act_bwd(const void* dy, const void* x, const void* y, void* d
             if (act == MCN_ACT_RELU) g = S::ld((const T*)y + i) > 0.f ? g : 0.f;
             else if (act == MCN_ACT_SWISH) g *= swish_grad(S::ld((const T*)x + i));
             else if (act == MCN_ACT_SIGMOID) { const float o = S::ld((const T*)y + i); g *= o * (1.f - o); }
+            else if (act == MCN_ACT_RELU6) { const float o = S::ld((const T*)y + i); g = (o > 0.f && o < 6.f) ? g : 0.f; }
+            else if (act == MCN_ACT_LRELU) g = S::ld((const T*)x + i) > 0.f ? g : param * g;
+            else if (act == MCN_ACT_TANH) { const float o = S::ld((const T*)y + i); g *= 1.f - o * o; }
             S::st((T*)dx + i, g);
         });
     });
+}
+extern "C" int mcn_act_bwd(const void* dy, const void* x, const void* y, void* dx, int64_t n, mcn_act act, mcn_dtype dtype, void* s) {
+    return mcn_act_bwd_p(dy, x, y, dx, n, act, 0.2f, dtype, s);
 }
 extern "C" int mcn_accumulate(void* a, const void* b, int64_t n, mcn_dtype dtype, void*) {
     return by_dtype(dtype, "accumulate", [&](auto s) {
@@ -952,7 +966,7 @@ extern "C" int mcn_fc_bwd(const void* dy, const void* x, const float* w, void* d
 
 // ---- loss (convnet.py:528-601) ---------------------------------------------------------------------------------------------------------------
 static int xent_rows(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float ls,
-                     float loss_scale) {
+                     float loss_scale, const float* avg = nullptr) {
     if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) return fail(MCN_E_BADARG, "softmax_xent: bad argument");
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
@@ -969,12 +983,17 @@ static int xent_rows(const float* logits, const float* labels, const float* clas
         const float lse = logf(se);
         const float valid = (sy > 1.f - 1e-5f && sy < 1.f + 1e-5f) ? 1.f : 0.f;
         const float cf = bw * valid;
-        const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
+        const float* av = (avg && ls > 0.f) ? avg + b * C : nullptr;
+        float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
+        if (av) {
+            lab_sum = 0.f;
+            for (int c = 0; c < C; ++c) lab_sum += yv[c] * (1.f - ls) + ls * av[c];
+        }
         const float gscale = cf * loss_scale / (float)B;
         float cel = 0.f;
         for (int c = 0; c < C; ++c) {
             const float lsm = z[c] - mx - lse, p = expf(lsm);
-            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : yv[c];
             cel -= lab * lsm;
             if (pred) pred[b * C + c] = p;
             if (dlogits) dlogits[b * C + c] = (p * lab_sum - lab) * gscale;
@@ -996,6 +1015,10 @@ extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels
 extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef, float* dlogits, float* loss,
                                              int64_t B, int32_t C, float label_smoothing, float loss_scale, void*, size_t, void*) {
     return xent_rows(logits, labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale);
+}
+extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred, float* ce, float* coef,
+                                                  float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void*, size_t, void*) {
+    return xent_rows(logits, labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, avg_labels);
 }
 
 // ---- segmentation path: bilinear resize (tf.image.resize_bilinear, convnet.py:2396) ------------------------------------------------------------
@@ -1119,6 +1142,24 @@ extern "C" int mcn_clip_by_global_norm(float* g, const float* w, int64_t n, int6
     if (norm_out) norm_out[0] = norm;
     return MCN_OK;
 }
+extern "C" int mcn_clip_by_global_norm_runs(float* g, const float* w, const int64_t* runs, int32_t nruns, float l2, float threshold, float* norm_out, void*, size_t,
+                                            void*) {
+    if (!g || !runs || nruns < 0 || !(threshold > 0.f)) return fail(MCN_E_BADARG, "clip_by_global_norm_runs: bad argument");
+    double a = 0.0;
+    for (int r = 0; r < nruns; ++r) {
+        const int64_t s = runs[3 * r], e = runs[3 * r + 1], le = runs[3 * r + 2];
+        if (s < 0 || e < s || le < s || le > e || (le > s && l2 != 0.f && !w)) return fail(MCN_E_BADARG, "clip_by_global_norm_runs: bad run");
+        for (int64_t i = s; i < e; ++i) {
+            if (i < le && l2 != 0.f) g[i] = fmaf(l2, w[i], g[i]);
+            a += (double)g[i] * g[i];
+        }
+    }
+    const float norm = (float)std::sqrt(a), sc = threshold / std::max(norm, threshold);
+    for (int r = 0; r < nruns; ++r)
+        for (int64_t i = runs[3 * r]; i < runs[3 * r + 1]; ++i) g[i] *= sc;
+    if (norm_out) norm_out[0] = norm;
+    return MCN_OK;
+}
 extern "C" int mcn_ema_update(float* shadow, const float* v, int64_t n, float decay_, void*) {
     if (!shadow || !v || n < 0) return fail(MCN_E_BADARG, "ema_update: bad argument");
     for (int64_t i = 0; i < n; ++i) shadow[i] = decay_ * shadow[i] + (1.f - decay_) * v[i];
@@ -1128,12 +1169,15 @@ extern "C" int mcn_ema_update_h(float* shadow, const float* v, int64_t n, const 
     if (!hyper) return fail(MCN_E_BADARG, "ema_update_h: null hyper-parameter buffer");
     return mcn_ema_update(shadow, v, n, hyper[2], nullptr);
 }
-extern "C" int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void*) {
-    if (!running || !batch || towers < 0 || n < 0) return fail(MCN_E_BADARG, "bn_running_chain: bad argument");
+extern "C" int mcn_bn_running_chain_strided(float* running, const float* batch, int32_t towers, int64_t n, int64_t tower_stride, float momentum, void*) {
+    if (!running || !batch || towers < 0 || n < 0 || tower_stride < n) return fail(MCN_E_BADARG, "bn_running_chain: bad argument");
     for (int64_t i = 0; i < n; ++i) {
         float r = running[i];
-        for (int k = 0; k < towers; ++k) r = momentum * r + (1.f - momentum) * batch[(size_t)k * n + i];
+        for (int k = 0; k < towers; ++k) r = momentum * r + (1.f - momentum) * batch[(size_t)k * tower_stride + i];
         running[i] = r;
     }
     return MCN_OK;
+}
+extern "C" int mcn_bn_running_chain(float* running, const float* batch, int32_t towers, int64_t n, float momentum, void* s) {
+    return mcn_bn_running_chain_strided(running, batch, towers, n, n, momentum, s);
 }

@@ -473,12 +473,12 @@ class Lowering(object):
 
     def fwd_act(self, n):
         x, y = n.inputs[0], n.outputs[0]
-        self.fwd.add(lib.mcn_act_fwd, x.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel(), n.attrs['kind'], MCN_DT[x.dtype])
+        self.fwd.add(lib.mcn_act_fwd_p, x.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel(), n.attrs['kind'], float(n.attrs.get('param', 0.2)), MCN_DT[x.dtype])
 
     def bwd_act(self, n):
         x, y = n.inputs[0], n.outputs[0]
-        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_act_bwd, y.grad.data_ptr(), x.buf.data_ptr(), y.buf.data_ptr(), dst,
-                                                                y.buf.numel(), n.attrs['kind'], MCN_DT[x.dtype]))
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_act_bwd_p, y.grad.data_ptr(), x.buf.data_ptr(), y.buf.data_ptr(), dst,
+                                                                y.buf.numel(), n.attrs['kind'], float(n.attrs.get('param', 0.2)), MCN_DT[x.dtype]))
 
     def _mulmask_args(self, n):
         """dropout / stochastic depth through the channel-scale kernel: [N, HW, C] * mask[N, C] with, for the per-sample
@@ -857,7 +857,12 @@ class Lowering(object):
         dl = logits.grad.data_ptr() if (self.train and logits.needs_grad) else 0
         if dl:
             self.written.add(logits.id)
-        if a.get('per_pixel'):
+        if len(n.inputs) == 3:                               # SegNet label smoothing: raw one-hot map + its 5x5 average (segnet.py:117-122)
+            assert a.get('per_pixel')
+            self.fwd.add(lib.mcn_softmax_xent_rows_soft_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), n.inputs[2].buf.data_ptr(), ptr(a.get('class_w')),
+                         a['pred'].buf.data_ptr(), a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']),
+                         self.loss_scale, self.ws_ptr, self.ws_bytes)
+        elif a.get('per_pixel'):
             self.fwd.add(lib.mcn_softmax_xent_rows_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
                          a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale,
                          self.ws_ptr, self.ws_bytes)

@@ -7,6 +7,7 @@ remaining backward kernels run (dist.py); Nesterov momentum, the L2 term, the EM
 decoupled decay are one fused kernel over the flat parameter buffer; the per-step device->host copy of
 Y_all / pred (optimizers.py:590-594) is optional (`fetch=False`) so the training loop never synchronises.
 """
+import ctypes
 import os
 import time
 
@@ -87,8 +88,6 @@ class Optimizer(object):
         st = m.store
         nw, n = m.n_l2_elems, st.size
         frozen = any(not v.trainable for v in st.variables)
-        if frozen and self.gradient_threshold is not None:
-            raise NotImplementedError('gradient clipping together with blocks_to_train (frozen variables) is not built')
         # update_vars = tf.trainable_variables() (optimizers.py:53): maximal contiguous runs of trainable / frozen variables of
         # the flat store, cut at the end of the regularised range.  A frozen run only moves its EMA shadow (ema.apply runs
         # for every variable, convnet.py:1400-1404).
@@ -131,8 +130,22 @@ class Optimizer(object):
         if self.gradient_threshold is not None:
             self.grad_norm = torch.zeros(1, dtype=torch.float32, device=m.device)
             low = m._train_low
-            self._clip.add(lib.mcn_clip_by_global_norm, st.grad.data_ptr(), st.data.data_ptr(), n, nw, self.l2_reg, float(self.gradient_threshold),
-                           self.grad_norm.data_ptr(), low.ws_ptr, low.ws_bytes)
+            if not frozen:
+                self._clip.add(lib.mcn_clip_by_global_norm, st.grad.data_ptr(), st.data.data_ptr(), n, nw, self.l2_reg, float(self.gradient_threshold),
+                               self.grad_norm.data_ptr(), low.ws_ptr, low.ws_bytes)
+            else:
+                # clipping with blocks_to_train: norm and L2 fold over update_vars only (optimizers.py:53,106,112-113) = the trainable runs
+                tr = [(s1, e1, min(max(nw, s1), e1)) for s1, e1, trainable in runs if trainable]
+                merged = []
+                for s1, e1, le in tr:                      # re-join runs that were only cut at the end of the regularised range
+                    if merged and merged[-1][1] == s1 and merged[-1][2] == merged[-1][1]:
+                        merged[-1] = (merged[-1][0], e1, le)
+                    else:
+                        merged.append((s1, e1, le))
+                self._clip_runs = (ctypes.c_int64 * (3 * len(merged)))(*[x for r in merged for x in r])       # host array, read at launch time
+                self._clip_ws = torch.zeros(len(merged) * 1024 + 8, dtype=torch.float32, device=m.device)   # one partial row per run
+                self._clip.add(lib.mcn_clip_by_global_norm_runs, st.grad.data_ptr(), st.data.data_ptr(), self._clip_runs, len(merged), self.l2_reg,
+                               float(self.gradient_threshold), self.grad_norm.data_ptr(), self._clip_ws.data_ptr(), self._clip_ws.numel() * 4)
         # EMA of the BN running statistics (pre-assign value), launched before the forward pass
         self._pre = Program()
         if self.use_ema and m.stats.size > 0:
@@ -144,8 +157,26 @@ class Optimizer(object):
             from .dist import DataParallel
             self.dp = DataParallel(m, bucket_mb=float(kwargs.get('allreduce_bucket_mb', 25.0)))
             if m.world_size > 1:                         # with one rank the BN kernel itself updates the running statistics
-                self._post_fwd.add(lib.mcn_bn_running_chain, m.stats.data.data_ptr(), self.dp.gathered_stats.data_ptr(), m.world_size,
-                                   m.stats.size, float(m.batch_norm_decay))
+                # Only BNs that update their statistics take part (a frozen BN — update_batch_norm=False / outside blocks_to_train — has
+                # no update op in the reference, convnet.py:1915-1923; its batch-statistics slots are never written and its backward
+                # pass READS the running statistics while this chain runs on its own stream): maximal runs of updating ranges
+                runs = []
+                for n_ in m.graph.nodes:
+                    if n_.op == 'bn' and n_.attrs['update']:
+                        for v in (n_.attrs['mu'], n_.attrs['sigma']):
+                            s0, e0 = v.offset, v.offset + (v.size + 3) // 4 * 4
+                            runs.append([s0, e0])
+                runs.sort()
+                merged_runs = []
+                for s0, e0 in runs:
+                    if merged_runs and merged_runs[-1][1] == s0:
+                        merged_runs[-1][1] = e0
+                    else:
+                        merged_runs.append([s0, e0])
+                stride = self.dp.gathered_stats.shape[1]
+                for s0, e0 in merged_runs:
+                    self._post_fwd.add(lib.mcn_bn_running_chain_strided, m.stats.data.data_ptr() + 4 * s0, self.dp.gathered_stats.data_ptr() + 4 * s0,
+                                       m.world_size, min(e0, m.stats.size) - s0, stride, float(m.batch_norm_decay))
         return P
 
     def _set_hyper(self):

@@ -2,8 +2,8 @@
 
 Per-pixel labels [N, H, W] (0 = ignore, k = class k-1; NaN -> 0), one-hot of depth num_classes with all-zero rows for
 ignored pixels, backbone (`_build_model` with backbone_only) + segmentation head (`_build_model_seg`), per-pixel softmax
-cross-entropy averaged over ALL pixels (ignored ones contribute 0), L2 as in ConvNet.  Augmentation, cutmix, the debug
-colour images and the 5x5 label smoothing are outside the built path."""
+cross-entropy averaged over ALL pixels (ignored ones contribute 0), L2 as in ConvNet; label smoothing = the 5x5 SAME average of
+the one-hot label map (segnet.py:117-122).  Augmentation, cutmix and the debug colour images are outside the built path."""
 from abc import abstractmethod
 
 from .convnet import ConvNet
@@ -42,5 +42,11 @@ class SegNet(ConvNet):
         """Must return a dict of tensors including 'logits' [N, H, W, classes] (segnet.py:99-106)."""
 
     def _label_smoothing(self, labels, ls_factor, name='label_smoothing'):
-        """reference segnet.py:117-122: the smoothed labels are a 5x5 SAME average of the one-hot label map, not the uniform mix."""
-        raise NotImplementedError('SegNet label smoothing (5x5 average of the labels, segnet.py:117-122) is not built')
+        """reference segnet.py:117-122: labels <- (1 - f) * labels + f * avg_pool2d(labels, 5x5, stride 1, SAME).  The average is one
+        mcn_avgpool_fwd over the fp32 one-hot map (SAME: divided by the number of in-image cells); the mix itself happens inside the loss
+        kernel (mcn_softmax_xent_rows_soft_fwd_bwd), so the factor and the raw map ride on the averaged tensor."""
+        with self.variable_scope(name):
+            avg = self.avg_pool(labels, (5, 5), (1, 1), padding='SAME')
+        avg.ls_factor = float(ls_factor)
+        avg.soft_avg_of = labels
+        return avg

@@ -764,7 +764,9 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
         # SegNet: labels [N,H,W], per-pixel CE averaged over all pixels, ignored pixels weigh 0 (segnet.py:31-50, convnet.py:528-597)
         onehot = ops.seg_one_hot_labels(y_float, spec.num_classes, dtype=dt)
         c = spec.num_classes
-        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a.reshape(-1, c).astype(dt), onehot.reshape(-1, c), None, 0.0)
+        ls_f = float(hp.get('label_smoothing', 0.0))
+        avg = ops.avgpool_fwd(onehot, 5, 1, 'SAME').reshape(-1, c) if ls_f > 0.0 else None       # segnet.py:117-122
+        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a.reshape(-1, c).astype(dt), onehot.reshape(-1, c), None, ls_f, avg_labels=avg)
         pred, dlogits = pred.reshape(out.a.shape), dlogits.reshape(out.a.shape)
     else:
         onehot = ops.one_hot_labels(y_float, spec.num_classes, dtype=dt)

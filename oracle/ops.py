@@ -324,6 +324,36 @@ def relu_bwd(dy, y):
     return dy * (y > 0)
 
 
+def relu6_fwd(x):
+    """tf.nn.relu6 (convnet.py:2539-2540): min(max(x, 0), 6)."""
+    return np.minimum(np.maximum(x, 0), 6.0)
+
+
+def relu6_bwd(dy, x):
+    """Relu6Grad: dy * [0 < x < 6]."""
+    return dy * ((x > 0) & (x < 6))
+
+
+def lrelu_fwd(x, alpha=0.2):
+    """tf.nn.leaky_relu (convnet.py:2542-2545; the reference's default alpha is 0.2)."""
+    return np.where(x > 0, x, alpha * x)
+
+
+def lrelu_bwd(dy, x, alpha=0.2):
+    """LeakyReluGrad: x > 0 ? dy : alpha * dy."""
+    return np.where(x > 0, dy, alpha * dy)
+
+
+def tanh_fwd(x):
+    """tf.nn.tanh (convnet.py:2547)."""
+    return np.tanh(x)
+
+
+def tanh_bwd(dy, y):
+    """TanhGrad: dy * (1 - y^2)."""
+    return dy * (1.0 - y * y)
+
+
 def sigmoid_fwd(x):
     """tf.nn.sigmoid (convnet.py:2550)."""
     return 1.0 / (1.0 + np.exp(-x))
@@ -495,10 +525,11 @@ def softmax(logits):
     return e / e.sum(axis=-1, keepdims=True)
 
 
-def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0, loss_scale=1.0):
+def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0, loss_scale=1.0, avg_labels=None):
     """pred = softmax(logits) (models/resnet_v1_5.py:78);
     valid = |sum(Y) - 1| < 1e-5 (convnet.py:567-573); batch_w = sum(Y * w) (convnet.py:552);
-    labels = Y*(1-ls) + ls/C (convnet.py:603-607);
+    labels = Y*(1-ls) + ls/C (convnet.py:603-607), or with `avg_labels` SegNet's Y*(1-ls) + ls*avg_pool2d(Y, 5x5, SAME)
+    (segmentation/segnet.py:117-122: avg_labels = avgpool_fwd(Y, 5, 1, 'SAME') flattened like Y);
     CE_i = -sum_c labels_ic * log_softmax_ic (softmax_cross_entropy_with_logits_v2, convnet.py:600);
     softmax_loss = mean_i(batch_w_i * valid_i * CE_i) over ALL rows (convnet.py:594).
     Returns pred, softmax_loss, per-sample CE, dlogits (= d(loss_scale*softmax_loss)/dlogits)."""
@@ -509,6 +540,8 @@ def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0
     sumy = onehot.sum(axis=-1)
     valid = ((sumy > 1.0 - 1e-5) & (sumy < 1.0 + 1e-5)).astype(dt)
     labels = onehot * (1.0 - label_smoothing) + label_smoothing / c if label_smoothing > 0 else onehot
+    if label_smoothing > 0 and avg_labels is not None:
+        labels = onehot * (1.0 - label_smoothing) + label_smoothing * np.asarray(avg_labels, dtype=dt)
     z = logits - logits.max(axis=-1, keepdims=True)
     lse = np.log(np.exp(z).sum(axis=-1, keepdims=True))
     logsm = z - lse

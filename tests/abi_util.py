@@ -203,12 +203,16 @@ def channel_scale(x, m, dy, dtype='float32'):
     return host(y), host(dx), host(dm)
 
 
-def act(x, dy, kind, dtype='float32'):
+def act(x, dy, kind, dtype='float32', param=None):
     xd, dyd = dev(x, dtype), dev(dy, dtype)
     y = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
     dx = torch.full(x.shape, float('nan'), dtype=TDT[dtype], device=DEV)
-    _ffi.check(lib.mcn_act_fwd(xd.data_ptr(), y.data_ptr(), x.size, kind, MDT[dtype], stream()))
-    _ffi.check(lib.mcn_act_bwd(dyd.data_ptr(), xd.data_ptr(), y.data_ptr(), dx.data_ptr(), x.size, kind, MDT[dtype], stream()))
+    if param is None:
+        _ffi.check(lib.mcn_act_fwd(xd.data_ptr(), y.data_ptr(), x.size, kind, MDT[dtype], stream()))
+        _ffi.check(lib.mcn_act_bwd(dyd.data_ptr(), xd.data_ptr(), y.data_ptr(), dx.data_ptr(), x.size, kind, MDT[dtype], stream()))
+    else:
+        _ffi.check(lib.mcn_act_fwd_p(xd.data_ptr(), y.data_ptr(), x.size, kind, float(param), MDT[dtype], stream()))
+        _ffi.check(lib.mcn_act_bwd_p(dyd.data_ptr(), xd.data_ptr(), y.data_ptr(), dx.data_ptr(), x.size, kind, float(param), MDT[dtype], stream()))
     return host(y), host(dx)
 
 

@@ -15,11 +15,11 @@ from test_gpu_efficientnet import worst_grad  # noqa: E402  (BN -> conv -> BN ch
 B, SIZE, CLASSES = 4, 97, 6
 
 
-def make(dtype, fuse=True):
+def make(dtype, fuse=True, **kw):
     import myconvnet_amd as M
     spec = ON.DeepLabSpec(CLASSES, width_div=8, depth_div=3, aspp_dilations=(1, 2, 3))
     model = M.DeepLabV3PlusResNet50([SIZE, SIZE, 3], CLASSES, batch_size=B, width_div=8, depth_div=3, aspp_dilations=[1, 2, 3], fuse=fuse,
-                                    half_precision=(dtype == 'bfloat16'), num_gpus=1)
+                                    half_precision=(dtype == 'bfloat16'), num_gpus=1, **kw)
     params, stats = ON.init_variables(spec.variables(), seed=6, dtype=np.float32)
     rng = np.random.default_rng(12)
     for k in params:
@@ -68,6 +68,30 @@ def test_deeplab_two_steps_fp32(fuse):
         got = model.get_variables('data')
         worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
         assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
+
+
+def test_deeplab_label_smoothing_is_the_5x5_average_of_the_label_map():
+    """SegNet._label_smoothing (segmentation/segnet.py:117-122): labels <- (1 - f) * Y + f * avg_pool2d(Y, 5x5, 1, SAME); batch weights and
+    the valid mask keep reading Y (convnet.py:552, 567-573).  One mcn_avgpool_fwd over the one-hot map + mcn_softmax_xent_rows_soft_fwd_bwd."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(54)
+    model, spec, params, stats = make('float32', label_smoothing=0.2)
+    fns = [getattr(fn, '__name__', '') for fn, _ in model._train_low.fwd.calls]
+    assert 'mcn_softmax_xent_rows_soft_fwd_bwd' in fns and 'mcn_avgpool_fwd' in fns
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    state, plain = ON.TrainState(f64(params), f64(stats)), ON.TrainState(f64(params), f64(stats))
+    x, y = batch(rng)
+    y[1, 40:60, 40:60] = 3.0                                                  # a uniform region (average == label) next to noisy labels
+    model.feed(x, y)
+    loss, y_true, y_pred = opt._step(None)
+    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=B, hp=dict(label_smoothing=0.2))
+    ploss, _, pgrads = ON.train_step(spec, plain, x.astype(np.float64), y.astype(np.float64), batch_total=B)
+    assert abs(rloss - ploss) > 1e-2 * abs(ploss)                             # the smoothing is visible at this size
+    assert abs(loss - rloss) <= 1e-4 * abs(rloss), (loss, rloss)
+    assert rel_l2(y_pred, rpred) <= 1e-4
+    np.testing.assert_array_equal(y_true, O.seg_one_hot_labels(y, CLASSES))   # Y itself stays the raw one-hot map
+    worst = worst_grad(model.get_variables('grad'), rgrads)
+    assert worst[0] <= 1e-3, 'worst gradient {}'.format(worst)
 
 
 def test_deeplab_eval_on_ema():

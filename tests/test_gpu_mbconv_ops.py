@@ -114,6 +114,29 @@ def test_swish_sigmoid_elementwise(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_relu6_lrelu_tanh_elementwise(dtype):
+    """the remaining entries of the reference's activation dispatcher (convnet.py:2514-2547): tf.nn.relu6 / Relu6Grad,
+    tf.nn.leaky_relu(alpha) / LeakyReluGrad (default alpha 0.2 and an explicit one), tf.nn.tanh / TanhGrad"""
+    u = _u()
+    from myconvnet_amd import _ffi
+    x = (4.0 * RNG.standard_normal((37, 24))).astype(np.float32)          # values on both sides of 0 and of 6; vector body + scalar tail
+    x[0, :6] = [0.0, 6.0, -0.0, 7.5, 5.9921875, -3.0]                     # the kinks themselves (bf16-representable)
+    dy = RNG.standard_normal(x.shape).astype(np.float32)
+    xq, dyq = q(x, dtype), q(dy, dtype)
+    y, dx = u.act(x, dy, _ffi.ACT_RELU6, dtype)
+    np.testing.assert_array_equal(y, O.relu6_fwd(xq))                     # clamps are exact in every storage type
+    np.testing.assert_array_equal(dx, O.relu6_bwd(dyq, xq))
+    for alpha in (None, 0.05):
+        y, dx = u.act(x, dy, _ffi.ACT_LRELU, dtype, param=alpha)
+        a = 0.2 if alpha is None else alpha
+        check(y, O.lrelu_fwd(xq, np.float32(a)), dtype, 'lrelu')
+        check(dx, O.lrelu_bwd(dyq, xq, np.float32(a)), dtype, 'lrelu bwd')
+    y, dx = u.act(x, dy, _ffi.ACT_TANH, dtype)
+    check(y, O.tanh_fwd(xq), dtype, 'tanh')
+    check(dx, O.tanh_bwd(dyq, q(y, dtype)), dtype, 'tanh bwd')            # differentiates through the stored (rounded) y
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(3, 7, 7, 32), (4, 5, 9, 144), (2, 14, 14, 480), (2, 1, 1, 8)])
 def test_se_channel_scale(shape, dtype):
     u = _u()

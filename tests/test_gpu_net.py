@@ -188,6 +188,43 @@ def test_resnet_frozen_blocks_and_frozen_batch_norm(freeze, dtype):
                 np.testing.assert_array_equal(got[k], stats[k])
 
 
+@pytest.mark.parametrize('freeze', [dict(blocks_to_train=[0, None]), dict(blocks_to_train=[3, 4, None])])
+def test_resnet_frozen_blocks_with_gradient_clipping(freeze):
+    """gradient_threshold together with blocks_to_train (optimizers.py:53,106,112-113 + convnet.py:1384-1389): tf.clip_by_global_norm sees
+    the gradients of update_vars only, so the norm and the folded L2 gradient cover the trainable runs of the flat store
+    (mcn_clip_by_global_norm_runs); frozen variables stay bit-identical and the clip is active (norm > threshold)."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(321)
+    model, spec, params, stats = make_resnet(18, 'float32', True, **freeze)
+    thr = 0.05
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, gradient_threshold=thr)
+    assert 'mcn_clip_by_global_norm_runs' in [getattr(fn, '__name__', '') for fn, _ in opt._clip.calls]
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    hp = dict(freeze, gradient_threshold=thr)
+    trainable = set(v.name for v in model.store.variables if v.trainable)
+    for step in range(2):
+        x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+        model.feed(x, LABELS)
+        loss, _, y_pred = opt._step(None)
+        rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=hp, batch_total=BATCH)
+        assert set(rgrads) == trainable
+        assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, loss, rloss)
+        norm = float(opt.grad_norm.item())
+        assert norm > thr                                                     # the clip did something
+        grads = model.get_variables('grad')                                   # the flat gradient holds the clipped full-loss gradient
+        gn = np.sqrt(sum(float(np.sum(np.asarray(grads[k], np.float64) ** 2)) for k in trainable))
+        assert abs(gn - thr) <= 1e-4 * thr, (gn, thr)
+        worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads if np.linalg.norm(rgrads[k]) > 1e-9)
+        assert worst[0] <= 1e-3, 'step {}: worst clipped gradient {}'.format(step, worst)
+        got = model.get_variables('data')
+        worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
+        assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
+        for k in params:
+            if k not in trainable:
+                np.testing.assert_array_equal(got[k], params[k])
+                assert not np.any(grads[k])                                   # nothing was folded into a frozen variable's slot
+
+
 def test_resnet_fp32_bn_statistics_from_conv_epilogue():
     """fuse_bn_stats (default on for bf16 only) / defer_dskip: the fp32 network with the BN statistics taken in the conv
     epilogues and the residual fan-in applied in the dgrad epilogue / projection BN backward."""

@@ -198,3 +198,41 @@ def test_loss_scale_rule_and_relower_contract():
     import inspect
     src = inspect.getsource(M.ConvNet.compile)
     assert '_allocated' in src and 'initialize_variables' not in src
+
+
+def test_build_identity_covers_every_kernel_source(tmp_path):
+    """wino_kernels.h was in neither source_digest() nor the mtime check.  Every file under csrc/ must be part of the
+    build identity, every `#include "..."` must resolve into it, and touching any one file must change the digest."""
+    import importlib.util
+    import os
+    import re
+    import shutil
+    pkg = os.path.dirname(M.__file__)
+    spec = importlib.util.spec_from_file_location('_mcn_build_t', os.path.join(pkg, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    covered = {os.path.normpath(os.path.join(mod.CSRC, f)) for f in mod.SOURCES + mod.HEADERS}
+    on_disk = {os.path.normpath(os.path.join(mod.CSRC, f)) for f in os.listdir(mod.CSRC) if os.path.isfile(os.path.join(mod.CSRC, f))}
+    assert on_disk <= covered, sorted(on_disk - covered)
+    assert os.path.normpath(os.path.join(pkg, '..', 'include', 'mcn.h')) in covered
+    for f in sorted(on_disk):
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), re.M):
+            assert os.path.normpath(os.path.join(os.path.dirname(f), inc)) in covered, (f, inc)
+    # a one-byte edit of ANY covered file changes the digest (run on a copy of the tree's csrc/ + include/)
+    root = tmp_path / 'pkg'
+    shutil.copytree(mod.CSRC, root / 'csrc', ignore=shutil.ignore_patterns('_obj'))
+    os.makedirs(tmp_path / 'include')
+    shutil.copy(os.path.join(pkg, '..', 'include', 'mcn.h'), tmp_path / 'include' / 'mcn.h')
+    shutil.copy(os.path.join(pkg, 'build.py'), root / 'build.py')
+    spec = importlib.util.spec_from_file_location('_mcn_build_c', str(root / 'build.py'))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    base = cp.source_digest()
+    assert base == mod.source_digest()
+    for f in cp.SOURCES + cp.HEADERS:
+        path = os.path.join(cp.CSRC, f)
+        orig = open(path, 'rb').read()
+        open(path, 'ab').write(b'\n')
+        assert cp.source_digest() != base, f
+        open(path, 'wb').write(orig)
+    assert cp.source_digest() == base

@@ -52,7 +52,7 @@ OUT_OF_SCOPE = {
                                                                     '_test_drive'],          # (TF timeline trace of one epoch: rocprofv3 is the profiler here)
     'normalisation variants other than batch norm (raise NotImplementedError through `normalization`)': [
         'group_norm', 'group_renorm', 'grouped_batch_norm', 'batch_renorm'],
-    'layers no model of the path uses': ['transposed_conv_layer', 'lrelu', 'relu6', 'tanh', 'prelu', 'elu', 'selu', 'gelu', 'mish',
+    'layers no model of the path uses': ['transposed_conv_layer', 'prelu', 'elu', 'selu', 'gelu', 'mish',
                                          'bilinear_upsampling_layer', 'pad_layer'],
 }
 _ALLOWED_MISSING = {m for names in OUT_OF_SCOPE.values() for m in names}
