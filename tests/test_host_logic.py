@@ -119,8 +119,12 @@ def test_deeplab_inventory_and_graph():
     assert dil == [(1, 1), (1, 2), (2, 2), (4, 1), (6, 1), (8, 1), (12, 1), (18, 1)]      # multi-grid 2,4,8 in block 4 (stride 2 on the first), ASPP 6,12,18
     r101 = M.DeepLabV3PlusResNet([65, 65, 3], 5, batch_size=2, auto_compile=False, device='cpu')
     assert r101.res_units == [None, 3, 4, 23, 3] and r101.strides == [2, 1, 2, 2, 1]
-    with pytest.raises(NotImplementedError):
-        M.DeepLabV3PlusResNet50([65, 65, 3], 5, batch_size=2, label_smoothing=0.1, auto_compile=False, device='cpu')
+    # SegNet label smoothing (segmentation/segnet.py:117-122): a 5x5 / stride 1 SAME average of the one-hot map feeds the loss beside the raw map
+    ls = M.DeepLabV3PlusResNet50([65, 65, 3], 5, batch_size=2, label_smoothing=0.1, auto_compile=False, device='cpu')
+    loss = [n for n in ls.graph.nodes if n.op == 'loss'][0]
+    assert len(loss.inputs) == 3 and loss.inputs[1] is ls.Y and loss.attrs['label_smoothing'] == 0.1
+    pool = loss.inputs[2].producer
+    assert pool.op == 'avgpool' and pool.inputs[0] is ls.Y and (pool.attrs['kh'], pool.attrs['kw'], pool.attrs['sh'], pool.attrs['pt']) == (5, 5, 1, 2)
 
 
 def test_lr_schedule_matches_reference_formulas():
