@@ -86,10 +86,10 @@ def build_model(args, dtype, world):
     return model, opt
 
 
-def run_steps(opt, n):
+def run_steps(opt, n, fetch=False):
     for _ in range(n):
         opt._update_learning_rate()
-        opt._step(None, fetch=False)
+        opt._step(None, fetch=fetch)
         opt.curr_step += 1
 
 
@@ -491,6 +491,56 @@ def cpu_baseline():
     return out
 
 
+def executed_flop_per_image(dtype):
+    """FLOP the MFMA pipes EXECUTE per image and training step.  fp32: the 13 stride-1 3x3 layers (forward, dgrad and wgrad) run Winograd
+    F(2x2, 3x3) / F(3x3, 2x2) — 16 multiplications per 2x2 outputs instead of 36, times the tile cover of an odd map (7x7 is covered by 4x4
+    tiles of 2x2: 64/49) — unless MCN_WINOGRAD=0.  The 2-byte types run every layer as a direct convolution.  (the headline
+    utilisation used the direct count for both.)"""
+    if dtype != 'fp32' or os.environ.get('MCN_WINOGRAD', '1') == '0':
+        return float(TRAIN_FLOP_PER_IMAGE)
+    saved = 0.0
+    for h, c, n in ((56, 64, 3), (28, 128, 3), (14, 256, 5), (7, 512, 2)):
+        direct = 2.0 * h * h * 9 * c * c * 3                              # fwd + dgrad + wgrad of one layer
+        cover = float(((h + 1) // 2 * 2) ** 2) / (h * h)
+        saved += n * direct * (1.0 - 16.0 / 36.0 * cover)
+    return float(TRAIN_FLOP_PER_IMAGE) - saved
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one per GPU, started BEFORE this process makes any GPU call
+    (a process that has initialised the GPU must never exec or fork into another one; this parent only ever waits).  Rank 0's stdout is
+    this process's stdout, so exactly one JSON line comes out; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                c = p.poll()
+                if c is None:
+                    continue
+                pending.remove(p)
+                if c != 0:
+                    rc = rc or c
+                    for q in pending:                   # one rank died: the others would wait for it in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def local_device():
     """GPU index of this rank: LOCAL_RANK (one process per GPU); MCN_BENCH_DEVICE overrides it (rehearsing several ranks on a
     one-GPU box with MCN_DIST_BACKEND=gloo)."""
@@ -499,9 +549,11 @@ def local_device():
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))          # no launcher: this process only starts and reaps the ranks (no GPU call above this line)
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
-    assert world == args.gpus, '--gpus {} but WORLD_SIZE={} (launch with torch.distributed.run for N>1)'.format(args.gpus, world)
+    assert world == args.gpus, '--gpus {} but WORLD_SIZE={}'.format(args.gpus, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     torch.cuda.set_device(local_device())
@@ -536,9 +588,23 @@ def main():
                    .format(args.dtype, args.batch), 'global_batch': args.batch * world, 'parallelism': 'dp{}'.format(world),
                    'ema': not args.no_ema, 'fetch': False},
         'train_flop_per_image': TRAIN_FLOP_PER_IMAGE,
-        'e2e_mfma_frac': round(ips / world * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
+        # MFMA-pipe utilisation of the whole step from the flop the kernels EXECUTE (Winograd layers: 16/36 x tile cover); the direct-convolution
+        # equivalent of the same images/s rides beside it (the two used to be one number)
+        'executed_flop_per_image': int(executed_flop_per_image(args.dtype)),
+        'e2e_mfma_frac': round(ips / world * executed_flop_per_image(args.dtype) / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
+        'direct_equivalent_frac': round(ips / world * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
     }
     if world == 1 and not args.no_roofline:
+        # the reference's own _step also copies loss, Y_all and pred to the host every step (optimizers.py:590-594: a device sync per step);
+        # `value` skips that (config.fetch = false) — this is the same step WITH it, over min(steps, 10) steps
+        nf = max(1, min(args.steps, 10))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(opt, nf, fetch=True)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0
+        out['fetch_true'] = {'value': round(args.batch * nf / dtf, 2), 'unit': 'images/sec', 'ms_per_step': round(dtf / nf * 1e3, 3), 'steps': nf,
+                             'what': 'the same step with the per-step device->host copy of loss / Y_all / pred (optimizers.py:590-594)'}
         table = instrumented_pass(model, args.dtype, layers=args.layers)
         bracket_us = table.pop('_bracket_us')[1] * 1e3
         convs = {k: v for k, v in table.items() if k.startswith('conv_gemm') or k.startswith('conv_wino')}
@@ -584,7 +650,7 @@ def main():
             dt2 = timed(o2, args.steps, args.warmup, 1, args.autotune)
             ips2 = args.batch * args.steps / dt2
             out['bf16'] = {'value': round(ips2, 2), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                           'e2e_mfma_frac': round(ips2 * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS['bf16'] * 1e12), 4)}
+                           'e2e_mfma_frac': round(ips2 * executed_flop_per_image('bf16') / (PEAK_TFLOPS['bf16'] * 1e12), 4)}
             del m2, o2
             torch.cuda.empty_cache()
             # the reference's own half precision: fp16 storage + loss scaling (same kernels, the f16 MFMA instead of the bf16 one)

@@ -15,6 +15,19 @@ import numpy as np
 
 from oracle import net as ON
 
+# What the tests that use flip_aware_step allow per step, and what they have needed so far (rounds 3-4: 0-2).  The search itself may take up
+# to `max_flips` = 6 inversions; a test asserts its own count against THIS budget with the count in the message (a drift
+# from 1-2 to 6 must not pass unnoticed).
+FLIP_BUDGET = 3
+
+
+def assert_flip_budget(flips, where=''):
+    """Every use reports the number of inverted near-tie decisions and fails above FLIP_BUDGET."""
+    n = len(flips)
+    assert n <= FLIP_BUDGET, '{}: {} ReLU near-tie decisions had to be inverted to meet the 1e-3 bar (budget {}; rounds 3-4 needed 0-2): {}'.format(
+        where, n, FLIP_BUDGET, flips)
+    return n
+
 
 def rel_l2(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)

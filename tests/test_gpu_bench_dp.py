@@ -37,6 +37,23 @@ def test_bench_n_ranks_prints_one_json_line(ranks, batch):
     assert 'roofline' not in out and 'cpu_baseline' not in out            # N=1-only objects
 
 
+def test_bench_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (it used to die on an assertion): the parent
+    starts two fresh rank processes before touching the GPU itself, rank 0 prints the one JSON line, the exit code is the ranks'."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MCN_BENCH_DEVICE='0', MCN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dtype', 'bf16', '--batch', '32']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['value'] > 0
+    # a failing rank fails the parent (bad flag -> argparse exits 2 in every rank)
+    r = subprocess.run(cmd + ['--no-such-flag'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'fp16'])
 def test_bench_single_gpu_line_carries_the_roofline_object(dtype):
     """The N=1 contract: one JSON line with metric / value / ms_per_step and a `roofline` object whose bound follows the dominant
@@ -56,3 +73,7 @@ def test_bench_single_gpu_line_carries_the_roofline_object(dtype):
     assert rf['kernel'].startswith('conv_gemm_') and rf['launches_per_step'] > 0 and rf['avg_launch_us'] > 0
     assert 0.0 < rf['frac'] <= 1.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) <= 2e-3
     assert rf['kernel'] in out['roofline_by_kernel'] and out['kernel_ms_total'] > 0
+    # utilisation from EXECUTED flop (Winograd layers in fp32) beside the direct-convolution equivalent; the reference's per-step fetch
+    assert 0.0 < out['e2e_mfma_frac'] <= out['direct_equivalent_frac'] and out['executed_flop_per_image'] <= out['train_flop_per_image']
+    assert (out['executed_flop_per_image'] < out['train_flop_per_image']) == (dtype == 'fp32')
+    assert out['config']['fetch'] is False and out['fetch_true']['value'] > 0.0

@@ -69,7 +69,7 @@ def test_two_rank_step_matches_multi_tower_oracle(kind, world):
     """(world 4: the largest rehearsal the one-GPU box allows beside the test runner — its process guard admits six GPU processes;
     the N = 8 exchange arithmetic is covered on the CPU by tests/test_dist_gloo.py)"""
     from oracle import net as ON
-    from flip_util import flip_aware_step
+    from flip_util import assert_flip_budget, flip_aware_step
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -92,7 +92,7 @@ def test_two_rank_step_matches_multi_tower_oracle(kind, world):
             # fp32 device vs float64 oracle, every gradient tensor within 1e-3 — ReLU decisions at near-ties follow the device (flip_util)
             dev = {k: v / world for k, v in res[0][1][step][2].items()}
             rloss, rpred, _, flips = flip_aware_step(spec, state, towers, dev, hp=hp or None, batch_total=B * world)
-            print('step {}: {} ReLU near-tie decision(s) taken from the device'.format(step, len(flips)))
+            print('step {}: {} ReLU near-tie decision(s) taken from the device'.format(step, assert_flip_budget(flips, 'world {} step {}'.format(world, step))))
         else:
             rloss, rpred, _ = ON.train_step(spec, state, None, None, batch_total=B * world, tower_batches=towers, hp=hp or None)
         for r in range(world):

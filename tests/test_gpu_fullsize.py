@@ -84,6 +84,58 @@ def test_conv_adjoint_identities_at_b256(layer, dtype):
         assert err <= 2e-6, ('linearity', err)
 
 
+SPOT = (0, 127, 255)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('layer', R50_CONVS, ids=lambda l: 'h{}_{}to{}_k{}s{}'.format(*l))
+def test_conv_oracle_spot_parity_at_b256(layer, dtype):
+    """The ORACLE at the bench's own launch sizes (the adjoint identities above cannot see an indexing error common to
+    forward, dgrad and wgrad — shared tile / transform bookkeeping, 32-bit byte offsets, tile rounds beyond one pass of the chip — that only
+    shows at B = 256).  A convolution is independent per image, so images 0, 127 and 255 of the full-size launch are compared with
+    oracle.ops.conv2d_fwd / conv2d_dgrad on those images; the weight gradient of a dy that is zero outside them with conv2d_wgrad on them
+    (every split / slab of the full-size wgrad launch still runs).  Same per-op bars as tests/test_gpu_ops.py."""
+    from myconvnet_amd import _ffi
+    from oracle import ops as O
+    from test_gpu_ops import check
+    u = _u()
+    lib = _ffi.lib
+    h, cin, cout, k, s = layer
+    gen = torch.Generator(device=u.DEV).manual_seed(h * 977 + cin * 3 + cout + k)
+    td = u.TDT[dtype]
+    ce = 4 if dtype == 'float32' else 8
+    cs = cin if cin % ce == 0 else (cin + ce - 1) // ce * ce
+    x = torch.zeros((B, h, h, cs), device=u.DEV, dtype=td)
+    x[..., :cin] = torch.randn((B, h, h, cin), device=u.DEV, generator=gen).to(td)
+    w = (torch.randn((k, k, cin, cout), device=u.DEV, generator=gen) / np.sqrt(k * k * cin)).float()
+    g = u.geom((B, h, h, cin), (k, k, cin, cout), s, 'SAME', x_cs=cs if cs != cin else 0)
+    oh = -(-h // s)
+    ws = u.workspace(max(lib.mcn_conv2d_workspace_bytes(op, ctypes.byref(g), u.MDT[dtype]) for op in (_ffi.CONV_FWD, _ffi.CONV_DGRAD, _ffi.CONV_WGRAD)))
+    st = u.stream()
+    sel = list(SPOT)
+    xs = x[sel][..., :cin].double().cpu().numpy()                          # the stored (already rounded) values of the three images
+    wq = w.to(td).double().cpu().numpy()                                  # the weights as the kernels use them
+    # forward
+    y = torch.full((B, oh, oh, cout), float('nan'), device=u.DEV, dtype=td)
+    _ffi.check(lib.mcn_conv2d_fwd(x.data_ptr(), w.data_ptr(), 0, 0, y.data_ptr(), ctypes.byref(g), u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
+    assert torch.isfinite(y.float()).all()
+    check(y[sel].float().cpu().numpy(), O.conv2d_fwd(xs, wq, s, 'SAME', 1), dtype, 'fwd images {}'.format(SPOT))
+    # data gradient (the stem has none in the network)
+    dy = torch.randn((B, oh, oh, cout), device=u.DEV, generator=gen).to(td)
+    dys = dy[sel].double().cpu().numpy()
+    if cs == cin:
+        dx = torch.full((B, h, h, cin), float('nan'), device=u.DEV, dtype=td)
+        _ffi.check(lib.mcn_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), 0, dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
+        assert torch.isfinite(dx.float()).all()
+        check(dx[sel].float().cpu().numpy(), O.conv2d_dgrad(dys, wq, (3, h, h, cin), s, 'SAME', 1), dtype, 'dgrad images {}'.format(SPOT))
+    # weight gradient: dy zero outside the three images
+    dyz = torch.zeros_like(dy)
+    dyz[sel] = dy[sel]
+    dw = torch.full((k, k, cin, cout), float('nan'), device=u.DEV, dtype=torch.float32)
+    _ffi.check(lib.mcn_conv2d_wgrad(x.data_ptr(), dyz.data_ptr(), dw.data_ptr(), 0, ctypes.byref(g), 1.0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
+    check(dw.cpu().numpy(), O.conv2d_wgrad(xs, dys, (k, k, cin, cout), s, 'SAME', 1), 'float32', 'wgrad images {}'.format(SPOT), rel=2e-5 if dtype == 'float32' else 2e-5)
+
+
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
 def test_batch_norm_at_stem_size(dtype):
     """[256, 112, 112, 64]: 3.2 M rows per channel."""
@@ -312,6 +364,42 @@ def test_depthwise_adjoint_identities_at_b512(layer, dtype):
     per_w = (wq.double() * dw.double()).sum((0, 1))
     cs = torch.sqrt((y.double() ** 2).sum((0, 1, 2)) * (dy.double() ** 2).sum((0, 1, 2)))
     assert float(((per_c - per_w).abs() / cs).max()) <= tol * 4, ('wgrad adjoint per channel', float(((per_c - per_w).abs() / cs).max()))
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('layer', B0_DW, ids=lambda l: 'h{}_c{}_k{}s{}'.format(*l))
+def test_depthwise_oracle_spot_parity_at_b512(layer, dtype):
+    """The oracle on images 0, 255 and 511 of the full-size depthwise launches of configs[3] (see test_conv_oracle_spot_parity_at_b256)."""
+    from myconvnet_amd import _ffi
+    from oracle import ops as O
+    from test_gpu_ops import check
+    u = _u()
+    lib = _ffi.lib
+    h, c, k, s = layer
+    bsz = 512
+    sel = [0, 255, 511]
+    td = u.TDT[dtype]
+    gen = torch.Generator(device=u.DEV).manual_seed(h * 131 + c + k)
+    x = torch.randn((bsz, h, h, c), device=u.DEV, generator=gen).to(td)
+    w = (torch.randn((k, k, c), device=u.DEV, generator=gen) / k).float()
+    g = u.dw_geom((bsz, h, h, c), k, s, 'SAME')
+    oh = -(-h // s)
+    y = torch.full((bsz, oh, oh, c), float('nan'), device=u.DEV, dtype=td)
+    dy = torch.randn((bsz, oh, oh, c), device=u.DEV, generator=gen).to(td)
+    dyz = torch.zeros_like(dy)
+    dyz[sel] = dy[sel]
+    dx = torch.full((bsz, h, h, c), float('nan'), device=u.DEV, dtype=td)
+    dw = torch.full((k, k, c), float('nan'), device=u.DEV, dtype=torch.float32)
+    ws = u.workspace(lib.mcn_dwconv2d_workspace_bytes(ctypes.byref(g), u.MDT[dtype]))
+    st = u.stream()
+    _ffi.check(lib.mcn_dwconv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(g), u.MDT[dtype], st))
+    _ffi.check(lib.mcn_dwconv2d_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], st))
+    _ffi.check(lib.mcn_dwconv2d_wgrad(x.data_ptr(), dyz.data_ptr(), dw.data_ptr(), ctypes.byref(g), 1.0, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, st))
+    xs, dys = x[sel].double().cpu().numpy(), dy[sel].double().cpu().numpy()
+    wq = w.to(td).double().cpu().numpy().reshape(k, k, c, 1)
+    check(y[sel].float().cpu().numpy(), O.depthwise_conv2d_fwd(xs, wq, s, 'SAME', 1), dtype, 'dw fwd images {}'.format(sel))
+    check(dx[sel].float().cpu().numpy(), O.depthwise_conv2d_dgrad(dys, wq, xs.shape, s, 'SAME', 1), dtype, 'dw dgrad images {}'.format(sel))
+    check(dw.cpu().numpy().reshape(k, k, c, 1), O.depthwise_conv2d_wgrad(xs, dys, (k, k, c, 1), s, 'SAME', 1), 'float32', 'dw wgrad images {}'.format(sel), rel=2e-5)
 
 
 # the 1x1 convs that run OFF the MFMA path at their BASELINE sizes: the DeepLabv3+ class-logit conv (configs[4]: 16 x 129 x 129 pixels,
