@@ -261,6 +261,16 @@ int32_t mcn_conv2d_dgrad_bnred_rows(const mcn_conv_geom* geom, mcn_dtype dtype);
 int mcn_conv2d_dgrad_bnred(const void* dy, const float* w_hwio, const void* w_packed, void* dx, const void* bn_x, const uint8_t* relu_mask,
                            float* red_partials, const mcn_conv_geom* geom, mcn_dtype dtype, mcn_layout layout, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* mcn_conv2d_dgrad_addmasked and mcn_conv2d_dgrad_bnred in ONE launch (round 4): dx = dgrad(dy) + add_src * [add_mask bit] is the complete
+ * gradient of a residual unit's output y_b = relu(bn(x_b) + skip_b) (models/resnet_v1_5.py:176-183: its readers are the next unit's conv_0 —
+ * this launch — and the next unit's residual add), so the backward sums of that unit's output BN (convnet.py:1883; tf.gradients of
+ * fused_batch_norm) ride in the epilogue: red_partials [rows][2][Cin] as in mcn_conv2d_dgrad_bnred with bn_x = x_b and relu_mask = the
+ * [y_b > 0] byte mask, and mcn_bn_bwd_from_partials runs that BN's backward without its reduction pass over (dy, x_b).  Eligible when
+ * mcn_conv2d_dgrad_addmasked_ok() != 0 and mcn_conv2d_dgrad_bnred_rows() > 0 (= rows). */
+int mcn_conv2d_dgrad_addmasked_bnred(const void* dy, const float* w, const void* w_packed, void* dx, const void* add_src,
+                                     const uint8_t* add_mask, const void* bn_x, const uint8_t* relu_mask, float* red_partials,
+                                     const mcn_conv_geom* g, mcn_dtype dtype, mcn_layout layout, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 int mcn_bn_bwd_from_partials(const void* dy, const void* x, const uint8_t* relu_mask, const float* gamma, const float* beta,
                              const float* save_mean, const float* save_invstd, const float* red_partials, int32_t nparts, void* dx,
                              float* dgamma, float* dbeta, float grad_scale, int64_t M, int32_t C, mcn_dtype dtype, void* workspace,

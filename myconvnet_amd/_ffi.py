@@ -70,6 +70,7 @@ SIGNATURES = {
     'mcn_bn_fwd_train_fused_affskip': (c_int, [c_void_p, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_float, c_int64, c_int32, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_dgrad_bnred_rows': (c_int32, [ctypes.POINTER(ConvGeom), c_int]),
     'mcn_conv2d_dgrad_bnred': (c_int, [c_void_p] * 7 + [ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_conv2d_dgrad_addmasked_bnred': (c_int, [c_void_p] * 9 + [ctypes.POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_bn_bwd_from_partials': (c_int, [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_channel_scale_bwd_dm': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_bn_bwd_se': (c_int, [c_void_p] * 11 + [c_float, c_int32, c_int64, c_int32, c_int, c_void_p, c_size_t, c_void_p]),

@@ -419,6 +419,13 @@ static bool nt_window_geom(const Geo& g, size_t es, int cpt, const NtTile& t) {
     return nt_window_lds((g.KH - 1) * g.DH * g.W + (g.KW - 1) * g.DW, t) != 0;
 }
 
+// epilogue variant of a launch: the accumulate modes have their own instantiation (batched loads), so do the BN statistics, the BN-backward
+// sums, and the masked residual fan-in TOGETHER with the BN-backward sums (NT_EPI_ACCRED: mcn_conv2d_dgrad_addmasked_bnred)
+static inline int nt_epi_of(const GemmNTParams& p) {
+    if (p.stats) return NT_EPI_STATS;
+    if (p.accumulate) return (p.accumulate == 2 && p.red_part) ? NT_EPI_ACCRED : NT_EPI_ACC;
+    return p.red_part ? NT_EPI_BNRED : NT_EPI_STORE;
+}
 template <typename T>
 static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mode, bool reduce, hipStream_t st) {
     const NtTile t = kNtCand[tile];
@@ -439,6 +446,7 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
         if (epi == NT_EPI_STATS) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_STATS);  \
         else if (epi == NT_EPI_ACC) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_ACC); \
         else if (epi == NT_EPI_BNRED) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_BNRED); \
+        else if (epi == NT_EPI_ACCRED) MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_ACCRED); \
         else MCN_LAUNCH_NT_S(BMV, BNV, NWV, MODEV, NT_EPI_STORE);                      \
     } while (0)
 #define MCN_LAUNCH_NT_MODE(BMV, BNV, NWV)                                                 \
@@ -447,13 +455,14 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
             if (epi == NT_EPI_STATS) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STATS>), grid, block, 0, st, p);    \
             else if (epi == NT_EPI_ACC) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_ACC>), grid, block, 0, st, p);   \
             else if (epi == NT_EPI_BNRED) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_BNRED>), grid, block, 0, st, p); \
+            else if (epi == NT_EPI_ACCRED) hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_ACCRED>), grid, block, 0, st, p); \
             else hipLaunchKernelGGL((conv_nt_sk_reduce<T, BMV, BNV, NWV, NT_EPI_STORE>), grid, block, 0, st, p);                        \
         } else if (mode_nt == NT_LINEAR) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_LINEAR);         \
         else if (mode_nt == NT_UNIFORM) MCN_LAUNCH_NT(BMV, BNV, NWV, NT_UNIFORM);         \
         else MCN_LAUNCH_NT(BMV, BNV, NWV, NT_GENERIC);                                    \
     } while (0)
     // epilogue variant: the accumulate modes have their own instantiation (batched loads), so do the BN statistics
-    const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : (p.red_part ? NT_EPI_BNRED : NT_EPI_STORE));
+    const int epi = nt_epi_of(p);
     if (mode == NT_WINDOW && !reduce) {
         const int wlds = nt_window_lds(p.win_rows - t.bm, t);
 #define MCN_LAUNCH_WIN_E(BMV, BNV, EPIV)                                                                  \
@@ -467,6 +476,7 @@ static int launch_nt_tiles(const GemmNTParams& p, int tile, int nblocks, int mod
         if (epi == NT_EPI_STATS) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_STATS);                                \
         else if (epi == NT_EPI_ACC) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_ACC);                               \
         else if (epi == NT_EPI_BNRED) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_BNRED);                           \
+        else if (epi == NT_EPI_ACCRED) MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_ACCRED);                         \
         else MCN_LAUNCH_WIN_E(BMV, BNV, NT_EPI_STORE);                                                    \
     } while (0)
         if (t.bm == 128 && t.bn == 128) MCN_LAUNCH_WIN(128, 128);
@@ -609,11 +619,11 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
     if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) {
-        const int epi = p.stats ? NT_EPI_STATS : (p.accumulate ? NT_EPI_ACC : (p.red_part ? NT_EPI_BNRED : NT_EPI_STORE));
+        const int epi = nt_epi_of(p);
         // (counted statistics rows are a property of the geometry — mcn_conv2d_bnstats_rows() promised them to the BN side — so
         // that launch is persistent with or without a bias)
         if (p.stats && nt_stats_counted<T>(mode, p.M, p.Nn, p.nchunks, tile, tile_hint, nullptr)) return launch_nt_pers<T>(p, tile, W, st, NT_EPI_STATSC);
-        if (mode == NT_LINEAR && !p.bias && epi != NT_EPI_BNRED && nt_pers_tile(t, sizeof(T), epi)) return launch_nt_pers<T>(p, tile, W, st, epi);
+        if (mode == NT_LINEAR && !p.bias && epi != NT_EPI_BNRED && epi != NT_EPI_ACCRED && nt_pers_tile(t, sizeof(T), epi)) return launch_nt_pers<T>(p, tile, W, st, epi);
         return launch_nt_tiles<T>(p, tile, (int)W, mode, false, st);
     }
     p.sk_mode = 1;
@@ -1152,6 +1162,27 @@ extern "C" int mcn_conv2d_dgrad_bnred(const void* dy, const float* w, const void
     if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, nullptr, nullptr, bn_x, relu_mask, red_partials);
     if (dtype == MCN_F16) return conv_dgrad_t<f16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, nullptr, nullptr, bn_x, relu_mask, red_partials);
     return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, nullptr, nullptr, bn_x, relu_mask, red_partials);
+}
+
+// Both at once (round 4): dx = dgrad(dy) + add_src * [add_mask bit] is the COMPLETE gradient of a residual unit's output y_b = relu(bn(x_b) + skip)
+// (its two readers are this conv and the next unit's residual add), so the backward sums of that unit's output BN ride in the same
+// epilogue: red_partials [rows][2][Cin] = sum dy', sum dy' * bn_x over the pixel rows of a wave row, dy' = the stored dx where relu_mask
+// (the BN's own [y_b > 0] bytes) is set.  mcn_bn_bwd_from_partials then runs the BN backward without a reduction pass.  Eligible when both
+// mcn_conv2d_dgrad_addmasked_ok() and mcn_conv2d_dgrad_bnred_rows() say so (rows = mcn_conv2d_dgrad_bnred_rows()).
+extern "C" int mcn_conv2d_dgrad_addmasked_bnred(const void* dy, const float* w, const void* w_packed, void* dx, const void* add_src, const uint8_t* add_mask,
+                                                const void* bn_x, const uint8_t* relu_mask, float* red_partials, const mcn_conv_geom* gg, mcn_dtype dtype,
+                                                mcn_layout layout, void* ws, size_t ws_bytes, void* stream) {
+    Geo g;
+    int rc = geo_from(gg, &g);
+    if (rc) return rc;
+    if (layout != MCN_NHWC) MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_addmasked_bnred: only NHWC activations");
+    if (!dy || !w || !dx || !add_src || !add_mask || !bn_x || !relu_mask || !red_partials) MCN_FAIL(MCN_E_BADARG, "conv2d_dgrad_addmasked_bnred: null pointer");
+    if (!mcn_conv2d_dgrad_addmasked_ok(gg, dtype) || mcn_conv2d_dgrad_bnred_rows(gg, dtype) <= 0)
+        MCN_FAIL(MCN_E_UNSUPPORTED, "conv2d_dgrad_addmasked_bnred: geometry not eligible (mcn_conv2d_dgrad_addmasked_ok / mcn_conv2d_dgrad_bnred_rows)");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return conv_dgrad_t<float>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask, bn_x, relu_mask, red_partials);
+    if (dtype == MCN_F16) return conv_dgrad_t<f16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask, bn_x, relu_mask, red_partials);
+    return conv_dgrad_t<bf16_t>(dy, w, w_packed, dx, g, 0, dtype, ws, ws_bytes, st, add_src, add_mask, bn_x, relu_mask, red_partials);
 }
 
 // ---- wgrad -----------------------------------------------------------------------------------------------

@@ -256,7 +256,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // offset carries "row past the end" / "column past Nn" in bit 31 (out of range => the store is dropped, the load returns
 // 0), the bias is folded into the accumulators under ONE uniform branch, the statistics run on packed fp32 pairs
 // (v_pk_add_f32 / v_pk_fma_f32), and the pixel of a row is its GEMM row unless the launch scatters a sub-grid (strided dgrad).
-enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2, NT_EPI_STATSC = 3, NT_EPI_BNRED = 4 };
+enum { NT_EPI_STORE = 0, NT_EPI_STATS = 1, NT_EPI_ACC = 2, NT_EPI_STATSC = 3, NT_EPI_BNRED = 4, NT_EPI_ACCRED = 5 };
+// NT_EPI_ACCRED (round 4) = NT_EPI_ACC (p.accumulate == 2: the masked gradient of the NEXT residual unit's output is added) AND NT_EPI_BNRED
+// in one epilogue: the launch writes the COMPLETE gradient of a residual unit's output y_b = relu(bn(x_b) + skip_b), so the backward sums of
+// that unit's own output BN (sum dy', sum dy' * x_b with dy' = the stored gradient where y_b > 0) ride along and its reduction pass over
+// (dy, x_b) disappears — two tensors in the output's layout are loaded: add_src / add_mask and red_x / red_mask.
 // NT_EPI_STATSC (conv_gemm_nt_pers only): the per-lane statistics sums are CARRIED across the tiles a persistent workgroup walks
 // (all its tiles share the channel block) and folded / written once per workgroup as a "counted" partial row
 // [s1][s2][pivot][count] — one lane fold and one row per workgroup and wave row instead of one per tile.
@@ -317,8 +321,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     typedef MmaNT<T> MM;
     typedef Quad<T> Q;
     constexpr bool CARRY = EPI == NT_EPI_STATSC;
-    constexpr bool STATS = EPI == NT_EPI_STATS || CARRY, ACC = EPI == NT_EPI_ACC;
-    constexpr bool BNRED = EPI == NT_EPI_BNRED;
+    constexpr bool BOTH = EPI == NT_EPI_ACCRED;                  // masked residual add AND BN-backward sums: two loaded tensors
+    constexpr bool STATS = EPI == NT_EPI_STATS || CARRY, ACC = EPI == NT_EPI_ACC || BOTH;
+    constexpr bool BNRED = EPI == NT_EPI_BNRED || BOTH;
     constexpr bool LD = ACC || BNRED;                          // the epilogue loads a tensor in the output's layout (+ a byte mask)
     constexpr int WROWS = NW / 2;
     constexpr int WTM = BM / WROWS, WTN = BN / 2;
@@ -373,13 +378,14 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     // kernel hipcc waits vmcnt(0) at the first use of every ordinary load, which also drains the stores in front of it) ----
     typename Q::Bits prev[LD ? TM : 1][LD ? TN : 1][LD ? NG : 1];
     unsigned char mbits[LD ? TM : 1][LD ? TN : 1][LD ? NG : 1];
+    typename Q::Bits prev2[BOTH ? TM : 1][BOTH ? TN : 1][BOTH ? NG : 1];   // NT_EPI_ACCRED: the BN's input x and its ReLU bits
+    unsigned char mbits2[BOTH ? TM : 1][BOTH ? TN : 1][BOTH ? NG : 1];
     if constexpr (LD) {
         constexpr int CEL = 16 / ES;                                    // elements per mask byte
         constexpr int MB = WTN / CEL;                                   // mask bytes per pixel for this wave's WTN channels: 4, 8 or 16
         static_assert(MB % 4 == 0, "mask bytes per wave row");
-        const bool masked = BNRED || p.accumulate == 2;
-        const void* const lsrc = BNRED ? p.red_x : (masked ? p.add_src : (const void*)p.out);
-        const unsigned char* const lmask = BNRED ? p.red_mask : p.add_mask;
+        // one tensor in the output's layout + its byte mask -> (pv, mbv)
+        auto load_src = [&](const void* const lsrc, const unsigned char* const lmask, const bool masked, auto& pv, auto& mbv) {
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(lsrc), 0, (int)p.out_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(lmask), 0, masked ? (int)(p.out_bytes >> 4) : 0, 0x00020000);
         // one wide mask load per row block (instead of a byte per accumulator) when the wave's channel range is whole
@@ -408,8 +414,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
                     const i32x4 w = buf_load16_epi(rsS, sat_add(srow, coloff[j][0] - pairshift));
                     const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)w[0], (unsigned)w[2], false, false);
                     const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)w[1], (unsigned)w[3], false, false);
-                    prev[2 * q][j][0] = u32x2{lo[0], hi[0]};
-                    prev[2 * q + 1][j][0] = u32x2{lo[1], hi[1]};
+                    pv[2 * q][j][0] = u32x2{lo[0], hi[0]};
+                    pv[2 * q + 1][j][0] = u32x2{lo[1], hi[1]};
                 }
             }
         } else {
@@ -418,7 +424,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) prev[i][j][g] = __builtin_bit_cast(typename Q::Bits, buf_load16_epi(rsS, sat_add(rowoff[i], coloff[j][g])));
+                    for (int g = 0; g < NG; ++g) pv[i][j][g] = __builtin_bit_cast(typename Q::Bits, buf_load16_epi(rsS, sat_add(rowoff[i], coloff[j][g])));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -427,19 +433,27 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (!masked) {
-                        mbits[i][j][g] = 0xff;
+                        mbv[i][j][g] = 0xff;
                     } else if (wide) {
                         const int nl = (MM::MT == 16) ? (4 * (lane >> 4)) : (8 * g + 4 * (lane >> 5));
                         const int idx = (j * MM::MT + nl) / CEL;           // byte of this accumulator within the wave row's MB bytes
                         unsigned dw = mw[i][0];
 #pragma unroll
                         for (int k = 1; k < MB / 4; ++k) dw = (idx >> 2) == k ? mw[i][k] : dw;
-                        mbits[i][j][g] = (unsigned char)(dw >> ((idx & 3) * 8));
+                        mbv[i][j][g] = (unsigned char)(dw >> ((idx & 3) * 8));
                     } else {
                         const unsigned bo = sat_add(rowoff[i], coloff[j][g]);
-                        mbits[i][j][g] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsM, (int)(((bo & 0x7fffffffu) >> 4) | (bo & 0x80000000u)), 0, 0);
+                        mbv[i][j][g] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsM, (int)(((bo & 0x7fffffffu) >> 4) | (bo & 0x80000000u)), 0, 0);
                     }
                 }
+        };
+        if constexpr (BOTH) {
+            load_src(p.add_src, p.add_mask, true, prev, mbits);
+            load_src(p.red_x, p.red_mask, true, prev2, mbits2);
+        } else {
+            const bool masked = BNRED || p.accumulate == 2;
+            load_src(BNRED ? p.red_x : (masked ? p.add_src : (const void*)p.out), BNRED ? p.red_mask : p.add_mask, masked, prev, mbits);
+        }
     }
 
     // ---- BN statistics of the STORED (rounded) values: per-lane sums of (y - pivot) and of its square over the wave's row
@@ -502,8 +516,10 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
             // mask = 0 (out-of-range buffer offsets), so they add nothing
             float r[4], xv[4];
             Q::unpack(o, r);
-            Q::unpack(prev[i][j][g], xv);
-            const unsigned mb = ES == 4 ? (unsigned)mbits[i][j][g] : ((unsigned)mbits[i][j][g] >> (col(j, g) & 4));
+            unsigned char mraw;
+            if constexpr (BOTH) { Q::unpack(prev2[i][j][g], xv); mraw = mbits2[i][j][g]; }
+            else { Q::unpack(prev[i][j][g], xv); mraw = mbits[i][j][g]; }
+            const unsigned mb = ES == 4 ? (unsigned)mraw : ((unsigned)mraw >> (col(j, g) & 4));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x2 d = f32x2{(mb >> (2 * h)) & 1u ? r[2 * h] : 0.f, (mb >> (2 * h + 1)) & 1u ? r[2 * h + 1] : 0.f};

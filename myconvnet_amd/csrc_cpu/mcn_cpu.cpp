@@ -131,6 +131,8 @@ extern "C" int mcn_conv2d_fwd_bnstats(const void*, const float*, const void*, co
 extern "C" int32_t mcn_conv2d_dgrad_bnred_rows(const mcn_conv_geom*, mcn_dtype) { return 0; }
 extern "C" int mcn_conv2d_dgrad_bnred(const void*, const float*, const void*, void*, const void*, const uint8_t*, float*, const mcn_conv_geom*, mcn_dtype, mcn_layout, void*, size_t,
                                       void*) { UNSUPPORTED("conv2d_dgrad_bnred"); }
+extern "C" int mcn_conv2d_dgrad_addmasked_bnred(const void*, const float*, const void*, void*, const void*, const uint8_t*, const void*, const uint8_t*, float*, const mcn_conv_geom*,
+                                                mcn_dtype, mcn_layout, void*, size_t, void*) { UNSUPPORTED("conv2d_dgrad_addmasked_bnred"); }
 
 // per-use cast of the fp32 master (convnet.py:1421-1422): the weights as the storage type sees them, kept in fp32
 template <typename S>

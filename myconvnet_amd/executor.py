@@ -50,6 +50,10 @@ class Lowering(object):
         # 22.55 ms bf16).  Re-measured on the round's final tree (streaming BN loads, XCD-aware wgrad order): fp32 68.42-68.46 vs 68.97-69.28 ms,
         # bf16 21.41-21.48 vs 21.32-21.35 ms.  On for fp32, off for the 2-byte types.
         self.fuse_bn_bwd_red = bool(model._parameters.get('fuse_bn_bwd_red', _env_flag('MCN_FUSE_BN_BWD_RED', graph.dtype == 'float32')))
+        # ... and of a residual unit's OUTPUT BN in the epilogue of the launch that completes its gradient (round 4: the next unit's first dgrad with
+        # the masked fan-in, mcn_conv2d_dgrad_addmasked_bnred): 12 of ResNet-50's 16 unit-output BNs (36 % of all BN elements) lose their
+        # reduction pass over (dy, x).  MCN_FUSE_BN_OUT_RED=0 / fuse_bn_out_red=False: off.
+        self.fuse_bn_out_red = bool(model._parameters.get('fuse_bn_out_red', _env_flag('MCN_FUSE_BN_OUT_RED', True)))
         self.scratch = {}
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -328,6 +332,27 @@ class Lowering(object):
             return None
         return c
 
+    def _out_red_bn(self, conv, x):
+        """`conv` is about to write the complete gradient of x with mcn_conv2d_dgrad_addmasked (x's readers: this conv and the next residual
+        add).  If x is itself the output of a training-mode BN + residual + ReLU whose own skip gradient will be deferred (so that its backward
+        writes nothing but dx), return that BN: its backward sums can ride in this launch's epilogue (mcn_conv2d_dgrad_addmasked_bnred).
+        fuse_bn_out_red / MCN_FUSE_BN_OUT_RED=0 switch it off."""
+        bn = x.producer
+        if not (self.train and self.fuse_bn_out_red and bn is not None and bn.op == 'bn' and bn in self.g.nodes and bn.outputs[0] is x):
+            return None
+        a = bn.attrs
+        skip = a.get('skip')
+        if not (a['update'] and a.get('act', 0) == _ffi.ACT_RELU and skip is not None and 'relu_mask' in a and bn.inputs[0].needs_grad
+                and bn.inputs[0].shape[-1] % (4 if self.g.dtype == 'float32' else 8) == 0):
+            return None
+        if x.id in self.pool_routes or x.id in self.se_routes:
+            return None
+        if skip.needs_grad and not self._can_defer_dskip(bn, skip):
+            return None                                     # its backward would have to materialise dskip: keep the two-pass form
+        if int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(self.op_geom(conv, _ffi.CONV_DGRAD)), self.dt)) <= 0:
+            return None
+        return bn
+
     def fwd_conv(self, n):
         x, y = n.inputs[0], n.outputs[0]
         gm = self.op_geom(n, _ffi.CONV_FWD)
@@ -384,8 +409,20 @@ class Lowering(object):
             # identity shortcut: dx = dgrad + [y_block > 0] * dy_block in the epilogue (first and only writer of x.grad so far)
             assert x.needs_grad and x.id not in self.written
             self.written.add(x.id)
-            self.bwd.add(lib.mcn_conv2d_dgrad_addmasked, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), lazy[0], lazy[1],
-                         ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
+            red = self._out_red_bn(n, x)
+            if red is not None:
+                # x = y_b = relu(bn(u_b) + skip_b) and this launch writes its COMPLETE gradient (this dgrad + the next unit's masked fan-in): the
+                # backward sums of that unit's output BN ride in the same epilogue (bwd_bn then runs mcn_bn_bwd_from_partials: no reduction pass)
+                pa = red.attrs
+                rows = int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(gm), self.dt))
+                pa['bwd_red'] = (torch.zeros((rows, 2, x.shape[-1]), dtype=torch.float32, device=self.g.device), gm, n)
+                self.bwd.add(lib.mcn_conv2d_dgrad_addmasked_bnred, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), lazy[0], lazy[1],
+                             red.inputs[0].buf.data_ptr(), pa['relu_mask'].data_ptr(), pa['bwd_red'][0].data_ptr(), ctypes.byref(gm), self.dt, _ffi.NHWC,
+                             self.ws_ptr, self.ws_bytes)
+                pa['bwd_red_done'] = True
+            else:
+                self.bwd.add(lib.mcn_conv2d_dgrad_addmasked, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), lazy[0], lazy[1],
+                             ctypes.byref(gm), self.dt, _ffi.NHWC, self.ws_ptr, self.ws_bytes)
         elif x.needs_grad and x.producer is not None and x.producer.op == 'bn' and x.producer.attrs.get('bwd_red', (None, None, None))[2] is n:
             # x = relu(bn(u)), read by this conv only: the epilogue also leaves the BN backward's sums (bwd_bn then runs its apply pass only)
             pa = x.producer.attrs
@@ -583,26 +620,31 @@ class Lowering(object):
             self.fwd.add(lib.mcn_bn_fwd_infer, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), mp, sp,
                          ptr(skip.buf) if skip else 0, y.buf.data_ptr(), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype])
 
-    def _defer_dskip(self, n, skip, y):
-        """Residual BN (y = relu(bn(x) + skip)) with a ReLU byte mask: instead of materialising dskip = [y > 0] * dy, let
-        the skip branch's only other gradient consumer apply it — the dgrad of the block's first conv (identity shortcut:
-        mcn_conv2d_dgrad_addmasked) or the projection shortcut's BN backward.  Returns True when deferred."""
+    def _can_defer_dskip(self, n, skip):
+        """Could _defer_dskip hand this residual BN's skip gradient to the skip branch's other consumer?  1 = projection shortcut's BN backward,
+        2 = the dgrad of the block's first conv, 0 = no.  No side effects (also asked ahead of time by _out_red_bn)."""
         a = n.attrs
         if 'relu_mask' not in a or not self.defer_dskip or skip.id in self.written or skip.id in self.lazy_grad:
-            return False
-        lazy = (y.grad.data_ptr(), a['relu_mask'].data_ptr())
+            return 0
         others = [c for c in skip.consumers if c is not n]
         prod = skip.producer
         if not others and prod is not None and prod.op == 'bn' and prod.attrs.get('update') and not prod.attrs.get('act', 0) \
                 and prod.attrs.get('skip') is None and self.train:
-            self.lazy_grad[skip.id] = lazy                                  # projection shortcut: conv_skip -> bn -> (add)
-            return True
+            return 1                                                        # projection shortcut: conv_skip -> bn -> (add)
         if len(others) == 1 and others[0].op == 'conv' and others[0].inputs[0] is skip and others[0] in self.g.nodes \
                 and self.g.nodes.index(others[0]) < self.g.nodes.index(n) \
                 and lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(self.op_geom(others[0], _ffi.CONV_DGRAD)), self.dt):
-            self.lazy_grad[skip.id] = lazy                                  # identity shortcut: the block's conv_0 reads it
-            return True
-        return False
+            return 2                                                        # identity shortcut: the block's conv_0 reads it
+        return 0
+
+    def _defer_dskip(self, n, skip, y):
+        """Residual BN (y = relu(bn(x) + skip)) with a ReLU byte mask: instead of materialising dskip = [y > 0] * dy, let
+        the skip branch's only other gradient consumer apply it — the dgrad of the block's first conv (identity shortcut:
+        mcn_conv2d_dgrad_addmasked) or the projection shortcut's BN backward.  Returns True when deferred."""
+        if not self._can_defer_dskip(n, skip):
+            return False
+        self.lazy_grad[skip.id] = (y.grad.data_ptr(), n.attrs['relu_mask'].data_ptr())
+        return True
 
     def bwd_bn(self, n):
         x, y = n.inputs[0], n.outputs[0]
@@ -665,7 +707,9 @@ class Lowering(object):
                              b.grad.data_ptr() if b is not None and b.trainable else 0, gs, *(self._pool_args(route) + [MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes]))
                 return
             if a.get('bwd_red_done'):
-                assert act == _ffi.ACT_RELU and skip is None and lazy is None and mptr
+                # (internal BN + ReLU read by one conv: mcn_conv2d_dgrad_bnred; or a residual unit's output BN whose complete gradient came out of
+                # mcn_conv2d_dgrad_addmasked_bnred — its own skip gradient is deferred or not needed, so only dx is written)
+                assert act == _ffi.ACT_RELU and lazy is None and mptr and not dskip_ptr and post is None
                 part, gd = a['bwd_red'][0], a['bwd_red'][1]
                 self.bwd.add(lib.mcn_bn_bwd_from_partials, dy_ptr, x.buf.data_ptr(), mptr, self.vptr(g), self.vptr(b), st['mean'].data_ptr(), st['invstd'].data_ptr(),
                              part.data_ptr(), int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(gd), self.dt)), dst,

@@ -259,11 +259,16 @@ def test_resnet_bn_backward_sums_from_dgrad_epilogue(dtype):
     res = {}
     x = np.random.default_rng(67).random((BATCH, 64, 64, 3)).astype(np.float32)
     for on in (True, False):
-        model, spec, params, stats = make_resnet(50, dtype, True, fuse_bn_bwd_red=on)
+        model, spec, params, stats = make_resnet(50, dtype, True, fuse_bn_bwd_red=on, fuse_bn_out_red=on)
         names = [getattr(fn, '__name__', '') for fn, _ in model._train_low.bwd.calls]
         assert ('mcn_conv2d_dgrad_bnred' in names) == on and ('mcn_bn_bwd_from_partials' in names) == on
+        assert ('mcn_conv2d_dgrad_addmasked_bnred' in names) == on
         if on:
-            assert names.count('mcn_conv2d_dgrad_bnred') == names.count('mcn_bn_bwd_from_partials') == 32      # 16 bottlenecks x (BN0, BN1)
+            assert names.count('mcn_conv2d_dgrad_bnred') == 32                                                  # 16 bottlenecks x (BN0, BN1)
+            # round 4: the unit-output BNs whose gradient is completed by the next unit's conv_0 dgrad + masked fan-in: 16 units - the last of
+            # each of the four stages (their readers are two convs / the global mean)
+            assert names.count('mcn_conv2d_dgrad_addmasked_bnred') == 12 and 'mcn_conv2d_dgrad_addmasked' not in names
+            assert names.count('mcn_bn_bwd_from_partials') == 32 + 12
         opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
         model.feed(x, LABELS)
         loss, _, _ = opt._step(None)

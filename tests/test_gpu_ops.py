@@ -803,6 +803,72 @@ def test_conv_dgrad_with_masked_residual_add(case, dtype):
     assert lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(g2), u.MDT[dtype]) == 0      # strided: not eligible
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(4, 14, 14, 64, 32, 1), (3, 9, 11, 72, 136, 3), (2, 28, 28, 256, 64, 1), (8, 16, 16, 8, 8, 1), (40, 28, 28, 512, 128, 1)])
+def test_conv_dgrad_masked_residual_add_with_bn_backward_sums(case, dtype):
+    """mcn_conv2d_dgrad_addmasked_bnred (round 4): ONE launch gives dx = dgrad(dy) + add_src * [add_mask bit] — bit for bit
+    mcn_conv2d_dgrad_addmasked — AND the partial rows of the BN-backward sums over that dx (dy' = dx where the unit's OWN ReLU bit is set,
+    x = the input of the unit's output BN): column sums against NumPy, then mcn_bn_bwd_from_partials against mcn_bn_bwd."""
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, cin, cout, k = case
+    md = u.MDT[dtype]
+    wgt = (RNG.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    dy = RNG.standard_normal((n, h, w_, cout)).astype(np.float32)
+    dyn = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)            # gradient of the NEXT unit's output ...
+    ynext = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)          # ... and its sign pattern (add_mask)
+    vec = 4 if dtype == 'float32' else 8
+    nbits = (ynext.reshape(-1, vec) > 0).astype(np.uint32)
+    add_mask = (nbits << np.arange(vec, dtype=np.uint32)).sum(-1).astype(np.uint8)
+    # this unit's output BN: y_b = relu(bn(xbn) + skip), its byte mask from the forward kernel itself
+    xbn = (1.2 * RNG.standard_normal((n, h, w_, cin)) + 0.2).astype(np.float32)
+    skip = RNG.standard_normal((n, h, w_, cin)).astype(np.float32)
+    gamma = (0.5 + RNG.random(cin)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(cin)).astype(np.float32)
+    fw = u.bn_fwd_train(xbn, gamma, beta, 1e-3, dtype, skip=skip, act=1, want_mask=True)
+    g = u.geom((n, h, w_, cin), wgt.shape, 1, 'SAME')
+    assert lib.mcn_conv2d_dgrad_addmasked_ok(ctypes.byref(g), md) == 1
+    rows = lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(g), md)
+    assert rows > 0
+    dyd, wd, src, amd = u.dev(dy, dtype), u.dev(wgt), u.dev(dyn, dtype), torch.as_tensor(add_mask).to(u.DEV)
+    xd, mk = u.dev(xbn, dtype), torch.as_tensor(fw['relu_mask']).to(u.DEV)
+    ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), md))
+    ref = torch.full((n, h, w_, cin), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_conv2d_dgrad_addmasked(dyd.data_ptr(), wd.data_ptr(), 0, ref.data_ptr(), src.data_ptr(), amd.data_ptr(), ctypes.byref(g), md, _ffi.NHWC,
+                                              ws.data_ptr(), ws.numel() * 4, u.stream()))
+    dx = torch.full((n, h, w_, cin), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    part = torch.full((rows, 2, cin), float('nan'), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_conv2d_dgrad_addmasked_bnred(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), src.data_ptr(), amd.data_ptr(), xd.data_ptr(), mk.data_ptr(),
+                                                    part.data_ptr(), ctypes.byref(g), md, _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    dx_ref = u.host(ref)
+    np.testing.assert_array_equal(u.host(dx), dx_ref)
+    p = u.host(part).astype(np.float64)
+    assert not np.isnan(p).any()
+    bits = (fw['y'].reshape(-1, cin) > 0).astype(np.float64)
+    dxm = dx_ref.reshape(-1, cin).astype(np.float64) * bits
+    xq = q(xbn, dtype).reshape(-1, cin)
+    np.testing.assert_allclose(p[:, 0].sum(0), dxm.sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm).sum(0).max())
+    np.testing.assert_allclose(p[:, 1].sum(0), (dxm * xq).sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm * xq).sum(0).max())
+    m = n * h * w_
+    gd, bd, sm, si = u.dev(gamma), u.dev(beta), u.dev(fw['save_mean']), u.dev(fw['save_invstd'])
+    bws = u.workspace(lib.mcn_bn_workspace_bytes(m, cin))
+
+    def run(fn):
+        o = torch.full(xbn.shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+        dg, db = torch.zeros(cin, device=u.DEV), torch.zeros(cin, device=u.DEV)
+        fn(o, dg, db)
+        return u.host(o), u.host(dg), u.host(db)
+    a = run(lambda o, dg, db: _ffi.check(lib.mcn_bn_bwd(dx.data_ptr(), xd.data_ptr(), 0, mk.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), o.data_ptr(), 0,
+                                                        dg.data_ptr(), db.data_ptr(), 0.5, m, cin, 1, md, bws.data_ptr(), bws.numel() * 4, u.stream())))
+    b = run(lambda o, dg, db: _ffi.check(lib.mcn_bn_bwd_from_partials(dx.data_ptr(), xd.data_ptr(), mk.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                                                                      part.data_ptr(), rows, o.data_ptr(), dg.data_ptr(), db.data_ptr(), 0.5, m, cin, md,
+                                                                      bws.data_ptr(), bws.numel() * 4, u.stream())))
+    check(b[0], a[0], dtype, 'dx from partials', rel=2e-5 if dtype == 'float32' else 4e-3)
+    check(b[1], a[1], 'float32', 'dgamma', rel=1e-4)
+    check(b[2], a[2], 'float32', 'dbeta', rel=1e-4)
+
+
 @pytest.mark.parametrize('dtype', ['bfloat16', 'float16'])
 @pytest.mark.parametrize('case', [(2, 32, 32, 3, 64, 7, 'SAME'),      # the ResNet stem: TF SAME pads (2,3), even left pad
                                   (3, 18, 20, 3, 32, 3, 'SAME'),      # the EfficientNet stem: pads (0,1)
