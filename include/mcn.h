@@ -181,6 +181,14 @@ int mcn_bn_fwd_train(const void* x, const float* gamma, const float* beta, const
                      uint8_t* relu_mask, float* save_mean, float* save_invstd, float* batch_mean, float* batch_var,
                      float* running_mean, float* running_var, float momentum, int64_t M, int32_t C, float eps,
                      mcn_act act, mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* mcn_bn_fwd_train (no residual, no ReLU mask) whose apply pass ALSO leaves the per-image channel means of the stored output
+ * (round 4): y [N][HW][C] = act(bn(x)), gap [N][C] = mean over HW of y as stored — the squeeze-excite block's
+ * tf.reduce_mean(x, axis=[1, 2]) right behind the depthwise conv's BN + swish (models/efficientnet.py:150-152, 183), which was a
+ * second full read of y (mcn_global_avgpool_fwd).  Sums in fp32, one rounding to the storage type. */
+int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const float* beta, void* y, void* gap, float* save_mean,
+                         float* save_invstd, float* batch_mean, float* batch_var, float* running_mean, float* running_var,
+                         float momentum, int32_t N, int32_t HW, int32_t C, float eps, mcn_act act, mcn_dtype dtype,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* conv -> batch-norm fusion: the forward conv accumulates, in its epilogue, the column sums and sums of squares of the
  * values it stores and writes them as mcn_conv2d_bnstats_rows() partial rows — [rows][3][Cout] fp32: sum(y-p),

@@ -61,6 +61,7 @@ SIGNATURES = {
     'mcn_bn_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'mcn_bn_relu_mask_bytes': (c_size_t, [c_int64, c_int32, c_int]),
     'mcn_bn_fwd_train': (c_int, [c_void_p] * 12 + [c_float, c_int64, c_int32, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_bn_fwd_train_gap': (c_int, [c_void_p] * 11 + [c_float, c_int32, c_int32, c_int32, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_conv2d_pair_geom': (c_int, [ctypes.POINTER(ConvGeom), c_int, ctypes.POINTER(ConvGeom)]),
     'mcn_conv2d_pair_weights': (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_void_p]),
     'mcn_conv2d_pair_wgrad_fold': (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int, c_void_p]),

@@ -777,6 +777,101 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     return MCN_OK;
 }
 
+// y = act(x*scale + shift) AND the per-image channel means of the STORED y in one pass (round 4): the squeeze-excite block reads the global
+// average of its input right after the BN + swish that produces it (models/efficientnet.py:183 -> tf.reduce_mean(x, axis=[1, 2])), which
+// used to be a second full read of that tensor (gap_fwd_kernel).  One block per (image, group of TX channel chunks): TY row lanes walk the
+// image's HW pixels, the rounded outputs are summed in fp32 per thread and folded over the row lanes through LDS, gap[n][c] = sum / HW.
+template <typename T, int VEC, int ACT>
+__global__ __launch_bounds__(256) void bn_apply_gap_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ gap, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int HW, int C, int TX, int TY) {
+    extern __shared__ float gapred[];                              // [TY][TX * VEC]
+    const int cv = C / VEC;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const long n = blockIdx.y;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (ty < TY && col < cv) {
+        float sc[VEC], sh[VEC];
+        ldc<VEC>(scale + col * VEC, sc);
+        ldc<VEC>(shift + col * VEC, sh);
+        const long base = n * HW * C + (long)col * VEC;
+        for (int q = ty; q < HW; q += TY) {
+            float v[VEC];
+            ldv<T, VEC>(x + base + (long)q * C, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float o = fmaf(v[i], sc[i], sh[i]);
+                if (ACT == 1) o = fmaxf(o, 0.f);
+                if (ACT == 2) o = o * fast_sigmoid(o);
+                v[i] = to_f32(from_f32<T>(o));                     // the value as stored: what a separate pooling pass would read back
+                acc[i] += v[i];
+            }
+            stv<T, VEC>(y + base + (long)q * C, v);
+        }
+    }
+    const int cols = TX * VEC;
+    if (ty < TY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gapred[ty * cols + tx * VEC + i] = acc[i];
+    }
+    __syncthreads();
+    if (ty == 0 && col < cv) {
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float s2 = 0.f;
+            for (int k = 0; k < TY; ++k) s2 += gapred[k * cols + tx * VEC + i];
+            acc[i] = s2 * inv;
+        }
+        stv<T, VEC>(gap + n * C + (long)col * VEC, acc);
+    }
+}
+template <typename T, int VEC>
+static int bn_fwd_train_gap_t(const void* x, const float* gamma, const float* beta, void* y, void* gap, float* save_mean, float* save_invstd, float* batch_mean,
+                              float* batch_var, float* running_mean, float* running_var, float momentum, int N, int HW, int C, float eps, mcn_act act, void* ws,
+                              hipStream_t st) {
+    const long M = (long)N * HW;
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
+    float* part = (float*)ws;
+    float* scale = (float*)((char*)ws + bn_parts_bytes(M, C));
+    float* shift = scale + C;
+    hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), dim3(L.gx, L.gy), dim3(256), 2 * 256 * VEC * sizeof(float), st, (const T*)x, part, M, C, L.TX, L.TY, L.rpb);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_fwd_finalize_kernel<T>), dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const T*)x, (const float*)part, L.gy, M, C, gamma,
+                       beta, eps, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, scale, shift);
+    MCN_CHECK_LAUNCH();
+    // apply + pooled means: image-aligned blocks (the statistics pass above keeps the row-block layout)
+    const int cv = C / VEC;
+    int TX = cv < 32 ? cv : 32;
+    int TY = 256 / TX;
+    if (TY > HW) TY = HW;
+    const dim3 grid((unsigned)((cv + TX - 1) / TX), (unsigned)N);
+    const size_t lds = (size_t)TY * TX * VEC * sizeof(float);
+    const int a = (int)act;
+#define BN_APPLY_GAP(RL) hipLaunchKernelGGL((bn_apply_gap_kernel<T, VEC, RL>), grid, dim3(256), lds, st, (const T*)x, (T*)y, (T*)gap, (const float*)scale, (const float*)shift, HW, C, TX, TY)
+    if (a == 1) BN_APPLY_GAP(1); else if (a == 2) BN_APPLY_GAP(2); else BN_APPLY_GAP(0);
+#undef BN_APPLY_GAP
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const float* beta, void* y, void* gap, float* save_mean, float* save_invstd,
+                                    float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t HW,
+                                    int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y || !gap || !save_mean || !save_invstd || N <= 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_gap: bad argument (N=%d HW=%d C=%d)", N, HW, C);
+    if (N > 65535) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: more than 65535 images (one block row per image)");
+    const int64_t M = (int64_t)N * HW;
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_gap: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+#define BN_GAP_T(TT, VV) return bn_fwd_train_gap_t<TT, VV>(x, gamma, beta, y, gap, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, N, HW, C, eps, act, ws, st)
+    if (dtype == MCN_F32) { if (C % 4 == 0) BN_GAP_T(float, 4); BN_GAP_T(float, 1); }
+    if (dtype == MCN_BF16) { if (C % 8 == 0) BN_GAP_T(bf16_t, 8); BN_GAP_T(bf16_t, 1); }
+    if (dtype == MCN_F16) { if (C % 8 == 0) BN_GAP_T(f16_t, 8); BN_GAP_T(f16_t, 1); }
+#undef BN_GAP_T
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: dtype %d unsupported", (int)dtype);
+}
+
 // ---- statistics from conv-epilogue partials -----------------------------------------------------------------------
 // part[(k*3 + {0,1,2})*C + c] = sum(y - p), sum((y - p)^2), p over the rows [k*rpp, min(M, (k+1)*rpp)) of y.
 // Each partial is an accurate fp32 (count, mean, M2) thanks to its own pivot; partials are merged in double as

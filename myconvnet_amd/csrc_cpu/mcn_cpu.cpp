@@ -910,6 +910,14 @@ static int gap_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, m
         });
     });
 }
+extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const float* beta, void* y, void* gap, float* save_mean, float* save_invstd, float* batch_mean,
+                                    float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t HW, int32_t C, float eps, mcn_act act,
+                                    mcn_dtype dtype, void* ws, size_t ws_bytes, void* st) {
+    if (!gap || N <= 0 || HW <= 0) return fail(MCN_E_BADARG, "bn_fwd_train_gap: bad argument");
+    const int rc = mcn_bn_fwd_train(x, gamma, beta, nullptr, y, nullptr, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, (int64_t)N * HW, C,
+                                    eps, act, dtype, ws, ws_bytes, st);
+    return rc ? rc : mcn_global_avgpool_fwd(y, gap, N, HW, C, dtype, st);
+}
 extern "C" int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void*) { return gap_bwd<false>(dy, dx, N, HW, C, dtype); }
 extern "C" int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void*) { return gap_bwd<true>(dy, dx, N, HW, C, dtype); }
 

@@ -40,6 +40,8 @@ class Lowering(object):
         self.lazy_grad = {}            # tensor id -> (dy_block ptr, mask ptr): a gradient contribution that is applied by the consumer
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.fused_pools = set()       # ids of max-pool nodes whose forward runs inside the BN apply pass in front of them
+        self.fused_gaps = set()        # ids of global-average nodes whose forward runs inside the BN apply pass in front of them
+        self.fuse_bn_gap = bool(model._parameters.get('fuse_bn_gap', _env_flag('MCN_FUSE_BN_GAP', True)))
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
         self.aff_skips = {}            # shortcut-BN output tensor id -> (its input tensor, its affine [2][C]): applied by the consumer BN
@@ -609,6 +611,16 @@ class Lowering(object):
                              a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
                              float(a['momentum']), M, C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
                 return
+            gap = self._gap_consumer(n) if (skip is None and not mask_ptr) else None
+            if gap is not None:
+                # BN + swish in front of a squeeze-excite block: the apply pass also leaves the per-image channel means (the SE branch's
+                # tf.reduce_mean, models/efficientnet.py:183) — fwd_gap then emits nothing
+                self.fused_gaps.add(id(gap))
+                self.fwd.add(lib.mcn_bn_fwd_train_gap, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), y.buf.data_ptr(), gap.outputs[0].buf.data_ptr(),
+                             st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
+                             a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
+                             float(a['momentum']), x.shape[0], M // x.shape[0], C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+                return
             self.fwd.add(lib.mcn_bn_fwd_train, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), ptr(skip.buf) if skip else 0,
                          y.buf.data_ptr(), mask_ptr, st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
                          a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
@@ -852,7 +864,20 @@ class Lowering(object):
         x, y = n.inputs[0], n.outputs[0]
         self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_avgpool_bwd, y.grad.data_ptr(), dst, *(self._pool_args(n) + [MCN_DT[x.dtype]])))
 
+    def _gap_consumer(self, bn):
+        """the global-average node that reads this training-mode BN's (4-D, dense) output, when the BN's apply pass can produce the pooled
+        means itself (mcn_bn_fwd_train_gap: the squeeze-excite squeeze, round 4).  MCN_FUSE_BN_GAP=0 switches it off."""
+        y = bn.outputs[0]
+        if not self.train or not self.fuse_bn_gap or len(y.shape) != 4 or y.shape[0] > 65535:
+            return None
+        gaps = [c for c in y.consumers if c.op == 'gap' and c.inputs[0] is y and c in self.g.nodes]
+        if len(gaps) != 1 or self.g.nodes.index(gaps[0]) < self.g.nodes.index(bn):
+            return None
+        return gaps[0]
+
     def fwd_gap(self, n):
+        if id(n) in self.fused_gaps:                        # produced by the BN apply pass in front of it
+            return
         x, y = n.inputs[0], n.outputs[0]
         N, H, W, C = x.shape
         self.fwd.add(lib.mcn_global_avgpool_fwd, x.buf.data_ptr(), y.buf.data_ptr(), N, H * W, C, MCN_DT[x.dtype])

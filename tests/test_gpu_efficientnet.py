@@ -58,6 +58,10 @@ def test_efficientnet_two_steps_fp32(fuse):
     ops = [n.op for n in model.graph.nodes]
     assert ('act' in ops) and (fuse is False or sum(1 for n in model.graph.nodes if n.op == 'bn' and n.attrs.get('act') == 2) > 0)
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    names = [getattr(fn, '__name__', '') for fn, _ in model._train_low.fwd.calls]
+    if fuse:
+        # round 4: every squeeze-excite squeeze rides in the apply pass of the BN + swish in front of it; the one pooling launch left is the head's
+        assert names.count('mcn_bn_fwd_train_gap') >= 1 and names.count('mcn_global_avgpool_fwd') == 1
     state = ON.TrainState(f64(params), f64(stats))
     for step in range(2):
         x = RNG.random((BATCH, 64, 64, 3)).astype(np.float32)

@@ -97,6 +97,44 @@ def test_bn_swish_fwd_bwd(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 7, 7, 1152), (2, 14, 14, 672), (5, 28, 28, 40), (2, 56, 56, 96), (4, 1, 1, 16), (3, 9, 5, 24)])
+def test_bn_swish_with_pooled_means_in_one_pass(shape, dtype):
+    """mcn_bn_fwd_train_gap (round 4): BN + swish whose apply pass also leaves the squeeze-excite squeeze (per-image channel means of the
+    STORED output, models/efficientnet.py:183).  y and every statistic bit-identical to mcn_bn_fwd_train; the means against the oracle's mean of
+    the stored y and against mcn_global_avgpool_fwd on it (fp32 sums in another order, one rounding to the storage type)."""
+    import torch
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, c = shape
+    x = (1.5 * RNG.standard_normal(shape) + 0.3).astype(np.float32)
+    gamma = (0.5 + RNG.random(c)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    ref = u.bn_fwd_train(x, gamma, beta, 1e-3, dtype, act=2, running=(np.zeros(c, np.float32), np.ones(c, np.float32)))
+    md, td = u.MDT[dtype], u.TDT[dtype]
+    xd, gd, bd = u.dev(x, dtype), u.dev(gamma), u.dev(beta)
+    y = torch.full(shape, float('nan'), dtype=td, device=u.DEV)
+    gap = torch.full((n, c), float('nan'), dtype=td, device=u.DEV)
+    sm, si, bm, bv = [torch.zeros(c, dtype=torch.float32, device=u.DEV) for _ in range(4)]
+    rm, rv = u.dev(np.zeros(c, np.float32)), u.dev(np.ones(c, np.float32))
+    m = n * h * w_
+    ws = u.workspace(lib.mcn_bn_workspace_bytes(m, c))
+    _ffi.check(lib.mcn_bn_fwd_train_gap(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), gap.data_ptr(), sm.data_ptr(), si.data_ptr(), bm.data_ptr(), bv.data_ptr(),
+                                        rm.data_ptr(), rv.data_ptr(), 0.99, n, h * w_, c, 1e-3, 2, md, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    yh = u.host(y)
+    np.testing.assert_array_equal(yh, ref['y'])
+    for got, key in ((sm, 'save_mean'), (si, 'save_invstd'), (bm, 'batch_mean'), (bv, 'batch_var'), (rm, 'running_mean'), (rv, 'running_var')):
+        np.testing.assert_array_equal(u.host(got), ref[key])
+    want = yh.astype(np.float64).reshape(n, h * w_, c).mean(1)
+    check(u.host(gap), want, dtype, 'pooled means', rel={'float32': 2e-6, 'bfloat16': 4e-3, 'float16': 5e-4}[dtype])
+    g2 = torch.full((n, c), float('nan'), dtype=td, device=u.DEV)
+    _ffi.check(lib.mcn_global_avgpool_fwd(y.data_ptr(), g2.data_ptr(), n, h * w_, c, md, u.stream()))
+    a, b = u.host(gap).astype(np.float64), u.host(g2).astype(np.float64)
+    ulp = {'float32': 2.0 ** -22, 'bfloat16': 2.0 ** -7, 'float16': 2.0 ** -10}[dtype]      # two summation orders: at most one storage ulp apart
+    assert np.all(np.abs(a - b) <= ulp * np.maximum(np.abs(b), 1e-3)), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_swish_sigmoid_elementwise(dtype):
     u = _u()
     from myconvnet_amd import _ffi

@@ -1010,8 +1010,10 @@ def test_bn_backward_routes_maxpool_gradient(case, dtype):
         np.testing.assert_array_equal(u.host(dg), u.host(dg_ref))
         np.testing.assert_array_equal(u.host(db), u.host(db_ref))
     else:
-        np.testing.assert_allclose(u.host(dg), u.host(dg_ref), rtol=2e-5, atol=1e-6)
-        np.testing.assert_allclose(u.host(db), u.host(db_ref), rtol=2e-5, atol=1e-6)
+        # (two orders of the same fp32 sums: the absolute noise follows the size of the sums — a channel whose total nearly cancels sits next
+        # to channels of magnitude 60 — not the size of the result)
+        np.testing.assert_allclose(u.host(dg), u.host(dg_ref), rtol=2e-5, atol=5e-7 * float(np.abs(u.host(dg_ref)).max()) + 1e-6)
+        np.testing.assert_allclose(u.host(db), u.host(db_ref), rtol=2e-5, atol=5e-7 * float(np.abs(u.host(db_ref)).max()) + 1e-6)
         a, b = u.host(dx).astype(np.float64), u.host(dx_ref).astype(np.float64)
         ulp = {'float32': 2.0 ** -23, 'bfloat16': 2.0 ** -8, 'float16': 2.0 ** -11}[dtype]
         assert np.abs(a - b).max() <= 2 * ulp * np.abs(b).max() + 1e-7            # the coefficients moved by ~1e-7: at most a rounding step
