@@ -540,7 +540,10 @@ static int pers_slots(K kernel, int threads, int lds) {
 template <typename T, int BMV, int BNV, int EPIV>
 static long nt_pers_cap_of() {
     static const int slots = pers_slots(conv_gemm_nt_pers<T, BMV, BNV, 4, EPIV>, 256, 2 * (BMV + BNV) * 128);
-    return (long)slots * MCN_NUM_CU;
+    // MCN_PERS_CUS (experiment, profiles/probes/rccl_interference.py): size the persistent grids for fewer CUs, i.e. leave the others to a
+    // collective's reduction kernel that runs beside them (a multiple of 32 keeps the counted statistics rows: grid / 8 % N tiles == 0)
+    static const int cus = [] { const char* e = getenv("MCN_PERS_CUS"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= MCN_NUM_CU ? v : MCN_NUM_CU; }();
+    return (long)slots * cus;
 }
 template <typename T>
 static long nt_pers_cap(int tile, int epi) {
