@@ -41,6 +41,7 @@ class Lowering(object):
         self.written = set()           # tensor ids whose .grad already holds a contribution
         self.fused_pools = set()       # ids of max-pool nodes whose forward runs inside the BN apply pass in front of them
         self.fused_gaps = set()        # ids of global-average nodes whose forward runs inside the BN apply pass in front of them
+        self.dw_wgrad_side = bool(model._parameters.get('dw_wgrad_side', _env_flag('MCN_DW_WGRAD_SIDE', True)))     # depthwise wgrad on the wgrad stream
         self.fuse_bn_gap = bool(model._parameters.get('fuse_bn_gap', _env_flag('MCN_FUSE_BN_GAP', True)))
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
@@ -448,13 +449,26 @@ class Lowering(object):
         x, y = n.inputs[0], n.outputs[0]
         w = n.attrs['w']
         gm = n.attrs['geom']
-        if w.trainable:
-            self.bwd.add(lib.mcn_dwconv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(), ctypes.byref(gm), 1.0 / self.loss_scale,
-                         self.dt, self.ws_ptr, self.ws_bytes)
+        def emit_wgrad():
+            if not w.trainable:
+                return
+            if self.overlap_wgrad and self.dw_wgrad_side:
+                # (round 4) like the conv wgrads: on the side stream, behind the event at this point of the main list — its two reads (x, dy) and the
+                # slab fold then run beside the dgrad -> BN-backward chain instead of in front of it
+                self.bwd.add_side(lib.mcn_dwconv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(), ctypes.byref(gm), 1.0 / self.loss_scale,
+                                  self.dt, self.ws2.data_ptr(), self.ws2.numel() * 4)
+            else:
+                self.bwd.add(lib.mcn_dwconv2d_wgrad, x.buf.data_ptr(), y.grad.data_ptr(), w.grad.data_ptr(), ctypes.byref(gm), 1.0 / self.loss_scale,
+                             self.dt, self.ws_ptr, self.ws_bytes)
             self.bwd.mark(('grad_ready', (w.name,)))
+        late = self.overlap_wgrad and self.dw_wgrad_side
+        if not late:
+            emit_wgrad()
         if x.needs_grad:
             self.contribute(x, lambda dst, acc: self.bwd.add(lib.mcn_dwconv2d_dgrad, y.grad.data_ptr(), w.data.data_ptr(), dst, ctypes.byref(gm), acc,
                                                              self.dt))
+        if late:
+            emit_wgrad()
 
     def fwd_chscale(self, n):
         x, m, y = n.inputs[0], n.inputs[1], n.outputs[0]
