@@ -232,7 +232,8 @@ def test_resnet_fp32_bn_statistics_from_conv_epilogue():
     rng = np.random.default_rng(61)
     model, spec, params, stats = make_resnet(50, 'float32', True, fuse_bn_stats=True, defer_dskip=True)
     assert any(getattr(fn, '__name__', '') == 'mcn_bn_fwd_train_fused' for fn, _ in model._train_low.fwd.calls)
-    assert any(getattr(fn, '__name__', '') == 'mcn_conv2d_dgrad_addmasked' for fn, _ in model._train_low.bwd.calls)
+    # (the masked fan-in of the identity shortcuts: with or — round 4 — together with the unit-output BN's backward sums)
+    assert any(getattr(fn, '__name__', '') in ('mcn_conv2d_dgrad_addmasked', 'mcn_conv2d_dgrad_addmasked_bnred') for fn, _ in model._train_low.bwd.calls)
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
     state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
     for step in range(2):
