@@ -231,7 +231,7 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     from myconvnet_amd._ffi import lib, check
     low = model._train_low
     sp = model.stream_ptr()
-    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+    ops = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
     mdt = {'fp32': _ffi.F32, 'bf16': _ffi.BF16, 'fp16': _ffi.F16}[dtype]
     buf = ctypes.create_string_buffer(128)
     lbuf = ctypes.create_string_buffer(1024)
@@ -307,8 +307,12 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                     epi = ', 2>'                                           # ... with the accumulate epilogue
                 elif name == 'mcn_conv2d_dgrad_bnred':
                     epi = ', 4>'                                           # ... with the BN-backward sums
+                elif name == 'mcn_conv2d_dgrad_addmasked_bnred':
+                    epi = ', 5>'                                           # ... with the masked residual fan-in AND the BN-backward sums (round 4)
+                if launches and launches[0][0].startswith('conv_wino'):
+                    launches = launches[:1]                                # (a K-sliced Winograd tail adds a slice and a reduce launch: booked with the body)
                 launches = [(k.replace(', 0>', epi) if epi else k, int(t)) for k, t in launches]
-                if (epi == ', 2>' and dtype == 'fp32') or epi == ', 4>' or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
+                if (epi == ', 2>' and dtype == 'fp32') or epi in (', 4>', ', 5>') or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
                     # fp32 keeps conv_gemm_nt for the accumulate epilogue; by default only the statistics forward is persistent
                     launches = [(_not_persistent(k), t) for k, t in launches]
                 key = max(launches, key=lambda kt: kt[1])[0]               # (per-layer table: the launch with the most taps)
@@ -320,6 +324,8 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                     byt += es * xe                                         # accumulate / fused residual fan-in: one more read of a dx-sized tensor
                 if name == 'mcn_conv2d_dgrad_bnred':
                     byt += es * xe                                         # the BN's input, read beside the dx tile for sum dy' * x
+                if name == 'mcn_conv2d_dgrad_addmasked_bnred':
+                    byt += 2 * es * xe                                     # the next unit's gradient (masked fan-in) and the BN's input
                 if layers:
                     r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
                     r[0] += 1

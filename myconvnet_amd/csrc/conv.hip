@@ -298,9 +298,12 @@ extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------
+// (returns false when the runtime refuses the request: the launch behind it would fail with a less telling error)
 template <typename K>
-static void allow_lds(K kernel, int bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+static bool allow_lds(K kernel, int bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
 }
 
 // Tile shape for conv_gemm_nt.  In the MFMA-bound regime a CU's time is (tiles it receives) x (work per tile), so a layer
@@ -764,6 +767,28 @@ static inline unsigned nblocks(long total, int cap = 8192) {
     return (unsigned)b;
 }
 
+// K-sliced tail of the Winograd forward / dgrad (launch_wino): slices per block of the short last round, 1 = unsplit.  Shared by the launch
+// and by the introspection entry points (mcn_conv2d_kslices / mcn_conv2d_launch_list), which assume the executor's workspace
+// (mcn_conv2d_workspace_bytes: MCN_SK_MAX_BYTES behind the packed operand).
+static int wino_tail_slices(int total, int Kin, bool nosplit, bool have_ws, size_t sk_ws_bytes) {
+    static const int tail_on = [] { const char* e = getenv("MCN_WINO_TAIL"); return e ? atoi(e) : 1; }();
+    const int ns = Kin / 32, rem = total % MCN_NUM_CU;
+    int slices = 1;
+    if (tail_on && !nosplit && total > MCN_NUM_CU && rem > 0 && rem <= MCN_NUM_CU / 2 && ns >= 2 && have_ws) {
+        slices = MCN_NUM_CU / rem;
+        if (slices > ns) slices = ns;
+        if (slices > 8) slices = 8;
+        while (slices > 1 && (size_t)rem * slices * 8 * 128 * 64 * sizeof(float) > sk_ws_bytes) --slices;
+        const int per = (ns + slices - 1) / slices;
+        slices = (ns + per - 1) / per;                     // no empty slices
+    }
+    return slices;
+}
+static int wino_geom_slices(int N, int H, int W, int Kin, int Kout, bool nosplit) {
+    const int total = (((long)N * ((H + 1) / 2) * ((W + 1) / 2) + 63) / 64) * ((Kout + 63) / 64);
+    return wino_tail_slices(total, Kin, nosplit, true, MCN_SK_MAX_BYTES);
+}
+
 // ---- forward -------------------------------------------------------------------------------------------
 // Winograd launch: `in` [N][H][W][Cs] (Kin channels) -> `out` [N][H][W][Kout]; exactly one of stats / red_part may be set
 static int launch_wino(const void* in, const void* u, void* out, const float* bias, int N, int H, int W, int Cs, int Kin, int Kout, float* stats,
@@ -783,29 +808,23 @@ static int launch_wino(const void* in, const void* u, void* out, const float* bi
     // K-sliced tail: one workgroup per CU, so `total` blocks run in ceil(total / 256) rounds; when the last round is short its blocks are cut
     // along the 32-channel super-steps into slices that fill the chip once more (a second launch parks their accumulators, a third sums them in a
     // fixed order and runs the epilogue: deterministic).  14 x 14, 256 -> 256, B = 256: 784 blocks = 3 rounds + 16 blocks -> 64 slices of a quarter block.
-    static const int tail_on = [] { const char* e = getenv("MCN_WINO_TAIL"); return e ? atoi(e) : 1; }();
-    const int ns = Kin / 32, rem = total % MCN_NUM_CU;
-    int slices = 1;
-    if (tail_on && !nosplit && total > MCN_NUM_CU && rem > 0 && rem <= MCN_NUM_CU / 2 && ns >= 2 && sk_ws) {
-        slices = MCN_NUM_CU / rem;
-        if (slices > ns) slices = ns;
-        if (slices > 8) slices = 8;
-        while (slices > 1 && (size_t)rem * slices * 8 * 128 * 64 * sizeof(float) > sk_ws_bytes) --slices;
-        const int per = (ns + slices - 1) / slices;
-        slices = (ns + per - 1) / per;                     // no empty slices
-    }
+    const int rem = total % MCN_NUM_CU;
+    const int slices = wino_tail_slices(total, Kin, nosplit, sk_ws != nullptr, sk_ws_bytes);
     p.sk_slices = slices;
     p.sk_body = slices > 1 ? total - rem : total;
     p.partial = (float*)sk_ws;
     const dim3 grid((unsigned)p.sk_body), sgrid((unsigned)(rem * slices)), rgrid((unsigned)rem);
+    // (the attribute is set ONCE per instantiation — 40 Winograd calls per step, also under graph capture — and checked; every
+    // launch asks for the same WINO_LDS_MAX-bounded size class, so the one-time request covers the largest)
 #define MCN_WINO_LAUNCH(EPIV)                                                                                          \
     do {                                                                                                               \
-        allow_lds(conv_wino_f2k3_w8<0, EPIV>, lds);                                                                    \
+        static const bool ok0 = allow_lds(conv_wino_f2k3_w8<0, EPIV>, 160 * 1024);                                     \
+        static const bool ok1 = allow_lds(conv_wino_f2k3_w8<WINO_SLICE, NT_EPI_STORE>, 160 * 1024);                    \
+        static const bool ok2 = allow_lds(conv_wino_f2k3_w8<WINO_REDUCE, EPIV>, 160 * 1024);                           \
+        if (!ok0 || !ok1 || !ok2) MCN_FAIL(MCN_E_LAUNCH, "conv (Winograd): the runtime refused %d bytes of LDS", lds); \
         hipLaunchKernelGGL((conv_wino_f2k3_w8<0, EPIV>), grid, dim3(512), lds, st, p);                                 \
         if (slices > 1) {                                                                                              \
-            allow_lds(conv_wino_f2k3_w8<WINO_SLICE, NT_EPI_STORE>, lds);                                               \
             hipLaunchKernelGGL((conv_wino_f2k3_w8<WINO_SLICE, NT_EPI_STORE>), sgrid, dim3(512), lds, st, p);           \
-            allow_lds(conv_wino_f2k3_w8<WINO_REDUCE, EPIV>, lds);                                                      \
             hipLaunchKernelGGL((conv_wino_f2k3_w8<WINO_REDUCE, EPIV>), rgrid, dim3(512), lds, st, p);                  \
         }                                                                                                              \
     } while (0)
@@ -1265,7 +1284,8 @@ static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, 
         p.dy_bytes = (unsigned)((size_t)M * g.Cout * sizeof(float));
         if (M > 0) {
             const int lds = WINO_WG_LDS_W8;
-            allow_lds(conv_wino_wgrad_f3k2_w8, lds);
+            static const bool lds_ok = allow_lds(conv_wino_wgrad_f3k2_w8, WINO_WG_LDS_W8);
+            if (!lds_ok) MCN_FAIL(MCN_E_LAUNCH, "conv (Winograd wgrad): the runtime refused %d bytes of LDS", lds);
             hipLaunchKernelGGL(conv_wino_wgrad_f3k2_w8, dim3((unsigned)(p.nbc * p.nbn * splits)), dim3(512), lds, st, p);
             MCN_CHECK_LAUNCH();
         }
@@ -1605,6 +1625,15 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
         char one[96];
         const int n = mcn_conv2d_kernel_name(op, gg, dtype, one, sizeof(one));
         if (n < 0) return n;
+        const bool wf = op == MCN_CONV_FWD && mfma_path_ok(g, dtype) && wino_fwd_ok(g, dtype);
+        const bool wd = op == MCN_CONV_DGRAD && mfma_dgrad_ok(g, dtype) && wino_dgrad_ok(g, dtype);
+        if ((wf || wd) && !(g.tile & MCN_TILE_NOSPLIT)
+            && (wf ? wino_geom_slices(g.N, g.H, g.W, g.Cin, g.Cout, false) : wino_geom_slices(g.N, g.H, g.W, g.Cout, g.Cin, false)) > 1) {
+            // K-sliced tail (launch_wino): the body launch, the slices of the short last round (plain store: template argument 128 = WINO_SLICE) and
+            // the reduce launch that runs the epilogue (64 = WINO_REDUCE; its trailing 0 is replaced by the caller's epilogue like the body's)
+            snprintf(buf, buflen, "%s:%d\nconv_wino_f2k3_w8<%d, 0>:%d\nconv_wino_f2k3_w8<%d, 0>:%d\n", one, g.KH * g.KW, (int)WINO_SLICE, g.KH * g.KW, (int)WINO_REDUCE, 0);
+            return 3;
+        }
         snprintf(buf, buflen, "%s:%d\n", one, g.KH * g.KW);
         return 1;
     }
@@ -1651,10 +1680,12 @@ extern "C" int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* gg, m
     long M;
     int Nn, nchunks;
     if (op == MCN_CONV_FWD) {
-        if (!mfma_path_ok(g, dtype) || wino_fwd_ok(g, dtype)) return 1;
+        if (!mfma_path_ok(g, dtype)) return 1;
+        if (wino_fwd_ok(g, dtype)) return wino_geom_slices(g.N, g.H, g.W, g.Cin, g.Cout, false);      // K-sliced tail of the Winograd launch
         M = (long)g.N * g.OH * g.OW; Nn = g.Cout; nchunks = g.KH * g.KW * (round_up(g.Cin, ce) / ce);
     } else if (op == MCN_CONV_DGRAD) {
-        if (!mfma_dgrad_ok(g, dtype) || wino_dgrad_ok(g, dtype)) return 1;
+        if (!mfma_dgrad_ok(g, dtype)) return 1;
+        if (wino_dgrad_ok(g, dtype)) return wino_geom_slices(g.N, g.H, g.W, g.Cout, g.Cin, false);
         int nt0 = 0;                                      // taps of the first non-empty stride-parity class
         for (int py = 0; py < g.SH && py < g.H && !nt0; ++py)
             for (int px = 0; px < g.SW && px < g.W && !nt0; ++px)

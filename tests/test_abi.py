@@ -69,6 +69,14 @@ def test_argument_validation_without_gpu():
     assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) == 1                     # fp32 3x3 / stride 1: the Winograd kernel (its own tail plan)
     assert lib.mcn_conv2d_kernel_name(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32, buf, 96) == 1 and buf.value.startswith(b'conv_wino_f2k3_w8<')
     assert lib.mcn_conv2d_kernel_name(_ffi.CONV_WGRAD, ctypes.byref(gb), _ffi.F32, buf, 96) == 1 and buf.value == b'conv_wino_wgrad_f3k2_w8'
+    # ... which introspection now reports: 14 x 14 / 256 -> 256 at B = 256 is 784 blocks = 3 rounds + 16 blocks -> the tail blocks are K-sliced,
+    # and the launch list names the slice and the reduce launch beside the body
+    gw = _ffi.conv_geom(256, 14, 14, 256, 256, 3, 3, 1, 1, 1, 1, (1, 1, 1, 1))
+    assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gw), _ffi.F32) == 8 and lib.mcn_conv2d_kslices(_ffi.CONV_DGRAD, ctypes.byref(gw), _ffi.F32) == 8
+    assert lib.mcn_conv2d_launch_list(_ffi.CONV_FWD, ctypes.byref(gw), _ffi.F32, lbuf, 512) == 3
+    assert [ln.rsplit(':', 1)[0] for ln in lbuf.value.decode().splitlines()] == ['conv_wino_f2k3_w8<0, 0>', 'conv_wino_f2k3_w8<128, 0>', 'conv_wino_f2k3_w8<64, 0>']
+    gw.tile = 0x100                                                                                      # MCN_TILE_NOSPLIT
+    assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gw), _ffi.F32) == 1 and lib.mcn_conv2d_launch_list(_ffi.CONV_FWD, ctypes.byref(gw), _ffi.F32, lbuf, 512) == 1
     gb.tile = 0x200                                                                                      # MCN_TILE_NOWINO: the direct kernels
     assert lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.F32) > 1 and lib.mcn_conv2d_kslices(_ffi.CONV_FWD, ctypes.byref(gb), _ffi.BF16) == 1
     gb.tile = 0x300
