@@ -99,6 +99,7 @@ CALL_KERNELS = {
     'mcn_bn_bwd': ['bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel'],
     'mcn_bn_bwd_se': ['bn_bwd_reduce_se_kernel', 'bn_bwd_apply_se_kernel'],
     'mcn_bn_fwd_train_fused': ['bn_apply_kernel', 'bn_fwd_finalize_fused_kernel', 'bn_fold_partials_kernel'],
+    'mcn_bn_fwd_train_gap': ['bn_apply_gap_kernel'],
     'mcn_dwconv2d_fwd': ['dw_band_kernel', 'dw_strip_kernel'],
     'mcn_dwconv2d_dgrad': ['dw_dgrad', 'dw_band_kernel', 'dw_strip_kernel'],
     'mcn_dwconv2d_wgrad': ['dw_wgrad'],
@@ -193,6 +194,8 @@ def _hbm_call_bytes(name, a, es):
         return es * mc(17) * 3
     if name == 'mcn_bn_fwd_train':                       # statistics pass + apply pass
         return es * mc(13) * (3 + (1 if a[3] else 0))
+    if name == 'mcn_bn_fwd_train_gap':                   # statistics pass + apply pass (the pooled means ride in the apply pass)
+        return es * float(a[12]) * float(a[13]) * float(a[14]) * 3
     if name == 'mcn_bn_fwd_train_fused_maxpool':         # x -> pooled + arg-max
         n, h, w, c, oh, ow = a[15], a[16], a[17], a[18], a[-6], a[-5]
         return es * n * h * w * c + (es + 1) * n * oh * ow * c
