@@ -606,14 +606,15 @@ def main():
     if world == 1 and not args.no_roofline:
         # the reference's own _step also copies loss, Y_all and pred to the host every step (optimizers.py:590-594: a device sync per step);
         # `value` skips that (config.fetch = false) — this is the same step WITH it, over min(steps, 10) steps
-        nf = max(1, min(args.steps, 10))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(opt, nf, fetch=True)
-        torch.cuda.synchronize()
-        dtf = time.perf_counter() - t0
-        out['fetch_true'] = {'value': round(args.batch * nf / dtf, 2), 'unit': 'images/sec', 'ms_per_step': round(dtf / nf * 1e3, 3), 'steps': nf,
-                             'what': 'the same step with the per-step device->host copy of loss / Y_all / pred (optimizers.py:590-594)'}
+        nf = min(args.steps, 10)
+        if nf >= 5:                                       # (not in the one-step runs of the PMC passes: profiles/summarize.py counts their steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(opt, nf, fetch=True)
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t0
+            out['fetch_true'] = {'value': round(args.batch * nf / dtf, 2), 'unit': 'images/sec', 'ms_per_step': round(dtf / nf * 1e3, 3), 'steps': nf,
+                                 'what': 'the same step with the per-step device->host copy of loss / Y_all / pred (optimizers.py:590-594)'}
         table = instrumented_pass(model, args.dtype, layers=args.layers)
         bracket_us = table.pop('_bracket_us')[1] * 1e3
         convs = {k: v for k, v in table.items() if k.startswith('conv_gemm') or k.startswith('conv_wino')}
