@@ -421,6 +421,17 @@ int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels,
                                        float* pred, float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C,
                                        float label_smoothing, float loss_scale, void* workspace, size_t workspace_bytes,
                                        void* stream);
+/* the focal variants (convnet.py:581-592, round 4; focal_gamma = sigmoid_focal_alpha = 0: the entry points above):
+ *   focal_gamma > 0         : softmax_losses *= (1 - p_t)^gamma, p_t = sum_c Y_c * pred_c — differentiated through the softmax as tf.gradients does;
+ *   sigmoid_focal_alpha > 0 : softmax_losses *= stop_gradient(1 - sigmoid(alpha (p_t - 0.5))) / (1 - sigmoid(-alpha / 2)).
+ * `ce` receives the row's FACTORED cross-entropy, so loss = mean(coef * ce) as before. */
+int mcn_softmax_xent_focal_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce,
+                                   float* coef, float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing,
+                                   float loss_scale, float focal_gamma, float sigmoid_focal_alpha, void* stream);
+int mcn_softmax_xent_rows_focal_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w,
+                                        float* pred, float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C,
+                                        float label_smoothing, float loss_scale, float focal_gamma, float sigmoid_focal_alpha,
+                                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- segmentation path -----------------------------------------------------
  * tf.image.resize_bilinear (convnet.py:2396; align_corners=True at models/deeplabv3plus.py:64,74) and its gradient
@@ -440,6 +451,11 @@ int mcn_one_hot_seg(const float* labels, float* onehot, int64_t P, int32_t C, vo
 /* l2_factor * sum tf.nn.l2_loss(w) over a flat range (convnet.py:560-563): out[0] += factor*sum(w^2)/2 */
 int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, void* workspace, size_t workspace_bytes,
                 void* stream);
+/* L1 regulariser (convnet.py:553-557: l1_factor * sum_w sum|w|): out[0] += factor * sum |w|; workspace >= 1024 floats */
+int mcn_l1_loss(const float* w, int64_t n, float factor, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* ... and its gradient: g += (l1 / hyper[3]) * sign(w), launched in front of mcn_sgd_nesterov_fused_h, which scales g by
+ * hyper[3] = 1 / towers (the regulariser is not a tower mean) */
+int mcn_l1_grad_h(float* g, const float* w, int64_t n, float l1, const float* hyper, void* stream);
 
 /* ---- optimizer -------------------------------------------------------------------------------
  * tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True).apply_gradients (optimizers.py:676,

@@ -119,6 +119,10 @@ SIGNATURES = {
     'mcn_decoupled_decay_h': (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_float, c_void_p]),
     'mcn_ema_update_h': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'mcn_softmax_xent_rows_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    'mcn_softmax_xent_focal_fwd_bwd': (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
+    'mcn_softmax_xent_rows_focal_fwd_bwd': (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    'mcn_l1_loss': (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mcn_l1_grad_h': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     'mcn_softmax_xent_rows_soft_fwd_bwd': (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     'mcn_resize_bilinear_fwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),
     'mcn_resize_bilinear_bwd': (c_int, [c_void_p, c_void_p] + [c_int32] * 7 + [c_int, c_void_p]),

@@ -292,8 +292,6 @@ class ConvNet(object):
 
     def _build_loss(self, **kwargs):
         """reference convnet.py:528-597."""
-        if kwargs.get('l1_reg', 0.0) > 0.0 or kwargs.get('focal_loss_factor', 0.0) > 0.0 or kwargs.get('sigmoid_focal_loss_factor', 0.0) > 0.0:
-            raise NotImplementedError('l1 / focal losses are outside the built path')
         # bias_norm_decay (convnet.py:536-537, optimizers.py:150-151): biases, gammas and betas join the regularised set
         self.bias_norm_decay = bool(kwargs.get('bias_norm_decay', False))
         g = self.graph
@@ -317,7 +315,10 @@ class ConvNet(object):
         self.pred = g.tensor(shape, 'float32', 'pred')
         self.d['pred'] = self.pred
         raw = getattr(labels, 'soft_avg_of', None)          # SegNet smoothing: `labels` is the 5x5 average of the raw one-hot map `raw`
+        # l1_reg / focal_loss_factor / sigmoid_focal_loss_factor (convnet.py:530-533, 553-557, 581-592): 0 = off, as in the reference's defaults
         self._loss_node = g.node('loss', [logits, labels] if raw is None else [logits, raw, labels], [self.pred], l2_reg=float(kwargs.get('l2_reg', 1e-4)),
+                                 l1_reg=float(kwargs.get('l1_reg', 0.0)), focal_gamma=float(kwargs.get('focal_loss_factor', 0.0)),
+                                 sigmoid_focal_alpha=float(kwargs.get('sigmoid_focal_loss_factor', 0.0)),
                                  label_smoothing=float(getattr(labels, 'ls_factor', 0.0)), rows=int(np.prod(shape[:-1])), per_pixel=len(shape) == 4)
         return self._loss_node
 
@@ -748,8 +749,13 @@ class ConvNet(object):
         return y
 
     def stop_gradient(self, x):
-        """Stand-in for tf.stop_gradient (models/deeplabv3plus.py:53); not on the built path (feature_gradients are True)."""
-        raise NotImplementedError('stop_gradient on a backbone feature is not built')
+        """Stand-in for tf.stop_gradient (models/deeplabv3plus.py:50-53): the value of x, no gradient path into it.  A graph node whose output
+        SHARES x's storage (nothing is copied or launched) and never needs a gradient, so every consumer's backward skips its data gradient."""
+        y = self.graph.tensor(x.shape, x.dtype, self.scope_name('stop_gradient'), self._channel_first)
+        y.cs = x.cs
+        y.share_of = x
+        self.graph.node('stopgrad', [x], [y], scope=self.scope_name())
+        return y
 
     def channel_scale(self, x, mask):
         """Stand-in for `x = x*se_mask` (models/efficientnet.py:161): mask [N,1,1,C] broadcast over H, W."""

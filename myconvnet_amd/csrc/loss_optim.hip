@@ -24,10 +24,22 @@ __device__ __forceinline__ float block_reduce_max(float v, float* sh) {
     return t;
 }
 
+// focal factors of one row: fs = F * S (the factor on the row's cross-entropy), dfs = S * dF/dp_t (S is a constant under tf.stop_gradient)
+struct FocalTerms { float fs, dfs; };
+__device__ __forceinline__ FocalTerms focal_terms(float pt, float fgamma, float salpha) {
+    float F = 1.f, dF = 0.f, S = 1.f;
+    if (fgamma > 0.f) {
+        const float om = fmaxf(1.f - pt, 0.f);
+        F = powf(om, fgamma);
+        dF = om > 0.f ? -fgamma * powf(om, fgamma - 1.f) : 0.f;
+    }
+    if (salpha > 0.f) S = (1.f - 1.f / (1.f + expf(-salpha * (pt - 0.5f)))) / (1.f - 1.f / (1.f + expf(0.5f * salpha)));
+    return FocalTerms{F * S, dF * S};
+}
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                            const float* __restrict__ class_w, float* __restrict__ pred,
                                                            float* __restrict__ ce, float* __restrict__ coef, float* __restrict__ dlogits,
-                                                           int B, int C, float ls, float loss_scale) {
+                                                           int B, int C, float ls, float loss_scale, float fgamma, float salpha) {
     __shared__ float sh[4];
     const int b = blockIdx.x;
     const float* z = logits + (long)b * C;
@@ -52,6 +64,33 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
     const float lab_sum = ls > 0.f ? sy * (1.f - ls) + ls : sy;
     const float gscale = cf * loss_scale / (float)B;
     float cel = 0.f;
+    if (fgamma > 0.f || salpha > 0.f) {
+        // focal factors (convnet.py:581-592): F = (1 - p_t)^gamma with p_t = sum_c Y_c p_c — differentiated THROUGH the softmax, as
+        // tf.gradients does —, S = (1 - sigmoid(alpha (p_t - 0.5))) / (1 - sigmoid(-alpha / 2)) under tf.stop_gradient; the row's
+        // loss is coef * F * S * CE.  Both need the whole row's CE and p_t before the gradient: two passes over the row.
+        float pt = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float lsm = z[c] - mx - lse;
+            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+            cel -= lab * lsm;
+            pt += yv[c] * expf(lsm);
+        }
+        cel = block_reduce_sum(cel, sh);
+        pt = block_reduce_sum(pt, sh);
+        const FocalTerms ft = focal_terms(pt, fgamma, salpha);
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float lsm = z[c] - mx - lse;
+            const float p = expf(lsm);
+            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls / (float)C : yv[c];
+            if (pred) pred[(long)b * C + c] = p;
+            if (dlogits) dlogits[(long)b * C + c] = (ft.fs * (p * lab_sum - lab) + cel * ft.dfs * (yv[c] * p - pt * p)) * gscale;
+        }
+        if (threadIdx.x == 0) {
+            ce[b] = cel * ft.fs;
+            coef[b] = cf;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float lsm = z[c] - mx - lse;
         const float p = expf(lsm);
@@ -73,7 +112,8 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
 __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                                     const float* __restrict__ class_w, float* __restrict__ pred,
                                                                     float* __restrict__ ce, float* __restrict__ coef, float* __restrict__ dlogits,
-                                                                    long B, int C, float ls, float loss_scale, const float* __restrict__ avg) {
+                                                                    long B, int C, float ls, float loss_scale, const float* __restrict__ avg, float fgamma,
+                                                                    float salpha) {
     extern __shared__ float xs[];
     const int P = C | 1;
     float* zt = xs;
@@ -100,13 +140,14 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
             // soft-label target of the smoothing: 1/C (convnet.py:603-607) or the 5x5 average of the label map (segnet.py:117-122;
             // a rarely used option: the row's averages are read straight from global memory)
             const float* av = avg ? avg + (b0 + threadIdx.x) * C : nullptr;
-            float se = 0.f, sy = 0.f, bw = 0.f, slz = 0.f, sl = 0.f;
+            float se = 0.f, sy = 0.f, bw = 0.f, slz = 0.f, sl = 0.f, sye = 0.f;
             for (int c = 0; c < C; ++c) {
                 const float d = z[c] - mx;
                 const float e = expf(d);
                 se += e;
                 const float y = yv[c];
                 sy += y;
+                sye += y * e;
                 bw += y * (class_w ? class_w[c] : 1.f);
                 const float lab = ls > 0.f ? y * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : y;
                 sl += lab;
@@ -119,13 +160,18 @@ __global__ __launch_bounds__(XR_ROWS) void softmax_xent_rows_kernel(const float*
             const float cf = bw * valid;
             const float lab_sum = av ? sl : (ls > 0.f ? sy * (1.f - ls) + ls : sy);
             const float gscale = cf * loss_scale / (float)B;
-            const float cel = lse * lab_sum - slz;
+            float cel = lse * lab_sum - slz;
+            const float pt = sye * inv;
+            FocalTerms ft = {1.f, 0.f};
+            if (fgamma > 0.f || salpha > 0.f) ft = focal_terms(pt, fgamma, salpha);
             for (int c = 0; c < C; ++c) {
                 const float pr = z[c] * inv;
                 const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : yv[c];
+                const float yc = yv[c];
                 z[c] = pr;
-                yv[c] = (pr * lab_sum - lab) * gscale;
+                yv[c] = (ft.fs * (pr * lab_sum - lab) + cel * ft.dfs * (yc * pr - pt * pr)) * gscale;
             }
+            cel *= ft.fs;
             ce[b0 + threadIdx.x] = cel;
             coef[b0 + threadIdx.x] = cf;
         }
@@ -165,13 +211,13 @@ __global__ __launch_bounds__(256) void xent_mean_kernel(const float* __restrict_
     s = block_reduce_sum(s, sh);
     if (threadIdx.x == 0) loss[0] = s / (float)B;
 }
-extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
-                                        float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing, float loss_scale,
-                                        void* stream) {
-    if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "softmax_xent: bad argument");
+extern "C" int mcn_softmax_xent_focal_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
+                                              float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing, float loss_scale,
+                                              float focal_gamma, float sigmoid_focal_alpha, void* stream) {
+    if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0 || focal_gamma < 0.f || sigmoid_focal_alpha < 0.f) MCN_FAIL(MCN_E_BADARG, "softmax_xent: bad argument");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(softmax_xent_kernel, dim3(B), dim3(256), 0, st, logits, labels, class_w, pred, ce, coef, dlogits, B, C, label_smoothing,
-                       loss_scale);
+                       loss_scale, focal_gamma, sigmoid_focal_alpha);
     MCN_CHECK_LAUNCH();
     if (loss) {
         hipLaunchKernelGGL(xent_mean_kernel, dim3(1), dim3(256), 0, st, (const float*)ce, (const float*)coef, loss, B);
@@ -180,11 +226,18 @@ extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels
     return MCN_OK;
 }
 
+extern "C" int mcn_softmax_xent_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
+                                        float* dlogits, float* loss, int32_t B, int32_t C, float label_smoothing, float loss_scale,
+                                        void* stream) {
+    return mcn_softmax_xent_focal_fwd_bwd(logits, labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, 0.f, 0.f, stream);
+}
+
 /* per-pixel variant (segmentation: rows = N*H*W pixels, few classes): one thread per row, two-stage mean through the
  * caller's workspace (>= 1024 floats) */
-extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred,
-                                                  float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing,
-                                                  float loss_scale, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int mcn_softmax_xent_rows_focal_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred,
+                                                   float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing,
+                                                   float loss_scale, float focal_gamma, float sigmoid_focal_alpha, void* ws, size_t ws_bytes, void* stream) {
+    if (focal_gamma < 0.f || sigmoid_focal_alpha < 0.f) MCN_FAIL(MCN_E_BADARG, "softmax_xent_rows: negative focal factor");
     if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "softmax_xent_rows: bad argument");
     if (C > 64) MCN_FAIL(MCN_E_UNSUPPORTED, "softmax_xent_rows: C=%d > 64 classes: use mcn_softmax_xent_fwd_bwd", C);
     if (loss && (!ws || ws_bytes < 1024 * sizeof(float))) MCN_FAIL(MCN_E_WORKSPACE, "softmax_xent_rows: workspace needs 4096 bytes");
@@ -195,7 +248,7 @@ extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const flo
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XR_ROWS * 65 * 4), true);
     (void)once;
     hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((unsigned)blocks), dim3(XR_ROWS), lds, st, logits, labels, class_w, pred, ce, coef, dlogits, (long)B, C,
-                       label_smoothing, loss_scale, label_smoothing > 0.f ? avg_labels : (const float*)nullptr);
+                       label_smoothing, loss_scale, label_smoothing > 0.f ? avg_labels : (const float*)nullptr, focal_gamma, sigmoid_focal_alpha);
     MCN_CHECK_LAUNCH();
     if (loss) {
         hipLaunchKernelGGL(xent_partial_kernel, dim3(1024), dim3(256), 0, st, (const float*)ce, (const float*)coef, (float*)ws, (long)B);
@@ -204,6 +257,12 @@ extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const flo
         MCN_CHECK_LAUNCH();
     }
     return MCN_OK;
+}
+extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred,
+                                                  float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing,
+                                                  float loss_scale, void* ws, size_t ws_bytes, void* stream) {
+    return mcn_softmax_xent_rows_focal_fwd_bwd(logits, labels, avg_labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, 0.f, 0.f, ws,
+                                               ws_bytes, stream);
 }
 extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef,
                                              float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void* ws,
@@ -247,6 +306,54 @@ extern "C" int mcn_l2_loss(const float* w, int64_t n, float factor, float* out, 
     hipLaunchKernelGGL(l2_partial_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, w, (long)n, (float*)ws);
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(l2_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, L2_BLOCKS, factor, out);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
+// ---- L1 regulariser (convnet.py:553-557: l1_factor * sum_w sum |w|): value and gradient ---------------------------------------------------
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ w, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += fabsf(w[i]);
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int nparts, float factor, float* __restrict__ out) {
+    __shared__ double shd[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += (double)part[i];
+    shd[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += (float)((double)factor * shd[0]);
+}
+extern "C" int mcn_l1_loss(const float* w, int64_t n, float factor, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !out || n < 0) MCN_FAIL(MCN_E_BADARG, "l1_loss: bad argument");
+    if (!ws || ws_bytes < L2_BLOCKS * sizeof(float)) MCN_FAIL(MCN_E_WORKSPACE, "l1_loss: workspace needs %zu bytes", (size_t)L2_BLOCKS * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(L2_BLOCKS), dim3(256), 0, st, w, (long)n, (float*)ws);
+    MCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, L2_BLOCKS, factor, out);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+// g += (l1 / grad_scale) * sign(w): launched in front of the update, whose kernel multiplies g by grad_scale = hyper[3] (1 / towers)
+__global__ __launch_bounds__(256) void l1_grad_kernel(float* __restrict__ g, const float* __restrict__ w, long n, float l1, const float* __restrict__ hyper) {
+    const float f = l1 / hyper[3];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        g[i] += v > 0.f ? f : (v < 0.f ? -f : 0.f);
+    }
+}
+extern "C" int mcn_l1_grad_h(float* g, const float* w, int64_t n, float l1, const float* hyper, void* stream) {
+    if (!g || !w || !hyper || n < 0) MCN_FAIL(MCN_E_BADARG, "l1_grad: bad argument");
+    if (n == 0 || l1 == 0.f) return MCN_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(l1_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, w, (long)n, l1, hyper);
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }

@@ -976,7 +976,7 @@ extern "C" int mcn_fc_bwd(const void* dy, const void* x, const float* w, void* d
 
 // ---- loss (convnet.py:528-601) ---------------------------------------------------------------------------------------------------------------
 static int xent_rows(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef, float* dlogits, float* loss, int64_t B, int32_t C, float ls,
-                     float loss_scale, const float* avg = nullptr) {
+                     float loss_scale, const float* avg = nullptr, float fgamma = 0.f, float salpha = 0.f) {
     if (!logits || !labels || !ce || !coef || B <= 0 || C <= 0) return fail(MCN_E_BADARG, "softmax_xent: bad argument");
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
@@ -1000,14 +1000,28 @@ static int xent_rows(const float* logits, const float* labels, const float* clas
             for (int c = 0; c < C; ++c) lab_sum += yv[c] * (1.f - ls) + ls * av[c];
         }
         const float gscale = cf * loss_scale / (float)B;
-        float cel = 0.f;
+        float cel = 0.f, pt = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float lsm = z[c] - mx - lse;
+            const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : yv[c];
+            cel -= lab * lsm;
+            pt += yv[c] * expf(lsm);
+        }
+        // focal factors (convnet.py:581-592): F = (1 - p_t)^gamma differentiated through the softmax, S under stop_gradient
+        float F = 1.f, dF = 0.f, S = 1.f;
+        if (fgamma > 0.f) {
+            const float om = std::max(1.f - pt, 0.f);
+            F = std::pow(om, fgamma);
+            dF = om > 0.f ? -fgamma * std::pow(om, fgamma - 1.f) : 0.f;
+        }
+        if (salpha > 0.f) S = (1.f - 1.f / (1.f + expf(-salpha * (pt - 0.5f)))) / (1.f - 1.f / (1.f + expf(0.5f * salpha)));
         for (int c = 0; c < C; ++c) {
             const float lsm = z[c] - mx - lse, p = expf(lsm);
             const float lab = ls > 0.f ? yv[c] * (1.f - ls) + ls * (av ? av[c] : 1.f / (float)C) : yv[c];
-            cel -= lab * lsm;
             if (pred) pred[b * C + c] = p;
-            if (dlogits) dlogits[b * C + c] = (p * lab_sum - lab) * gscale;
+            if (dlogits) dlogits[b * C + c] = (F * S * (p * lab_sum - lab) + cel * dF * S * (yv[c] * p - pt * p)) * gscale;
         }
+        cel *= F * S;
         ce[b] = cel;
         coef[b] = cf;
     }
@@ -1029,6 +1043,30 @@ extern "C" int mcn_softmax_xent_rows_fwd_bwd(const float* logits, const float* l
 extern "C" int mcn_softmax_xent_rows_soft_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred, float* ce, float* coef,
                                                   float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, void*, size_t, void*) {
     return xent_rows(logits, labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, avg_labels);
+}
+extern "C" int mcn_softmax_xent_focal_fwd_bwd(const float* logits, const float* labels, const float* class_w, float* pred, float* ce, float* coef, float* dlogits, float* loss,
+                                              int32_t B, int32_t C, float label_smoothing, float loss_scale, float fg, float sa, void*) {
+    if (fg < 0.f || sa < 0.f) return fail(MCN_E_BADARG, "softmax_xent: negative focal factor");
+    return xent_rows(logits, labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, nullptr, fg, sa);
+}
+extern "C" int mcn_softmax_xent_rows_focal_fwd_bwd(const float* logits, const float* labels, const float* avg_labels, const float* class_w, float* pred, float* ce, float* coef,
+                                                   float* dlogits, float* loss, int64_t B, int32_t C, float label_smoothing, float loss_scale, float fg, float sa, void*, size_t,
+                                                   void*) {
+    if (fg < 0.f || sa < 0.f) return fail(MCN_E_BADARG, "softmax_xent_rows: negative focal factor");
+    return xent_rows(logits, labels, class_w, pred, ce, coef, dlogits, loss, B, C, label_smoothing, loss_scale, avg_labels, fg, sa);
+}
+extern "C" int mcn_l1_loss(const float* w, int64_t n, float factor, float* out, void*, size_t, void*) {
+    if (!w || !out || n < 0) return fail(MCN_E_BADARG, "l1_loss: bad argument");
+    double a = 0.0;
+    for (int64_t i = 0; i < n; ++i) a += std::fabs((double)w[i]);
+    out[0] += (float)((double)factor * a);
+    return MCN_OK;
+}
+extern "C" int mcn_l1_grad_h(float* g, const float* w, int64_t n, float l1, const float* hyper, void*) {
+    if (!g || !w || !hyper || n < 0) return fail(MCN_E_BADARG, "l1_grad: bad argument");
+    const float f = l1 / hyper[3];
+    for (int64_t i = 0; i < n; ++i) g[i] += w[i] > 0.f ? f : (w[i] < 0.f ? -f : 0.f);
+    return MCN_OK;
 }
 
 // ---- segmentation path: bilinear resize (tf.image.resize_bilinear, convnet.py:2396) ------------------------------------------------------------

@@ -12,11 +12,13 @@ class _DeepLabV3Plus(SegNet):
     def _init_deeplab_params(self):
         self.feature_blocks = [4, 1]
         self.feature_channels = [256, 48]
-        self.feature_gradients = [None, True]
+        # (reference: fixed attributes [None, True] / False — the kwargs exist so that the reference's other branch of each switch,
+        # tf.stop_gradient on the low-level feature and the ASPP image-level feature, can be exercised: models/deeplabv3plus.py:50-53, 90-99)
+        self.feature_gradients = list(self._parameters.get('feature_gradients', [None, True]))
         self.drop_rate_multipliers = [1.0, 0.0]
         self.conv_kernels = [None, 3]
         self.aspp_dilations = list(self._parameters.get('aspp_dilations', [6, 12, 18]))   # kwarg: test-only (small maps); reference: fixed
-        self.aspp_level_feature = False
+        self.aspp_level_feature = bool(self._parameters.get('aspp_level_feature', False))
         wd = getattr(self, '_width_div', 1)                        # test-only reduction of the head widths (not in the reference)
         if wd > 1:
             self.feature_channels = [max(8, c // wd) for c in self.feature_channels]
@@ -54,8 +56,6 @@ class _DeepLabV3Plus(SegNet):
         return d
 
     def aspp_unit(self, x, channels, dilations, level_feature=False, name='aspp'):
-        if level_feature:
-            raise NotImplementedError('ASPP image-level feature branch (off in the reference, aspp_level_feature=False) is not built')
         with self.variable_scope(name):
             ys = []
             with self.variable_scope('conv_0'):
@@ -65,6 +65,14 @@ class _DeepLabV3Plus(SegNet):
                 with self.variable_scope('conv_{}'.format(i + 1)):
                     y = self.conv_layer(x, 3, 1, channels, padding='SAME', biased=False, depthwise=False, dilation=dil)
                     ys.append(self.normalization(y, norm_type=self.norm_type, norm_param=self.norm_param))
+            if level_feature:
+                # image-level feature (models/deeplabv3plus.py:90-99): global mean -> 1x1 conv -> norm -> resized back to the feature map (from a
+                # 1x1 source: a broadcast; the reference's call leaves align_corners at its default False)
+                with self.variable_scope('conv_pool'):
+                    y = self.global_avg_pool(x, keepdims=True)
+                    y = self.conv_layer(y, 1, 1, channels, padding='SAME', biased=False, depthwise=False, dilation=dilations[-1])
+                    y = self.normalization(y, norm_type=self.norm_type, norm_param=self.norm_param)
+                    ys.append(self.upsampling_2d_layer(y, out_shape=x.shape[1:3]))
             with self.variable_scope('conv_out'):
                 x = self.concat(ys)
                 x = self.conv_layer(x, 1, 1, channels, padding='SAME', biased=False, depthwise=False)

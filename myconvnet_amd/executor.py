@@ -889,6 +889,12 @@ class Lowering(object):
             return None
         return gaps[0]
 
+    def fwd_stopgrad(self, n):
+        pass                                                # the output shares its input's storage (graph.allocate): no launch
+
+    def bwd_stopgrad(self, n):
+        pass                                                # ... and no gradient flows back (tf.stop_gradient, models/deeplabv3plus.py:53)
+
     def fwd_gap(self, n):
         if id(n) in self.fused_gaps:                        # produced by the BN apply pass in front of it
             return
@@ -940,11 +946,16 @@ class Lowering(object):
         dl = logits.grad.data_ptr() if (self.train and logits.needs_grad) else 0
         if dl:
             self.written.add(logits.id)
-        if len(n.inputs) == 3:                               # SegNet label smoothing: raw one-hot map + its 5x5 average (segnet.py:117-122)
+        fg, sa = float(a.get('focal_gamma', 0.0)), float(a.get('sigmoid_focal_alpha', 0.0))
+        if len(n.inputs) == 3 or ((fg > 0.0 or sa > 0.0) and a.get('per_pixel')):
+            # SegNet label smoothing: raw one-hot map + its 5x5 average (segnet.py:117-122); focal factors on the per-pixel loss (convnet.py:581-592)
             assert a.get('per_pixel')
-            self.fwd.add(lib.mcn_softmax_xent_rows_soft_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), n.inputs[2].buf.data_ptr(), ptr(a.get('class_w')),
-                         a['pred'].buf.data_ptr(), a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']),
-                         self.loss_scale, self.ws_ptr, self.ws_bytes)
+            self.fwd.add(lib.mcn_softmax_xent_rows_focal_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), n.inputs[2].buf.data_ptr() if len(n.inputs) == 3 else 0,
+                         ptr(a.get('class_w')), a['pred'].buf.data_ptr(), a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C,
+                         float(a['label_smoothing']), self.loss_scale, fg, sa, self.ws_ptr, self.ws_bytes)
+        elif fg > 0.0 or sa > 0.0:
+            self.fwd.add(lib.mcn_softmax_xent_focal_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
+                         a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale, fg, sa)
         elif a.get('per_pixel'):
             self.fwd.add(lib.mcn_softmax_xent_rows_fwd_bwd, logits.buf.data_ptr(), onehot.buf.data_ptr(), ptr(a.get('class_w')), a['pred'].buf.data_ptr(),
                          a['ce'].data_ptr(), a['coef'].data_ptr(), dl, a['loss'].data_ptr(), B, C, float(a['label_smoothing']), self.loss_scale,
@@ -956,3 +967,5 @@ class Lowering(object):
         if a['l2_reg'] > 0.0 and nw > 0:
             # the regulariser always reads the master variables (collection 'weight_variables', convnet.py:535)
             self.fwd.add(lib.mcn_l2_loss, m.store.data.data_ptr(), nw, float(a['l2_reg']), a['loss'].data_ptr(), self.ws_ptr, self.ws_bytes)
+        if a.get('l1_reg', 0.0) > 0.0 and nw > 0:              # L1 term over the same variables (convnet.py:553-557); its gradient: optimizers.py
+            self.fwd.add(lib.mcn_l1_loss, m.store.data.data_ptr(), nw, float(a['l1_reg']), a['loss'].data_ptr(), self.ws_ptr, self.ws_bytes)

@@ -311,13 +311,19 @@ class Graph(object):
 
     def allocate(self, training):
         for t in self.live_tensors():
-            if t.buf is None:
+            if t.buf is None and getattr(t, 'share_of', None) is None:
                 shape = t.shape[:-1] + (t.cs,)
                 t.buf = torch.zeros(shape, dtype=TORCH_DT[t.dtype], device=self.device)
+        for t in self.live_tensors():                       # stop_gradient outputs: the producer's storage under another name
+            src = getattr(t, 'share_of', None)
+            while src is not None and src.buf is None and getattr(src, 'share_of', None) is not None:
+                src = src.share_of
+            if t.buf is None and src is not None:
+                t.buf = src.buf
         if training:
             # which tensors need a gradient: anything downstream of a trainable variable
             for n in self.nodes:
-                if n.op in ('input', 'labels'):
+                if n.op in ('input', 'labels', 'stopgrad'):   # (tf.stop_gradient: nothing downstream of x through this node needs x's gradient)
                     continue
                 # (frozen variables, blocks_to_train, do not start a gradient path)
                 trains = n.attrs.get('has_params') and any(getattr(n.attrs.get(k), 'trainable', False) for k in ('w', 'b', 'gamma', 'beta'))

@@ -84,6 +84,9 @@ class Optimizer(object):
             self.decay_mode = _ffi.DECAY_L1 if kwargs.get('l1_weight_decay', False) else _ffi.DECAY_L2
         self.momentum = optimizer['momentum']
         self.l2_reg = float(m._parameters.get('l2_reg', 1e-4))
+        self.l1_reg = float(m._parameters.get('l1_reg', 0.0))              # convnet.py:529,553-557: l1_factor * sum |w| over the regularised variables
+        if self.l1_reg > 0.0 and self.gradient_threshold is not None:
+            raise NotImplementedError('l1_reg together with gradient clipping (the clip would have to see the L1 gradient) is not built')
         self.use_ema = bool(kwargs.get('update_ema', True))
         st = m.store
         nw, n = m.n_l2_elems, st.size
@@ -117,6 +120,8 @@ class Optimizer(object):
                     P.add(lib.mcn_ema_update_h, ema_w + off, st.data.data_ptr() + off, e1 - s1, hp)
                 continue
             reg = s1 < nw
+            if reg and self.l1_reg > 0.0:                # d/dw l1 * |w| = l1 * sign(w), added unscaled by the tower mean (the update kernel scales g by 1 / towers)
+                P.add(lib.mcn_l1_grad_h, st.grad.data_ptr() + off, st.data.data_ptr() + off, e1 - s1, self.l1_reg, hp)
             # (with clipping the L2 gradient was folded into g by mcn_clip_by_global_norm: l2 = 0 here)
             P.add(lib.mcn_sgd_nesterov_fused_h, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
                   (ema_w + off) if ema_w else 0, e1 - s1, hp, self.momentum, self.l2_reg if (reg and not clipping) else 0.0,

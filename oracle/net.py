@@ -275,6 +275,14 @@ class Tape(object):
         self.bw.append(lambda: x.acc(ops.global_avgpool_bwd(y.g.reshape(n, c), x.a.shape)))
         return y
 
+    def stop_gradient(self, x):
+        """tf.stop_gradient (models/deeplabv3plus.py:53): the stored value of x, nothing flows back (g = False: consumers skip their data gradient)."""
+        self._mat(x)
+        y = V(x.a, None, fused=self.fused)
+        y.q = x.q
+        y.g = False
+        return y
+
     def resize(self, x, out_hw, align_corners=True):
         self._mat(x)
         y = V(ops.resize_bilinear_fwd(x.a, out_hw, align_corners), self.quant, fused=self.fused)
@@ -583,7 +591,7 @@ class DeepLabSpec(object):
     segmentation = True
 
     def __init__(self, num_classes=19, width_div=1, depth_div=1, strides=(2, 1, 2, 2, 2), res_units=(None, 3, 4, 6, 3),
-                 dilations=(None, 1, 1, 1, 2), aspp_dilations=(6, 12, 18)):
+                 dilations=(None, 1, 1, 1, 2), aspp_dilations=(6, 12, 18), aspp_level_feature=False, feature_gradients=(None, True)):
         """Defaults = ResNet50OS16 (resnet_v1_5_dilated.py:7-12,145); ResNet101OS16: strides (2,1,2,2,1), units (None,3,4,23,3)."""
         units = [None if u is None else max(1, u // depth_div) for u in res_units]
         self.backbone = ResNetSpec(channels=[64 // width_div] + [c // width_div for c in (256, 512, 1024, 2048)], strides=strides,
@@ -592,6 +600,8 @@ class DeepLabSpec(object):
         self.backbone_only = False
         self.feature_channels = [max(8, 256 // width_div), max(8, 48 // width_div)] if width_div > 1 else [256, 48]
         self.aspp_dilations = list(aspp_dilations)
+        self.aspp_level_feature = bool(aspp_level_feature)        # models/deeplabv3plus.py:90-99 (the reference's default: off)
+        self.feature_gradients = list(feature_gradients)          # models/deeplabv3plus.py:50-53: False = tf.stop_gradient on that backbone feature
 
     def variables(self):
         out = self.backbone.variables()
@@ -605,7 +615,9 @@ class DeepLabSpec(object):
         conv_bn('block_5/aspp/conv_0', 1, c4, fa)
         for i in range(len(self.aspp_dilations)):
             conv_bn('block_5/aspp/conv_{}'.format(i + 1), 3, c4, fa)
-        conv_bn('block_5/aspp/conv_out', 1, fa * (1 + len(self.aspp_dilations)), fa)
+        if self.aspp_level_feature:
+            conv_bn('block_5/aspp/conv_pool', 1, c4, fa)
+        conv_bn('block_5/aspp/conv_out', 1, fa * (1 + len(self.aspp_dilations) + (1 if self.aspp_level_feature else 0)), fa)
         conv_bn('block_6/features', 1, c1, fd)
         conv_bn('block_6/decoder/conv_0', 3, fa + fd, fa)
         out.append(('block_None/logits/weights', (1, 1, fa, self.num_classes), 'weight'))
@@ -620,8 +632,13 @@ class DeepLabSpec(object):
         for i, dil in enumerate(self.aspp_dilations):
             sc = 'block_5/aspp/conv_{}'.format(i + 1)
             ys.append(t.bn(t.conv(f4, sc, 1, 'SAME', dil), sc + '/norm'))
+        if self.aspp_level_feature:
+            y = t.bn(t.conv(t.mean_keepdims(f4), 'block_5/aspp/conv_pool', 1), 'block_5/aspp/conv_pool/norm')
+            ys.append(t.resize(y, f4.a.shape[1:3], False))
         h = t.bn(t.conv(t.concat(ys), 'block_5/aspp/conv_out', 1), 'block_5/aspp/conv_out/norm')
         d['block_5'] = h
+        if not self.feature_gradients[1]:
+            f1 = t.stop_gradient(f1)
         feat = t.bn(t.conv(f1, 'block_6/features', 1), 'block_6/features/norm')
         h = t.resize(h, feat.a.shape[1:3], True)
         h = t.bn(t.conv(t.concat([h, feat]), 'block_6/decoder/conv_0', 1), 'block_6/decoder/conv_0/norm')
@@ -766,13 +783,18 @@ def forward_loss(spec, state, x_raw, y_float, hp=None, train=True, use_ema=False
         c = spec.num_classes
         ls_f = float(hp.get('label_smoothing', 0.0))
         avg = ops.avgpool_fwd(onehot, 5, 1, 'SAME').reshape(-1, c) if ls_f > 0.0 else None       # segnet.py:117-122
-        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a.reshape(-1, c).astype(dt), onehot.reshape(-1, c), None, ls_f, avg_labels=avg)
+        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a.reshape(-1, c).astype(dt), onehot.reshape(-1, c), None, ls_f, avg_labels=avg,
+                                                              focal_gamma=float(hp.get('focal_loss_factor', 0.0)),
+                                                              sigmoid_focal_alpha=float(hp.get('sigmoid_focal_loss_factor', 0.0)))
         pred, dlogits = pred.reshape(out.a.shape), dlogits.reshape(out.a.shape)
     else:
         onehot = ops.one_hot_labels(y_float, spec.num_classes, dtype=dt)
-        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'])
+        pred, sm_loss, ce, dlogits = ops.softmax_xent_fwd_bwd(out.a, onehot, None, hp['label_smoothing'], focal_gamma=float(hp.get('focal_loss_factor', 0.0)),
+                                                              sigmoid_focal_alpha=float(hp.get('sigmoid_focal_loss_factor', 0.0)))
     weights = [v for k, v in params.items() if _regularised(k, hp)]
     loss = float(sm_loss) + ops.l2_reg_loss(weights, hp['l2_reg'])
+    if hp.get('l1_reg', 0.0) > 0.0:                                            # convnet.py:553-557
+        loss += ops.l1_reg_loss(weights, hp['l1_reg'])
     # loss scaling (optimizers.py:102-111): the loss is multiplied by the factor (only when > 1) before differentiation, so every
     # activation gradient is stored scaled — what matters under fp16 storage — and the parameter gradients are divided again
     ls = float(hp.get('loss_scaling_factor', 1.0))
@@ -844,6 +866,8 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
             state.ema[k] = (d * state.ema[k] + (1.0 - d) * state.params[k]).astype(state.params[k].dtype)
             continue
         is_w = _regularised(k, hp)
+        if is_w and hp.get('l1_reg', 0.0) > 0.0:              # d/dw l1 * |w| = l1 * sign(w): part of the gradient the update sees (and of the returned dict,
+            grads[k] = grads[k] + hp['l1_reg'] * np.sign(state.params[k])      # like the device's flat buffer after mcn_l1_grad_h; one tower)
         w, a, e = ops.sgd_nesterov_step(state.params[k], grads[k], state.accum[k], lr, hp['momentum'],
                                         l2=hp['l2_reg'] if (is_w and hp.get('gradient_threshold') is None) else 0.0, ema=state.ema[k], ema_d=d,
                                         wd=wd if is_w else 0.0, l1_decay=bool(hp.get('l1_weight_decay', False)),

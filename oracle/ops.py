@@ -525,12 +525,14 @@ def softmax(logits):
     return e / e.sum(axis=-1, keepdims=True)
 
 
-def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0, loss_scale=1.0, avg_labels=None):
+def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0, loss_scale=1.0, avg_labels=None, focal_gamma=0.0, sigmoid_focal_alpha=0.0):
     """pred = softmax(logits) (models/resnet_v1_5.py:78);
     valid = |sum(Y) - 1| < 1e-5 (convnet.py:567-573); batch_w = sum(Y * w) (convnet.py:552);
     labels = Y*(1-ls) + ls/C (convnet.py:603-607), or with `avg_labels` SegNet's Y*(1-ls) + ls*avg_pool2d(Y, 5x5, SAME)
     (segmentation/segnet.py:117-122: avg_labels = avgpool_fwd(Y, 5, 1, 'SAME') flattened like Y);
     CE_i = -sum_c labels_ic * log_softmax_ic (softmax_cross_entropy_with_logits_v2, convnet.py:600);
+    focal factors (convnet.py:581-592): CE_i *= (1 - p_t)^gamma, p_t = sum_c Y_ic pred_ic, differentiated through the softmax (tf.gradients does);
+    CE_i *= stop_gradient(1 - sigmoid(alpha (p_t - 0.5))) / (1 - sigmoid(-alpha / 2));
     softmax_loss = mean_i(batch_w_i * valid_i * CE_i) over ALL rows (convnet.py:594).
     Returns pred, softmax_loss, per-sample CE, dlogits (= d(loss_scale*softmax_loss)/dlogits)."""
     b, c = logits.shape
@@ -548,9 +550,28 @@ def softmax_xent_fwd_bwd(logits, onehot, class_weights=None, label_smoothing=0.0
     pred = np.exp(logsm)
     ce = -(labels * logsm).sum(axis=-1)
     coef = bw * valid
+    dce = pred * labels.sum(axis=-1, keepdims=True) - labels                 # d CE_i / d logits_i
+    if focal_gamma > 0 or sigmoid_focal_alpha > 0:
+        pt = (onehot * pred).sum(axis=-1)
+        F, dF, S = np.ones_like(pt), np.zeros_like(pt), np.ones_like(pt)
+        if focal_gamma > 0:
+            om = np.maximum(1.0 - pt, 0.0)
+            F = om ** focal_gamma
+            dF = np.where(om > 0, -focal_gamma * np.maximum(om, 1e-300) ** (focal_gamma - 1.0), 0.0)
+        if sigmoid_focal_alpha > 0:
+            sig = lambda v: 1.0 / (1.0 + np.exp(-v))                          # noqa: E731
+            S = (1.0 - sig(sigmoid_focal_alpha * (pt - 0.5))) / (1.0 - sig(-0.5 * sigmoid_focal_alpha))
+        dpt = onehot * pred - pt[:, None] * pred                              # d p_t / d logits (softmax Jacobian applied to Y)
+        dce = (F * S)[:, None] * dce + (ce * dF * S)[:, None] * dpt
+        ce = ce * F * S
     loss = (coef * ce).mean()
-    dlogits = (pred * labels.sum(axis=-1, keepdims=True) - labels) * (coef * (loss_scale / b))[:, None]
+    dlogits = dce * (coef * (loss_scale / b))[:, None]
     return pred.astype(dt), dt.type(loss), ce.astype(dt), dlogits.astype(dt)
+
+
+def l1_reg_loss(weights, l1_factor):
+    """l1_factor * sum_w sum |w| (convnet.py:553-557); its gradient is l1_factor * sign(w)."""
+    return l1_factor * sum(float(np.abs(w.astype(np.float64)).sum()) for w in weights)
 
 
 def l2_reg_loss(weights, l2_factor=1e-4):

@@ -15,9 +15,9 @@ from test_gpu_efficientnet import worst_grad  # noqa: E402  (BN -> conv -> BN ch
 B, SIZE, CLASSES = 4, 97, 6
 
 
-def make(dtype, fuse=True, **kw):
+def make(dtype, fuse=True, spec_kw=None, **kw):
     import myconvnet_amd as M
-    spec = ON.DeepLabSpec(CLASSES, width_div=8, depth_div=3, aspp_dilations=(1, 2, 3))
+    spec = ON.DeepLabSpec(CLASSES, width_div=8, depth_div=3, aspp_dilations=(1, 2, 3), **(spec_kw or {}))
     model = M.DeepLabV3PlusResNet50([SIZE, SIZE, 3], CLASSES, batch_size=B, width_div=8, depth_div=3, aspp_dilations=[1, 2, 3], fuse=fuse,
                                     half_precision=(dtype == 'bfloat16'), num_gpus=1, **kw)
     params, stats = ON.init_variables(spec.variables(), seed=6, dtype=np.float32)
@@ -77,7 +77,7 @@ def test_deeplab_label_smoothing_is_the_5x5_average_of_the_label_map():
     rng = np.random.default_rng(54)
     model, spec, params, stats = make('float32', label_smoothing=0.2)
     fns = [getattr(fn, '__name__', '') for fn, _ in model._train_low.fwd.calls]
-    assert 'mcn_softmax_xent_rows_soft_fwd_bwd' in fns and 'mcn_avgpool_fwd' in fns
+    assert 'mcn_softmax_xent_rows_focal_fwd_bwd' in fns and 'mcn_avgpool_fwd' in fns
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
     state, plain = ON.TrainState(f64(params), f64(stats)), ON.TrainState(f64(params), f64(stats))
     x, y = batch(rng)
@@ -92,6 +92,34 @@ def test_deeplab_label_smoothing_is_the_5x5_average_of_the_label_map():
     np.testing.assert_array_equal(y_true, O.seg_one_hot_labels(y, CLASSES))   # Y itself stays the raw one-hot map
     worst = worst_grad(model.get_variables('grad'), rgrads)
     assert worst[0] <= 1e-3, 'worst gradient {}'.format(worst)
+
+
+def test_deeplab_image_level_feature_and_stop_gradient():
+    """The reference's other branch of two head switches (off in its defaults): the ASPP image-level feature — global mean -> 1x1 conv -> norm ->
+    resize back, concatenated as a fifth ASPP branch (models/deeplabv3plus.py:90-99) — and tf.stop_gradient on the low-level backbone feature
+    (feature_gradients[i] = False, :50-53): block_1 then receives its gradient through the deeper blocks only."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(55)
+    head = dict(aspp_level_feature=True, feature_gradients=[None, False])
+    model, spec, params, stats = make('float32', spec_kw=head, **head)
+    assert 'block_5/aspp/conv_pool/weights' in params and any(n.op == 'stopgrad' for n in model.graph.nodes)
+    sg = [n for n in model.graph.nodes if n.op == 'stopgrad'][0]
+    assert sg.outputs[0].buf.data_ptr() == sg.inputs[0].buf.data_ptr() and not sg.outputs[0].needs_grad      # shared storage, no gradient path
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    state, plain = ON.TrainState(f64(params), f64(stats)), ON.TrainState(f64(params), f64(stats))
+    x, y = batch(rng)
+    model.feed(x, y)
+    loss, _, y_pred = opt._step(None)
+    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), y.astype(np.float64), batch_total=B)
+    assert abs(loss - rloss) <= 1e-4 * abs(rloss), (loss, rloss)
+    assert rel_l2(y_pred, rpred) <= 1e-4
+    worst = worst_grad(model.get_variables('grad'), rgrads)
+    assert worst[0] <= 2e-3, 'worst gradient {}'.format(worst)               # (the image-level branch normalises over M = B = 4 rows)
+    # the stop is visible: with the gradient flowing (same weights) block_1's gradients differ
+    spec2 = ON.DeepLabSpec(CLASSES, width_div=8, depth_div=3, aspp_dilations=(1, 2, 3), aspp_level_feature=True)
+    _, _, g2 = ON.train_step(spec2, plain, x.astype(np.float64), y.astype(np.float64), batch_total=B)
+    k = 'block_1/res_0/conv_0/weights'
+    assert rel_l2(g2[k], rgrads[k]) > 1e-3
 
 
 def test_deeplab_eval_on_ema():

@@ -225,6 +225,38 @@ def test_resnet_frozen_blocks_with_gradient_clipping(freeze):
                 assert not np.any(grads[k])                                   # nothing was folded into a frozen variable's slot
 
 
+def test_resnet_l1_regulariser_and_focal_losses():
+    """l1_reg, focal_loss_factor and sigmoid_focal_loss_factor together (convnet.py:529-533, 553-557, 581-592; all 0 in the reference's defaults): the
+    loss value, the gradients (the flat buffer holds data gradient + l1 * sign(w) once the update has run) and the updated variables."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(91)
+    hp = dict(l1_reg=1e-5, focal_loss_factor=2.0, sigmoid_focal_loss_factor=3.0)
+    model, spec, params, stats = make_resnet(18, 'float32', True, **hp)
+    names = [getattr(fn, '__name__', '') for fn, _ in model._train_low.fwd.calls]
+    assert 'mcn_softmax_xent_focal_fwd_bwd' in names and 'mcn_l1_loss' in names
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    assert 'mcn_l1_grad_h' in [getattr(fn, '__name__', '') for fn, _ in opt.optimization_operation.calls]
+    state, plain = (ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()}) for _ in range(2))
+    for step in range(2):
+        x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+        model.feed(x, LABELS)
+        loss, _, y_pred = opt._step(None)
+        rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=hp, batch_total=BATCH)
+        if step == 0:
+            ploss, _, _ = ON.train_step(spec, plain, x.astype(np.float64), LABELS.astype(np.float64), batch_total=BATCH)
+            assert abs(rloss - ploss) > 5e-2 * abs(ploss)                      # the three terms are visible at this size
+        assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, loss, rloss)
+        assert rel_l2(y_pred, rpred) <= 1e-4
+        grads = model.get_variables('grad')
+        worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads if np.linalg.norm(rgrads[k]) > 1e-9)
+        assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+        got = model.get_variables('data')
+        worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
+        assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
+    with pytest.raises(NotImplementedError):
+        M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, gradient_threshold=1.0)        # l1_reg + clipping: not built
+
+
 def test_resnet_fp32_bn_statistics_from_conv_epilogue():
     """fuse_bn_stats (default on for bf16 only) / defer_dskip: the fp32 network with the BN statistics taken in the conv
     epilogues and the residual fan-in applied in the dgrad epilogue / projection BN backward."""

@@ -465,6 +465,66 @@ def test_softmax_xent(ls):
     np.testing.assert_array_equal(u.host(pred).argmax(-1), pred_r.argmax(-1))          # integer arg-max bit-exact
 
 
+@pytest.mark.parametrize('focal', [dict(focal_gamma=2.0), dict(sigmoid_focal_alpha=4.0), dict(focal_gamma=1.5, sigmoid_focal_alpha=3.0)])
+@pytest.mark.parametrize('rows', [False, True])
+def test_softmax_xent_focal_factors(focal, rows):
+    """focal_loss_factor / sigmoid_focal_loss_factor (convnet.py:581-592) in both loss kernels: (1 - p_t)^gamma differentiated THROUGH the softmax,
+    the sigmoid factor under stop_gradient; with label smoothing, class weights, an ignored row and loss scaling.  (The oracle's gamma gradient is
+    checked against finite differences in tests/test_oracle_vs_torch.py::test_focal_gradient_matches_autograd.)"""
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    B, C = (300, 19) if rows else (9, 257)
+    fg, sa = focal.get('focal_gamma', 0.0), focal.get('sigmoid_focal_alpha', 0.0)
+    logits = (RNG.standard_normal((B, C)) * 2).astype(np.float32)
+    lab = RNG.integers(0, C, B)
+    oh = np.eye(C, dtype=np.float32)[lab]
+    oh[3] = 0.0                                                           # ignored row: p_t = 0, factor 1, weight 0
+    cw = (0.5 + RNG.random(C)).astype(np.float32)
+    ls = 0.0 if rows else 0.1
+    pred_r, loss_r, ce_r, dl_r = O.softmax_xent_fwd_bwd(logits.astype(np.float64), oh.astype(np.float64), cw.astype(np.float64), ls, 2.0, focal_gamma=fg,
+                                                        sigmoid_focal_alpha=sa)
+    plain = O.softmax_xent_fwd_bwd(logits.astype(np.float64), oh.astype(np.float64), cw.astype(np.float64), ls, 2.0)
+    assert abs(loss_r - plain[1]) > 1e-2 * abs(plain[1])                  # the factors are visible
+    pred, dl = [torch.zeros((B, C), dtype=torch.float32, device=u.DEV) for _ in range(2)]
+    ce, coef = [torch.zeros(B, dtype=torch.float32, device=u.DEV) for _ in range(2)]
+    loss = torch.zeros(4, dtype=torch.float32, device=u.DEV)
+    ld, ohd, cwd = u.dev(logits), u.dev(oh), u.dev(cw)
+    if rows:
+        ws = u.workspace(8192)
+        _ffi.check(lib.mcn_softmax_xent_rows_focal_fwd_bwd(ld.data_ptr(), ohd.data_ptr(), 0, cwd.data_ptr(), pred.data_ptr(), ce.data_ptr(), coef.data_ptr(), dl.data_ptr(),
+                                                           loss.data_ptr(), B, C, ls, 2.0, fg, sa, ws.data_ptr(), ws.numel() * 4, u.stream()))
+    else:
+        _ffi.check(lib.mcn_softmax_xent_focal_fwd_bwd(ld.data_ptr(), ohd.data_ptr(), cwd.data_ptr(), pred.data_ptr(), ce.data_ptr(), coef.data_ptr(), dl.data_ptr(),
+                                                      loss.data_ptr(), B, C, ls, 2.0, fg, sa, u.stream()))
+    check(u.host(pred), pred_r, 'float32', 'pred', rel=1e-5)
+    check(u.host(ce), ce_r, 'float32', 'factored ce', rel=2e-5)
+    check(u.host(dl), dl_r, 'float32', 'dlogits', rel=2e-5)
+    assert abs(u.host(loss)[0] - loss_r) <= 1e-5 * abs(loss_r)
+    assert lib.mcn_softmax_xent_focal_fwd_bwd(ld.data_ptr(), ohd.data_ptr(), 0, pred.data_ptr(), ce.data_ptr(), coef.data_ptr(), dl.data_ptr(), loss.data_ptr(), B, C, 0.0, 1.0,
+                                              -1.0, 0.0, u.stream()) == _ffi.E_BADARG
+
+
+def test_l1_regulariser_value_and_gradient():
+    """l1_reg (convnet.py:553-557): out += factor * sum |w|; gradient l1 * sign(w) added to the flat gradient divided by the tower factor the update
+    kernel multiplies back (hyper[3])."""
+    u = _u()
+    from myconvnet_amd import _ffi
+    lib = _ffi.lib
+    n = 100003
+    w = RNG.standard_normal(n).astype(np.float32)
+    w[::17] = 0.0
+    g0 = RNG.standard_normal(n).astype(np.float32)
+    wd, gd = u.dev(w), u.dev(g0)
+    out = torch.full((4,), 1.5, dtype=torch.float32, device=u.DEV)
+    ws = u.workspace(8192)
+    _ffi.check(lib.mcn_l1_loss(wd.data_ptr(), n, 1e-3, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, u.stream()))
+    assert abs(u.host(out)[0] - (1.5 + O.l1_reg_loss([w], 1e-3))) <= 1e-5 * (1.5 + O.l1_reg_loss([w], 1e-3))
+    hyper = u.dev(np.array([0.1, 0.0, 0.99, 0.25], np.float32))
+    _ffi.check(lib.mcn_l1_grad_h(gd.data_ptr(), wd.data_ptr(), n, 1e-3, hyper.data_ptr(), u.stream()))
+    np.testing.assert_allclose(u.host(gd), g0 + np.float32(1e-3 / 0.25) * np.sign(w), rtol=1e-6, atol=1e-7)
+
+
 def test_sgd_nesterov_ema_l2_trajectory():
     """3-step trajectory of the fused update vs the oracle (EMA of the pre-update value, L2 folded into the gradient)."""
     u = _u()

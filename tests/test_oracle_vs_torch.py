@@ -323,3 +323,33 @@ def test_torch_cpu_step_matches_oracle():
         np.testing.assert_allclose(tc.S[k].numpy(), v, rtol=1e-6, atol=1e-10, err_msg=k)
     for k, v in state.ema_stats.items():
         np.testing.assert_allclose(tc.ema_stats[k].numpy(), v, rtol=1e-6, atol=1e-10, err_msg=k)
+
+
+def test_focal_gradient_matches_autograd():
+    """focal_loss_factor / sigmoid_focal_loss_factor (convnet.py:581-592): the oracle's closed-form gradient against torch autograd of the reference's
+    own expression — pow(1 - sum(Y * softmax), gamma) differentiated through the softmax, the sigmoid factor detached (tf.stop_gradient)."""
+    rng = np.random.default_rng(31)
+    B, C = 6, 9
+    z = rng.standard_normal((B, C))
+    y = np.eye(C)[rng.integers(0, C, B)]
+    y[1] = 0.0
+    w = 0.5 + rng.random(C)
+    for fg, sa, ls in ((2.0, 0.0, 0.0), (0.0, 4.0, 0.0), (1.5, 3.0, 0.1)):
+        from oracle import ops as O
+        pred, loss, ce, dl = O.softmax_xent_fwd_bwd(z, y, w, ls, 1.0, focal_gamma=fg, sigmoid_focal_alpha=sa)
+        zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+        yt, wt = torch.tensor(y), torch.tensor(w)
+        p = torch.softmax(zt, -1)
+        labels = yt * (1 - ls) + ls / C if ls > 0 else yt
+        losses = -(labels * torch.log_softmax(zt, -1)).sum(-1)
+        pt = (yt * p).sum(-1)
+        if fg > 0:
+            losses = losses * torch.pow(1.0 - pt, fg)
+        if sa > 0:
+            losses = losses * ((1.0 - torch.sigmoid(sa * (pt - 0.5))).detach() / (1.0 - torch.sigmoid(torch.tensor(-0.5 * sa, dtype=torch.float64))))
+        sy = yt.sum(-1)
+        valid = ((sy > 1 - 1e-5) & (sy < 1 + 1e-5)).double()
+        tl = ((yt * wt).sum(-1) * valid * losses).mean()
+        tl.backward()
+        assert abs(float(tl) - float(loss)) <= 1e-12 * abs(float(loss))
+        np.testing.assert_allclose(dl, zt.grad.numpy(), rtol=1e-10, atol=1e-13)
