@@ -478,6 +478,7 @@ def test_softmax_xent_focal_factors(focal, rows):
     fg, sa = focal.get('focal_gamma', 0.0), focal.get('sigmoid_focal_alpha', 0.0)
     logits = (RNG.standard_normal((B, C)) * 2).astype(np.float32)
     lab = RNG.integers(0, C, B)
+    logits[np.arange(B), lab] += 5.0                                      # p_t of a sizeable fraction: the factors matter
     oh = np.eye(C, dtype=np.float32)[lab]
     oh[3] = 0.0                                                           # ignored row: p_t = 0, factor 1, weight 0
     cw = (0.5 + RNG.random(C)).astype(np.float32)
