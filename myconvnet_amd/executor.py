@@ -417,8 +417,12 @@ class Lowering(object):
                 # x = y_b = relu(bn(u_b) + skip_b) and this launch writes its COMPLETE gradient (this dgrad + the next unit's masked fan-in): the
                 # backward sums of that unit's output BN ride in the same epilogue (bwd_bn then runs mcn_bn_bwd_from_partials: no reduction pass)
                 pa = red.attrs
-                rows = int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(gm), self.dt))
-                pa['bwd_red'] = (torch.zeros((rows, 2, x.shape[-1]), dtype=torch.float32, device=self.g.device), gm, n)
+                keep, cand = gm.tile, []
+                for t in range(lib.mcn_conv2d_tile_candidates(_ffi.CONV_DGRAD) + 1):        # room for any tile the autotuner may pin
+                    gm.tile = t
+                    cand.append(int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(gm), self.dt)))
+                gm.tile = keep
+                pa['bwd_red'] = (torch.zeros((max(cand), 2, x.shape[-1]), dtype=torch.float32, device=self.g.device), gm, n)
                 self.bwd.add(lib.mcn_conv2d_dgrad_addmasked_bnred, y.grad.data_ptr(), w.data.data_ptr(), self.wp(n, _ffi.CONV_DGRAD), x.grad.data_ptr(), lazy[0], lazy[1],
                              red.inputs[0].buf.data_ptr(), pa['relu_mask'].data_ptr(), pa['bwd_red'][0].data_ptr(), ctypes.byref(gm), self.dt, _ffi.NHWC,
                              self.ws_ptr, self.ws_bytes)
