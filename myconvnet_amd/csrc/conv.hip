@@ -279,7 +279,7 @@ static size_t wgrad_ws_bytes(const Geo& g, mcn_dtype dt) {
     return b;
 }
 
-extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 5; }      /* (the 256x256 wgrad tile of the 2-byte types is chosen by rule, not a candidate) */    /* NT: 128x128, 128x64, 64x64, 256x128 / 8 waves and 128x128 / 8 waves (2-byte types); TN: 4 shapes */
+extern "C" int mcn_conv2d_tile_candidates(mcn_conv_op op) { return op == MCN_CONV_WGRAD ? 4 : 6; }      /* (the 256x256 wgrad tile of the 2-byte types is chosen by rule, not a candidate) */    /* NT: 128x128, 128x64, 64x64, 256x128 / 8 waves and 128x128 / 8 waves (2-byte types); TN: 4 shapes */
 
 extern "C" size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* gg, mcn_dtype dtype) {
     Geo g;
@@ -315,12 +315,14 @@ static bool allow_lds(K kernel, int bytes) {
 // (conv fwd+dgrad 38.4 ms vs 41.5 ms per step with 128x128); bf16 is LDS-bandwidth sensitive and keeps the big tiles.
 // (A body/tail split — big tiles for whole rounds, small tiles for the remainder in a second launch — was measured
 // and lost 4 %: the kernel boundary costs more than the shorter tail saves.)
-struct NtTile { int bm, bn, nw; };
+struct NtTile { int bm, bn, nw, wpp; };
 // candidate 3 (256x128, 8 waves) is bf16 only: fp32 is MFMA-bound and prefers the smallest tile
 // candidate 4 (128x128 on 8 waves of 32x64): half the accumulators and epilogue registers per wave -> 4 waves per SIMD instead of
 // 2 at the same tile / L2 traffic: for the memory- and epilogue-bound 1x1 layers of the 2-byte types (statistics / residual epilogues)
-static const NtTile kNtCand[5] = {{128, 128, 4}, {128, 64, 4}, {64, 64, 4}, {256, 128, 8}, {128, 128, 8}};
-#define MCN_NT_CANDS 5
+// candidates 5 / 6 (round 4; tile hint 6 picks the one that fits Cout): conv_gemm_nt_wpp — 3x3 / stride-1 window kernel of the 2-byte types, 256 x 128 or
+// 256 x 64 on 8 waves (double-buffered input window, filter ring, two wave groups one phase apart); geometries it does not take run candidate 3 / 1
+static const NtTile kNtCand[7] = {{128, 128, 4, 0}, {128, 64, 4, 0}, {64, 64, 4, 0}, {256, 128, 8, 0}, {128, 128, 8, 0}, {256, 128, 8, 1}, {256, 64, 8, 1}};
+#define MCN_NT_CANDS 7
 static inline double nt_tile_work(int c, size_t es) {
     static const double w[3] = {128.0 * 128, 128.0 * 64, 64.0 * 64};
     static const double f32[3] = {1.08, 1.03, 1.00}, bf16[3] = {1.00, 1.30, 1.70};      // (round 2: the 2-byte kernels are bound by L2 -> LDS
@@ -332,6 +334,7 @@ static int pick_nt_tile(int M, int Nn, int hint = 0) {
     hint &= 0xff;
     if (hint >= 1 && hint <= 3) return hint - 1;
     if ((hint == 4 || hint == 5) && sizeof(T) == 2 && Nn > 64) return hint - 1;      // the 8-wave tiles: 2-byte types only; otherwise the heuristic below
+    if (hint == 6 && sizeof(T) == 2) return Nn > 64 ? 5 : 6;                          // the window ping-pong kernel's two tile widths
     static const int forced = [] { const char* e = getenv("MCN_NT_TILE"); return e ? atoi(e) : -1; }();
     if ((forced == 4 || forced == 3) && sizeof(T) == 2 && Nn > 64) return forced;
     const NtTile* cand = kNtCand;
@@ -358,7 +361,7 @@ static int pick_nt_tile(int M, int Nn, int hint = 0) {
 // the tiles of a thin last round run faster than those of a full one, and the split cost 4 % of the step (per-layer +10-38 %).
 struct SkPlan { int body, tail, slices; size_t bytes; };
 // resident workgroups per CU: 160 KB of LDS / (2 buffers x (BM + BN) x 128 B); registers allow at least as many
-static const int kNtSlotsPerCU[MCN_NT_CANDS] = {2, 3, 5, 1, 2};
+static const int kNtSlotsPerCU[MCN_NT_CANDS] = {2, 3, 5, 1, 2, 1, 1};
 #define MCN_SK_MAX_ROUNDS 8          /* more whole rounds than this: the tail is too small a share of the layer to pay */
 #define MCN_SK_MIN_KSTEPS 4          /* K-steps per slice (below: prologue + partial traffic outweigh the MFMAs) */
 static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
@@ -420,6 +423,30 @@ static int nt_window_span(size_t es, int ntaps, int cpt, int sy, int sx, bool sa
 static bool nt_window_geom(const Geo& g, size_t es, int cpt, const NtTile& t) {
     if (!nt_window_enabled(es) || g.KH * g.KW < 2 || g.KH * g.KW > 32 || g.SH != 1 || g.SW != 1 || g.OH != g.H || g.OW != g.W || cpt % 8) return false;
     return nt_window_lds((g.KH - 1) * g.DH * g.W + (g.KW - 1) * g.DW, t) != 0;
+}
+
+// conv_gemm_nt_wpp (tile hint 6): 2-byte types, 3x3 taps (any dilation that keeps the window in 376 rows), stride 1, output grid = input grid,
+// whole 64-channel K-steps per tap.  The one place that decides: every caller turns the geometry's hint into the effective one with nt_hint().
+#define MCN_WPP_MAX_SPAN (WPP_WROWS - 8 - 256)
+static bool nt_wpp_geom(const Geo& g, mcn_dtype dtype, bool dgrad) {
+    if (mcn_dtype_size(dtype) != 2 || g.KH != 3 || g.KW != 3 || g.SH != 1 || g.SW != 1 || g.OH != g.H || g.OW != g.W) return false;
+    const int ce = ce_of(dtype), cpt = round_up(dgrad ? g.Cout : g.Cin, ce) / ce;
+    return cpt % 8 == 0 && 2 * g.DH * g.W + 2 * g.DW <= MCN_WPP_MAX_SPAN;
+}
+// Without a hint the kernel takes the layers it was measured faster on (MI355X, B = 256, bf16, us: fwd / fwd + statistics / dgrad / dgrad + masked add)
+//   14x14 256 -> 256: 56.1 / 56.4 / 55.3 / 60.2 against 65.4 / 66.8 / 65.0 / 68.3 of the best two-buffer tile;  7x7 512 -> 512: 49.2 / 49.9 / 49.6 / 51.8 against 59.3 / 61.4 / 61.1 / 64.4;
+//   28x28 128 -> 128 (two chunks = 18 K-steps per tile: the one-workgroup-per-CU prologue shows) 73.4 against 68.4, 56x56 64 -> 64 (one chunk, BN = 64) 112 against 82:
+// i.e. four or more 64-channel chunks per tap and a full 128-column tile.  MCN_NT_WPP: 0 = only on request (tile hint 6), 1 = forward, 2 = forward and dgrad (default).
+static int nt_wpp_level() {
+    static const int v = [] { const char* e = getenv("MCN_NT_WPP"); return e ? atoi(e) : 2; }();
+    return v;
+}
+static int nt_hint(const Geo& g, mcn_dtype dtype, bool dgrad) {
+    const int hint = g.tile & 0xff;
+    if (hint == 6 && !nt_wpp_geom(g, dtype, dgrad)) return (g.tile & ~0xff) | 4;      // the plain 256 x 128 / 8-wave tile (Cout <= 64: the heuristic)
+    if (hint == 0 && nt_wpp_level() >= (dgrad ? 2 : 1) && (dgrad ? g.Cout : g.Cin) >= 256 && (dgrad ? g.Cin : g.Cout) >= 128 && nt_wpp_geom(g, dtype, dgrad))
+        return (g.tile & ~0xff) | 6;
+    return g.tile;
 }
 
 // epilogue variant of a launch: the accumulate modes have their own instantiation (batched loads), so do the BN statistics, the BN-backward
@@ -599,6 +626,45 @@ static int launch_nt_pers(const GemmNTParams& p, int tile, long W, hipStream_t s
     return MCN_OK;
 }
 
+// conv_gemm_nt_wpp: the geometry was admitted by nt_wpp_geom() (nt_hint) — checked again here from the GEMM parameters, loudly
+template <typename T>
+static int launch_nt_wpp(GemmNTParams p, const NtTile& t, long W, bool taps, hipStream_t st) {
+    const bool same_grid = p.OH == p.IH && p.OW == p.IW && p.osy == 1 && p.osx == 1 && p.OHf == p.OH && p.OWf == p.OW;
+    if (!taps || p.ntaps != 9 || p.cpt % 8 || p.sy != 1 || p.sx != 1 || !same_grid) MCN_FAIL(MCN_E_UNSUPPORTED, "conv: window ping-pong tile on a geometry it does not take");
+    int dmin = 0x7fffffff, dmax = -0x7fffffff;
+    for (int k = 0; k < p.ntaps; ++k) {
+        const int d = (int)(short)(p.tap[k] & 0xffff) * p.IW + (p.tap[k] >> 16);
+        if (d < dmin) dmin = d;
+        if (d > dmax) dmax = d;
+    }
+    if (dmax - dmin > MCN_WPP_MAX_SPAN) MCN_FAIL(MCN_E_UNSUPPORTED, "conv: window ping-pong tile: the taps span more rows than the window holds");
+    p.win_dmin = dmin;
+    p.win_rows = 256 + (dmax - dmin);
+    const int epi = nt_epi_of(p);
+    const dim3 grid((unsigned)W), block(512);
+#define MCN_LAUNCH_WPP_E(BNV, EPIV)                                                                                      \
+    do {                                                                                                                 \
+        constexpr int lds = 2 * WPP_WROWS * 128 + 3 * BNV * 128;                                                         \
+        static const bool ok = allow_lds(conv_gemm_nt_wpp<T, BNV, EPIV>, lds);                                           \
+        if (!ok) MCN_FAIL(MCN_E_UNSUPPORTED, "conv: the runtime refused the window ping-pong kernel's LDS request");         \
+        hipLaunchKernelGGL((conv_gemm_nt_wpp<T, BNV, EPIV>), grid, block, lds, st, p);                                   \
+    } while (0)
+#define MCN_LAUNCH_WPP(BNV)                                                          \
+    do {                                                                             \
+        if (epi == NT_EPI_STATS) MCN_LAUNCH_WPP_E(BNV, NT_EPI_STATS);                \
+        else if (epi == NT_EPI_ACC) MCN_LAUNCH_WPP_E(BNV, NT_EPI_ACC);               \
+        else if (epi == NT_EPI_BNRED) MCN_LAUNCH_WPP_E(BNV, NT_EPI_BNRED);           \
+        else if (epi == NT_EPI_ACCRED) MCN_LAUNCH_WPP_E(BNV, NT_EPI_ACCRED);         \
+        else MCN_LAUNCH_WPP_E(BNV, NT_EPI_STORE);                                    \
+    } while (0)
+    if (t.bn == 128) MCN_LAUNCH_WPP(128);
+    else MCN_LAUNCH_WPP(64);
+#undef MCN_LAUNCH_WPP
+#undef MCN_LAUNCH_WPP_E
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+
 // sk_ws: scratch for the stream-K partials (may be null / too small: the conv then runs unsplit)
 template <typename T>
 static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
@@ -610,6 +676,12 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
     // the epilogue addresses the output through a buffer descriptor: images x full output grid x channel stride
     p.out_bytes = (unsigned)((size_t)(p.M / (p.OH * p.OW)) * p.OHf * p.OWf * p.ldo * sizeof(T));
     const long W = (long)((p.M + t.bm - 1) / t.bm) * ((p.Nn + t.bn - 1) / t.bn);
+    static const int epi_flags = [] { const char* e = getenv("MCN_NT_EPI_FLAGS"); return e ? atoi(e) : 0; }();
+    p.epi_flags = epi_flags;
+    if (t.wpp) {
+        if constexpr (sizeof(T) == 2) return launch_nt_wpp<T>(p, t, W, taps, st);
+        else MCN_FAIL(MCN_E_UNSUPPORTED, "conv: the window ping-pong tiles are for the 2-byte types only");
+    }
     int mode = !taps ? NT_LINEAR : ((p.cpt % 8 == 0) ? NT_UNIFORM : NT_GENERIC);
     if (mode == NT_UNIFORM) {
         const bool same_grid = p.OH == p.IH && p.OW == p.IW && p.osy == 1 && p.osx == 1 && p.OHf == p.OH && p.OWf == p.OW;
@@ -621,8 +693,6 @@ static int launch_nt(GemmNTParams p, bool taps, int tile_hint, hipStream_t st, v
             p.win_rows = t.bm + span;
         }
     }
-    static const int epi_flags = [] { const char* e = getenv("MCN_NT_EPI_FLAGS"); return e ? atoi(e) : 0; }();
-    p.epi_flags = epi_flags;
     const SkPlan sp = sk_plan(tile, W, (p.nchunks + 7) >> 3, sizeof(T));
     if ((tile_hint & MCN_TILE_NOSPLIT) || sp.slices < 2 || !sk_ws || sk_ws_bytes < sp.bytes) {
         const int epi = nt_epi_of(p);
@@ -908,7 +978,7 @@ static int conv_fwd_t(const void* x, const float* w, const void* w_packed, const
     const bool linear = ntaps == 1 && g.SH == 1 && g.SW == 1 && g.pT == 0 && g.pL == 0 && g.OH == g.H && g.OW == g.W;
     // workspace: [packed weights unless the caller keeps them | stream-K partials]
     const size_t used = w_packed ? 0 : need;
-    return launch_nt<T>(p, !linear, g.tile, st, ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0);
+    return launch_nt<T>(p, !linear, nt_hint(g, DtypeOf<T>::value, false), st, ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0);
 }
 
 extern "C" int mcn_conv2d_fwd(const void* x, const float* w, const void* w_packed, const float* bias, void* y, const mcn_conv_geom* gg,
@@ -938,15 +1008,15 @@ extern "C" int32_t mcn_conv2d_bnstats_rows(const mcn_conv_geom* gg, mcn_dtype dt
     if (M <= 0) return 0;
     if (wino_fwd_ok(g, dtype)) return wino_rows(g);      // counted rows [rows][4][Cout] (*rows_per_partial stays 0)
     const NtTile* cand = kNtCand;
-    const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
+    const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, nt_hint(g, dtype, false)) : pick_nt_tile<bf16_t>((int)M, g.Cout, nt_hint(g, dtype, false));
     const int wrows = cand[t].nw / 2;
     // counted rows (rows_per_partial = -BN): one row per persistent workgroup (its wave rows are merged in the flush), [4][BN] floats each
     const int ce = ce_of(dtype), cpt = round_up(g.Cin, ce) / ce;
     const int mode = conv_is_linear(g) ? NT_LINEAR : NT_UNIFORM;
     long grid = 0;
-    const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
-                         : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid)
-                                            : nt_stats_counted<bf16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, g.tile, &grid);
+    const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, g.KH * g.KW * cpt, t, nt_hint(g, dtype, false), &grid)
+                         : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, nt_hint(g, dtype, false), &grid)
+                                            : nt_stats_counted<bf16_t>(mode, M, g.Cout, g.KH * g.KW * cpt, t, nt_hint(g, dtype, false), &grid);
     if (counted) {
         // compact counted rows: keyed by the channel block of the persistent workgroup (conv_kernels.h, nt_stats_flush)
         if (rows_per_partial) *rows_per_partial = -(g.Cout < cand[t].bn ? g.Cout : cand[t].bn);      // (a layer narrower than the tile: one block of Cout channels)
@@ -1095,14 +1165,14 @@ static int conv_dgrad_t(const void* dy, const float* w, const void* w_packed, vo
         p.add_src = add_src; p.add_mask = add_mask;
         p.red_x = red_x; p.red_mask = red_mask; p.red_part = red_part; p.red_row0 = red_row;
         if (red_part) {
-            const NtTile rt = kNtCand[pick_nt_tile<T>(p.M, p.Nn, g.tile)];
+            const NtTile rt = kNtCand[pick_nt_tile<T>(p.M, p.Nn, nt_hint(g, DtypeOf<T>::value, true))];
             red_row += (rt.nw / 2) * ((p.M + rt.bm - 1) / rt.bm);
         }
         p.in_bytes = (unsigned)((size_t)g.N * g.OH * g.OW * g.Cout * sizeof(T));
         p.wt_bytes = (unsigned)((size_t)g.Cin * c.nt * Cp * sizeof(T));
         const bool linear = c.nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
         const size_t used = w_packed ? 0 : need;
-        rc = launch_nt<T>(p, !linear, g.tile, st, ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0);
+        rc = launch_nt<T>(p, !linear, nt_hint(g, DtypeOf<T>::value, true), st, ws ? (char*)ws + used : nullptr, ws && ws_bytes > used ? ws_bytes - used : 0);
         if (rc) return rc;
         wsp += align_up((size_t)g.Cin * c.nt * Cp * sizeof(T), 256);
     }
@@ -1166,7 +1236,7 @@ extern "C" int32_t mcn_conv2d_dgrad_bnred_rows(const mcn_conv_geom* gg, mcn_dtyp
             if (!nt) continue;
             const int OHs = (g.H - py + g.SH - 1) / g.SH, OWs = (g.W - px + g.SW - 1) / g.SW;
             const long M = (long)g.N * OHs * OWs;
-            const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
+            const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, nt_hint(g, dtype, true)) : pick_nt_tile<bf16_t>((int)M, g.Cin, nt_hint(g, dtype, true));
             rows += (long)(kNtCand[t].nw / 2) * ((M + kNtCand[t].bm - 1) / kNtCand[t].bm);
         }
     return rows > 0x7fffffffl ? 0 : (int32_t)rows;
@@ -1560,15 +1630,16 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
         if (!mfma_path_ok(g, dtype)) { snprintf(buf, buflen, "naive_conv_fwd<%s>", tn); return 1; }
         if (wino_fwd_ok(g, dtype)) { snprintf(buf, buflen, "conv_wino_f2k3_w8<0, 0>"); return 1; }      /* (the trailing parameter is the epilogue: 1 = BN statistics) */
         const long M = (long)g.N * g.OH * g.OW;
-        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cout, g.tile);
+        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cout, nt_hint(g, dtype, false)) : pick_nt_tile<bf16_t>((int)M, g.Cout, nt_hint(g, dtype, false));
         const int cpt = round_up(g.Cin, ce) / ce;
         const int mode = conv_is_linear(g) ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
-        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cout, cpt, mcn_dtype_size(dtype), g.tile, NT_EPI_STATS)) {
+        if (cand[t].wpp) snprintf(buf, buflen, "conv_gemm_nt_wpp<%s, %d, 0>", tn, cand[t].bn);
+        else if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cout, cpt, mcn_dtype_size(dtype), nt_hint(g, dtype, false), NT_EPI_STATS)) {
             /* (answers for mcn_conv2d_fwd_bnstats; a biased launch, and by default a forward without statistics: conv_gemm_nt.  Epilogue 3 = counted statistics rows) */
-            const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, cpt, t, g.tile, nullptr)
-                                 : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, cpt, t, g.tile, nullptr)
-                                                    : nt_stats_counted<bf16_t>(mode, M, g.Cout, cpt, t, g.tile, nullptr);
+            const bool counted = dtype == MCN_F32   ? nt_stats_counted<float>(mode, M, g.Cout, cpt, t, nt_hint(g, dtype, false), nullptr)
+                                 : dtype == MCN_F16 ? nt_stats_counted<f16_t>(mode, M, g.Cout, cpt, t, nt_hint(g, dtype, false), nullptr)
+                                                    : nt_stats_counted<bf16_t>(mode, M, g.Cout, cpt, t, nt_hint(g, dtype, false), nullptr);
             snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, %d>", tn, cand[t].bm, cand[t].bn, cand[t].nw, counted ? 3 : 0);
         }
         else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
@@ -1593,12 +1664,13 @@ extern "C" int mcn_conv2d_kernel_name(mcn_conv_op op, const mcn_conv_geom* gg, m
             }
         const int OHs = (g.H + g.SH - 1) / g.SH, OWs = (g.W + g.SW - 1) / g.SW;
         const long M = (long)g.N * OHs * OWs;
-        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
+        const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, nt_hint(g, dtype, true)) : pick_nt_tile<bf16_t>((int)M, g.Cin, nt_hint(g, dtype, true));
         const int cpt = round_up(g.Cout, ce) / ce;
         const bool lin = g.KH * g.KW == 1 && nt0 == 1;
         const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-        if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
-        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cin, nt0 * cpt, mcn_dtype_size(dtype), g.tile)) snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        if (cand[t].wpp) snprintf(buf, buflen, "conv_gemm_nt_wpp<%s, %d, 0>", tn, cand[t].bn);
+        else if (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, cand[t])) snprintf(buf, buflen, "conv_gemm_nt_win<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
+        else if (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cin, nt0 * cpt, mcn_dtype_size(dtype), nt_hint(g, dtype, true))) snprintf(buf, buflen, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, cand[t].nw);
         else snprintf(buf, buflen, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>", tn, cand[t].bm, cand[t].bn, mode, cand[t].nw);
         return ncls;
     }
@@ -1656,12 +1728,13 @@ extern "C" int mcn_conv2d_launch_list(mcn_conv_op op, const mcn_conv_geom* gg, m
             if (!nt) continue;
             const int OHs = (g.H - py + g.SH - 1) / g.SH, OWs = (g.W - px + g.SW - 1) / g.SW;
             const long M = (long)g.N * OHs * OWs;
-            const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, g.tile) : pick_nt_tile<bf16_t>((int)M, g.Cin, g.tile);
+            const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, g.Cin, nt_hint(g, dtype, true)) : pick_nt_tile<bf16_t>((int)M, g.Cin, nt_hint(g, dtype, true));
             const bool lin = nt == 1 && zero_off && OHs == g.OH && OWs == g.OW;
             const int mode = lin ? NT_LINEAR : (cpt % 8 == 0 ? NT_UNIFORM : NT_GENERIC);
-            const int w = (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, kNtCand[t]))
+            const int w = kNtCand[t].wpp ? snprintf(buf + used, buflen - used, "conv_gemm_nt_wpp<%s, %d, 0>:%d\n", tn, kNtCand[t].bn, nt)
+                          : (mode == NT_UNIFORM && nt_window_geom(g, mcn_dtype_size(dtype), cpt, kNtCand[t]))
                               ? snprintf(buf + used, buflen - used, "conv_gemm_nt_win<%s, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, kNtCand[t].nw, nt)
-                          : (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cin, nt * cpt, mcn_dtype_size(dtype), g.tile))
+                          : (mode == NT_LINEAR && nt_pers_geom(t, M, g.Cin, nt * cpt, mcn_dtype_size(dtype), nt_hint(g, dtype, true)))
                               ? snprintf(buf + used, buflen - used, "conv_gemm_nt_pers<%s, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, kNtCand[t].nw, nt)
                               : snprintf(buf + used, buflen - used, "conv_gemm_nt<%s, %d, %d, %d, %d, 0>:%d\n", tn, kNtCand[t].bm, kNtCand[t].bn, mode, kNtCand[t].nw, nt);
             if (w < 0 || (size_t)w >= buflen - used) MCN_FAIL(MCN_E_BADARG, "launch_list: buffer too small");
@@ -1697,7 +1770,7 @@ extern "C" int32_t mcn_conv2d_kslices(mcn_conv_op op, const mcn_conv_geom* gg, m
         return 1;
     }
     if (M <= 0) return 1;
-    const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, Nn, g.tile) : pick_nt_tile<bf16_t>((int)M, Nn, g.tile);
+    const int t = dtype == MCN_F32 ? pick_nt_tile<float>((int)M, Nn, nt_hint(g, dtype, op == MCN_CONV_DGRAD)) : pick_nt_tile<bf16_t>((int)M, Nn, nt_hint(g, dtype, op == MCN_CONV_DGRAD));
     const long W = (long)((M + kNtCand[t].bm - 1) / kNtCand[t].bm) * ((Nn + kNtCand[t].bn - 1) / kNtCand[t].bn);
     return sk_plan(t, W, (nchunks + 7) >> 3, mcn_dtype_size(dtype)).slices;
 }

@@ -1366,6 +1366,182 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && NW == 4 && BM == 128 &&
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_gemm_nt_wpp (round 4, 2-byte types): 3x3 / stride-1 / same-grid convolutions (forward and dgrad) as 256 x BN tiles on 8 waves with
+//   * the tile's INPUT WINDOW (256 + 2 W + 2 pixel rows of one 64-channel chunk) kept in LDS across the nine taps and DOUBLE-BUFFERED: the window
+//     of chunk cb + 1 arrives — one 64-row pass per K-step, six passes — under the nine K-steps of chunk cb;
+//   * the filter tiles (BN rows x 128 B per (tap, chunk) K-step) on a ring of three LDS slots, the tile of step s + 2 issued during step s;
+//   * two wave groups ONE PHASE APART (waves 4-7 share their SIMDs with waves 0-3): while one group multiplies (32 MFMAs at BN = 128) the other reads
+//     its fragments and issues its DMAs; every phase ends at a workgroup barrier (the late group runs one extra barrier up front, the early
+//     group one at the end);
+//   * COUNTED vmcnt throughout: the chunk loop is unrolled over (window parity, tap), every K-step issues a fixed number of LDS-DMAs — a window pass
+//     in steps 0-5 of a chunk (past the last chunk: out of range, i.e. zeros into a buffer nobody reads again), the filter tile of step s + 2 in every
+//     step (past the end likewise) — so that "all DMAs up to the filter tile of step s have landed" is `s_waitcnt vmcnt(constant(tap))`.
+// Why this shape: the two-buffer kernels and the plain ring / ping-pong forms of this round spend their K-step in DMA ISSUE (an LDS-DMA among
+// ds_reads costs the issuing wave 100-185 cycles; 6-8 of them per 32 MFMAs): here a wave issues 2-3 per 32 MFMAs (profiles/round4_*probe*).
+// LDS: 2 x 384 window rows + 3 x BN filter rows, 128 B each = 144 KB at BN = 128: one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+#define WPP_WROWS 384           /* window rows per buffer: six staging passes of 64 rows (P = 256 + span <= 376 + at least one zero row) */
+template <typename T, int BN, int EPI>
+__global__ __launch_bounds__(512) void conv_gemm_nt_wpp(const GemmNTParams p) {
+    typedef MmaNT<T> MM;
+    static_assert(sizeof(T) == 2 && MM::SLABS == 2 && MM::MT == 16 && MM::CPS == 4, "2-byte types: 16x16x32 MFMA, two 64-byte slabs per 128-byte K-step");
+    constexpr int BM = 256, NW = 8, RPP = 64;
+    constexpr int WTM = 64, WTN = BN / 2;
+    constexpr int TM = WTM / MM::MT, TN = WTN / MM::MT;
+    constexpr int NB = BN / RPP;                          // filter-tile DMAs per wave and K-step
+    constexpr int WB = WPP_WROWS * 128;                   // bytes of one window buffer
+    constexpr int SB = BN * 128;                          // bytes of one filter ring slot
+    constexpr int WOFF = 3 * SB;                          // LDS: [filter ring (ds_read immediates reach every slot)] [window 0] [window 1]
+    constexpr int NTAPS = 9, WPASS = WPP_WROWS / RPP;     // 6 window passes per chunk
+    static_assert(2 * SB + (TN - 1) * MM::MT * 128 + 64 < 65536 && WB < 65536, "fragment reads address ring slots / window buffers through the 16-bit ds_read offset");
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef const __attribute__((address_space(3))) typename MM::Frag lds_frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char* const lds = (lds_char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.Nn + BN - 1) / BN;
+    const int ntm = (p.m_end - p.m_begin + BM - 1) / BM;
+    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = p.m_begin + (L / ntn) * BM, n0 = (L % ntn) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
+
+    const int P = p.win_rows;                             // BM + span rows hold pixels; rows P .. 383 are staged out of range (zeros)
+    const int crow = tid >> 3;
+    const int cid = (tid & 7) ^ ((crow >> 1) & 7);        // filter tile: source-side swizzle of the tile image (rows start at multiples of 16)
+    const int cidw = (tid & 7) ^ (crow & 7);              // window rows are read at arbitrary row offsets: key = row & 7 (64 % 8 == 0: pass-invariant)
+    const int kpt = p.cpt >> 3;                           // 64-channel chunks
+    // everything a K-step needs is ADDRESS ARITHMETIC HOISTED OUT OF THE LOOP (measured: with ~85 VALU instructions per wave and K-step for the
+    // fragment addresses the load phase alone took 620 cycles against the 512 of the other group's 32 MFMAs):
+    //   * DMA sources: one byte offset per window pass / filter row block; a K-step adds a scalar (saturating: bit 31 = out of range = zeros);
+    //   * fragment reads: the LDS address of (tap, row block) for slab 0 (slab 1 = ^ 64; window buffer and ring slot ride in the instruction's offset).
+    unsigned b_off[NB], w_off[WPASS];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + crow + RPP * i;
+        b_off[i] = n < p.Nn ? (unsigned)n * (unsigned)p.nchunks * 16u + (unsigned)cid * 16u : MCN_OOB;
+    }
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) {
+        const int j = ps * RPP + crow;
+        const int q = m0 + p.win_dmin + j;                // input pixel of window row j
+        const unsigned bad = (unsigned)q | (unsigned)(p.M - 1 - q) | (unsigned)(P - 1 - j);     // sign bits
+        w_off[ps] = (bad >> 31) ? MCN_OOB : (unsigned)q * (unsigned)(p.Cs * (int)sizeof(T)) + (unsigned)cidw * 16u;
+    }
+    lds_char* const wbase = lds + __builtin_amdgcn_readfirstlane(wave * 1024);
+    // chunk offset of a DMA source (scalar): past the last chunk -> out of range, which keeps the DMA count of every K-step fixed
+    auto chunk_term = [&](int cb, int k128) -> unsigned { return cb < kpt ? (unsigned)k128 * 128u : MCN_OOB; };
+    // window pass `ps` (64 rows) of channel chunk cb into window buffer WSEL
+    auto issue_wpass = [&](int cb, auto wselc, auto psc) {
+        constexpr int WSEL = decltype(wselc)::value, ps = decltype(psc)::value;
+        const unsigned off = __builtin_elementwise_add_sat(w_off[ps], chunk_term(cb, cb));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(wbase + (WOFF + WSEL * WB + ps * RPP * 128)), 16, (int)off, 0, 0, MCN_DMA_AUX_A);
+    };
+    // filter tile of K-step (cb, t) into ring slot S
+    auto issue_b = [&](int cb, int t, auto setc) {
+        constexpr int S = decltype(setc)::value;
+        const unsigned koff = chunk_term(cb, t * kpt + cb);
+        static_for<NB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(wbase + (S * SB + i * RPP * 128)), 16,
+                                                     (int)__builtin_elementwise_add_sat(b_off[i], koff), 0, 0, 0);
+        });
+    };
+
+    const int fr = MM::frag_row(lane), fc = MM::frag_chunk(lane);
+    unsigned wa[NTAPS][TM];                               // slab 0 of (tap, row block) in window buffer 0; taps outside the image read the zero row P
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * MM::MT + fr;
+        const int hw = p.OH * p.OW;
+        const int rem = m - (m / hw) * hw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int tw = p.tap[t];
+            const int dy = (short)(tw & 0xffff), dx = tw >> 16;
+            const bool ok = m < p.m_end && (unsigned)(oy + dy) < (unsigned)p.IH && (unsigned)(ox + dx) < (unsigned)p.IW;
+            const int wr = wm * WTM + i * MM::MT + fr - p.win_dmin + dy * p.IW + dx;          // window row of this tap's input pixel
+            wa[t][i] = (unsigned)WOFF + (ok ? (unsigned)(wr << 7) + (unsigned)((fc ^ (wr & 7)) << 4) : (unsigned)(P << 7) + (unsigned)(fc << 4));
+        }
+    }
+    const unsigned ba = (unsigned)((wn * WTN + fr) * 128 + ((fc ^ ((fr >> 1) & 7)) << 4));      // slab 0 of the wave's filter rows in ring slot 0
+
+    typename MM::Acc acc[TN][TM];
+    nt_init_acc<T, TN, TM>(acc, p.bias, n0 + wn * WTN, p.Nn, lane);
+
+    typename MM::Frag xa[2][TM], wb[2][TN];
+    // all fragments of K-step (window buffer WSEL, tap TAP, ring slot S): 2 slabs x (TM + TN) ds_read_b128, one v_xor per slab-1 read
+    auto load_step = [&](auto tapc, auto wselc, auto setc) {
+        constexpr int TAP = decltype(tapc)::value, WSEL = decltype(wselc)::value, S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            xa[0][i] = *(lds_frag*)(lds + wa[TAP][i] + WSEL * WB);
+            xa[1][i] = *(lds_frag*)(lds + (wa[TAP][i] ^ 64u) + WSEL * WB);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            wb[0][j] = *(lds_frag*)(lds + ba + (S * SB + j * MM::MT * 128));
+            wb[1][j] = *(lds_frag*)(lds + (ba ^ 64u) + (S * SB + j * MM::MT * 128));
+        }
+    };
+    auto mma_set = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) MM::mma(acc[j][i], wb[set][j], xa[set][i]);
+    };
+
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+    auto bar = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // K-step (chunk cb, tap TAP) on window buffer WSEL.  DMAs of this step: [window pass TAP of chunk cb + 1 (TAP < 6)], then the filter tile of step
+    // s + 2.  "Everything up to the filter tile of step k has landed" leaves the DMAs of step k - 1 in flight: NB + (1 if step k - 1 staged a window pass).
+    auto pstep = [&](int cb, auto wselc, auto tapc) {
+        constexpr int WSEL = decltype(wselc)::value, TAP = decltype(tapc)::value;
+        constexpr int PREV = (TAP + NTAPS - 1) % NTAPS;                   // tap of the step in front of this one
+        constexpr int N_EARLY = NB + (PREV < WPASS ? 1 : 0);              // early group, in front of its load phase: waits for step s
+        constexpr int N_LATE = NB + (TAP < WPASS ? 1 : 0);                // late group, behind its load phase: waits for step s + 1
+        if (!late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_EARLY) : "memory");
+        bar();                                             // ---- load phase
+        load_step(tapc, wselc, std::integral_constant<int, TAP % 3>{});
+        if constexpr (TAP < WPASS) issue_wpass(cb + 1, std::integral_constant<int, WSEL ^ 1>{}, std::integral_constant<int, TAP>{});
+        {
+            // step s + 2 = (cb, TAP + 2) or (cb + 1, TAP + 2 - 9)
+            constexpr int T2 = (TAP + 2) % NTAPS;
+            issue_b(cb + (TAP + 2 >= NTAPS ? 1 : 0), T2, std::integral_constant<int, (TAP + 2) % 3>{});
+        }
+        if (late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LATE) : "memory");
+        bar();                                             // ---- compute phase
+        __builtin_amdgcn_s_setprio(1);
+        mma_set(0);
+        mma_set(1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: the whole window of chunk 0, the filter tiles of steps 0 and 1
+    static_for<WPASS>([&](auto pc) { issue_wpass(0, std::integral_constant<int, 0>{}, pc); });
+    issue_b(0, 0, std::integral_constant<int, 0>{});
+    issue_b(0, 1, std::integral_constant<int, 1>{});
+    if (late) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");        // window 0 and the tile of step 0 (the tile of step 1 stays in flight)
+        bar();
+    }
+    for (int cb = 0; cb < kpt; cb += 2) {
+        static_for<NTAPS>([&](auto tc) { pstep(cb, std::integral_constant<int, 0>{}, tc); });
+        if (cb + 1 < kpt) static_for<NTAPS>([&](auto tc) { pstep(cb + 1, std::integral_constant<int, 1>{}, tc); });
+    }
+    if (!late) bar();                                      // pairs with the late group's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the out-of-range DMAs behind the last step)
+    nt_epilogue<T, BM, BN, true, NW, EPI>(p, acc, m0, n0, lane, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_gemm_tn (wgrad): tile = 128 rows of (tap,c) x BN columns (cout), reduction over pixels
 // ------------------------------------------------------------------------------------------------
 template <typename T>

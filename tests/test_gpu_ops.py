@@ -906,7 +906,9 @@ def test_conv_dgrad_masked_residual_add_with_bn_backward_sums(case, dtype):
     np.testing.assert_array_equal(u.host(dx), dx_ref)
     p = u.host(part).astype(np.float64)
     assert not np.isnan(p).any()
-    bits = (fw['y'].reshape(-1, cin) > 0).astype(np.float64)
+    # (the unit's OWN mask bytes, not y > 0: a positive pre-activation below the storage type's smallest subnormal stores 0 with its bit set)
+    bits = ((np.asarray(fw['relu_mask']).reshape(-1, 1) >> np.arange(vec)) & 1).reshape(-1, cin).astype(np.float64)
+    assert np.abs(bits - (fw['y'].reshape(-1, cin) > 0)).sum() <= 2
     dxm = dx_ref.reshape(-1, cin).astype(np.float64) * bits
     xq = q(xbn, dtype).reshape(-1, cin)
     np.testing.assert_allclose(p[:, 0].sum(0), dxm.sum(0), rtol=2e-5, atol=2e-5 * np.abs(dxm).sum(0).max())
