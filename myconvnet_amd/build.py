@@ -29,6 +29,13 @@ HEADERS = _headers()
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-ffp-contract=fast']
+# MCN_KERNEL_PROBES=1 (set for the build AND for the run): compile the timing probes into the kernels (MCN_NT_EPI_FLAGS / MCN_TN_DBG skip a kind of
+# instruction — wrong results, timing only).  Off by default: as run-time branches they cost the K loops 0.6-0.8 % of the step.  Own object directory
+# and a different source digest, so that the two builds never mix.
+PROBES = os.environ.get('MCN_KERNEL_PROBES') == '1'
+if PROBES:
+    FLAGS.append('-DMCN_KERNEL_PROBES=1')
+    OBJ = os.path.join(CSRC, '_obj_probes')
 
 
 def source_digest():
@@ -38,6 +45,8 @@ def source_digest():
     for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), 'rb') as fh:
             h.update(f.encode() + b'\0' + fh.read() + b'\0')
+    if PROBES:
+        h.update(b'MCN_KERNEL_PROBES=1')
     return h.hexdigest()
 
 

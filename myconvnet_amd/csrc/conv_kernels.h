@@ -24,6 +24,13 @@
 
 #define MCN_MAX_TAPS 64
 #define MCN_OOB 0x80000000u
+// Timing probes inside the kernels (MCN_NT_EPI_FLAGS / MCN_TN_DBG: skip a kind of instruction, wrong results) are compiled in only with
+// -DMCN_KERNEL_PROBES=1: as run-time branches they split the K loop into basic blocks the scheduler does not interleave across
+// (measured on conv_gemm_nt_wpp: 49 us without, 60 us with four such branches in the loop, profiles/round4_nt_wpp_probe_bf16.txt).
+#ifndef MCN_KERNEL_PROBES
+#define MCN_KERNEL_PROBES 0
+#endif
+static constexpr bool MCN_PROBES = MCN_KERNEL_PROBES != 0;
 
 struct GemmNTParams {
     const void* in;
@@ -336,7 +343,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
     // odd ones, after which every lane owns 8 consecutive channels = one 16-byte access (loads of the accumulate path alike).
     constexpr bool PAIR = ES == 2;
     static_assert(!PAIR || (MM::MT == 16 && TM % 2 == 0), "lane pairing needs 16x16 accumulators and an even row-block count");
-    if (p.epi_flags & 32) return;                              // DEBUG probe (MCN_NT_EPI_FLAGS=32): no epilogue at all — timing only
+    if (MCN_PROBES && (p.epi_flags & 32)) return;                              // DEBUG probe (MCN_NT_EPI_FLAGS=32): no epilogue at all — timing only
     const int fr = MM::frag_row(lane);
     // first of the 4 consecutive output channels that accumulator group (j, g) holds in this lane
     auto col = [&](int j, int g) -> int { return n0 + wn * WTN + j * MM::MT + (MM::MT == 16 ? 4 * (lane >> 4) : 8 * g + 4 * (lane >> 5)); };
@@ -389,7 +396,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p,
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(lsrc), 0, (int)p.out_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(lmask), 0, masked ? (int)(p.out_bytes >> 4) : 0, 0x00020000);
         // one wide mask load per row block (instead of a byte per accumulator) when the wave's channel range is whole
-        const bool wide = masked && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)lmask & 15) == 0 && !(p.epi_flags & 2);
+        const bool wide = masked && p.Nn % WTN == 0 && (p.ldo / CEL) % MB == 0 && ((size_t)lmask & 15) == 0 && !(MCN_PROBES && (p.epi_flags & 2));
         unsigned mw[TM][MB / 4];
         const unsigned wcol = (unsigned)((n0 + wn * WTN) * ES) | (((unsigned)(p.Nn - 1 - (n0 + wn * WTN)) >> 31) << 31);
 #pragma unroll
@@ -867,7 +874,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : (sizeof(T) == 
             const int tw = p.tap[tap];
             const int dy = (short)(tw & 0xffff), dx = tw >> 16;
             const unsigned toff = (unsigned)((dy * p.IW + dx) * pix_bytes + cb * 128);
-            if (!((p.epi_flags & 8) && tap != 0))      // DEBUG probe (MCN_NT_EPI_FLAGS=8): A staged for the first tap only — wrong results, timing only
+            if (!(MCN_PROBES && (p.epi_flags & 8) && tap != 0))      // DEBUG probe (MCN_NT_EPI_FLAGS=8): A staged for the first tap only — wrong results, timing only
             static_for<AR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.IH && (unsigned)(a_x[i] + dx) < (unsigned)p.IW;
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : (sizeof(T) == 
             // K tail as arithmetic (bit 31 = out of range), not as a select: hipcc turned `kv ? off : OOB` into two DMA
             // instructions under complementary exec masks behind a branch — 12 DMAs and 11 branches per K-step instead of 8 and 0
             const unsigned oob = ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
-            if (!((p.epi_flags & 8) && ks != 0))
+            if (!(MCN_PROBES && (p.epi_flags & 8) && ks != 0))
             static_for<AR>([&](auto ic) { ldA(ic, (a_off[decltype(ic)::value] + (unsigned)ks * 128u) | oob); });
         } else {
             const int j = ks * 8 + cid;
@@ -895,7 +902,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && BM == 128 ? 4 : (sizeof(T) == 
             });
         }
         const unsigned oobb = MODE == NT_UNIFORM ? 0u : ((unsigned)(p.nchunks - 1 - (ks * 8 + cid)) >> 31) << 31;
-        if (!((p.epi_flags & 16) && ks % 9 != 0))      // DEBUG probe (MCN_NT_EPI_FLAGS=16): B staged every 9th K-step only
+        if (!(MCN_PROBES && (p.epi_flags & 16) && ks % 9 != 0))      // DEBUG probe (MCN_NT_EPI_FLAGS=16): B staged every 9th K-step only
         static_for<BR>([&](auto ic) { ldB(ic, (b_off[decltype(ic)::value] + (unsigned)ks * 128u) | oobb); });   // OOB + small stays OOB
     };
     typename MM::Acc acc[TN][TM];
@@ -1666,7 +1673,7 @@ __device__ __forceinline__ void tn_body(const GemmTNParams& p) {
         (__attribute__((address_space(3))) char*)smem + __builtin_amdgcn_readfirstlane(wave * 1024);
     auto issue = [&](int ks, auto bufc) {
         constexpr int B = decltype(bufc)::value;
-        if (!((p.dbg & 1) && ks != ks0))
+        if (!(MCN_PROBES && (p.dbg & 1) && ks != ks0))
         static_for<XN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + xpr + XPR * i;
@@ -1688,7 +1695,7 @@ __device__ __forceinline__ void tn_body(const GemmTNParams& p) {
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(wbase + (B * TILE_BYTES + i * (NT * 16))), 16, (int)off, 0, 0, MCN_DMA_AUX_X);
         });
-        if (!((p.dbg & 2) && ks != ks0))
+        if (!(MCN_PROBES && (p.dbg & 2) && ks != ks0))
         static_for<DN>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = ks * KP + dpr + DPR * i;
@@ -1721,7 +1728,7 @@ __device__ __forceinline__ void tn_body(const GemmTNParams& p) {
             static_assert(STAGES <= 4 && 2 * PER < 64, "vmcnt immediates of the ring");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (ks + STAGES - 1 < ks1) issue(ks + STAGES - 1, nxt);
-        } else if (p.dbg & 32) {
+        } else if (MCN_PROBES && (p.dbg & 32)) {
             // early issue: the next step's DMAs do not wait for THIS step's data — barrier (everybody has finished reading `nxt`), issue,
             // then wait for this step's DMAs only (the ones just issued stay in flight) and a second barrier to see the other threads' data
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
