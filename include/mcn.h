@@ -81,7 +81,9 @@ typedef struct {
 
 typedef enum { MCN_CONV_FWD = 0, MCN_CONV_DGRAD = 1, MCN_CONV_WGRAD = 2 } mcn_conv_op;
 
-/* number of tile shapes the given op can be forced to through mcn_conv_geom.tile (0: op takes no hint) */
+/* number of tile shapes the given op can be forced to through mcn_conv_geom.tile (0: op takes no hint).  Forward / dgrad: 1-3 = 128x128, 128x64, 64x64 on 4 waves;
+ * 4-5 = 256x128, 128x128 on 8 waves and 6 = the 3x3 window ping-pong kernel (conv_gemm_nt_wpp), 2-byte types only — a hint the geometry or dtype cannot take runs the
+ * library's own choice, never an error. */
 int mcn_conv2d_tile_candidates(mcn_conv_op op);
 /* bytes of workspace the given op needs for this geometry/dtype (0 is a valid answer) */
 size_t mcn_conv2d_workspace_bytes(mcn_conv_op op, const mcn_conv_geom* g, mcn_dtype dtype);
