@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(512) void conv_gemm_nt_wpp(const GemmNTParams p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
 
-    const int P = p.win_rows;                             // BM + span rows hold pixels; rows P .. 383 are staged out of range (zeros)
+    const int P = p.win_rows;                             // BM + span rows hold pixels; rows P .. 383 are staged out of range (zeros: at least the 8 rows behind P rounded up to 8)
     const int crow = tid >> 3;
     const int cid = (tid & 7) ^ ((crow >> 1) & 7);        // filter tile: source-side swizzle of the tile image (rows start at multiples of 16)
     const int cidw = (tid & 7) ^ (crow & 7);              // window rows are read at arbitrary row offsets: key = row & 7 (64 % 8 == 0: pass-invariant)
@@ -1472,7 +1472,12 @@ __global__ __launch_bounds__(512) void conv_gemm_nt_wpp(const GemmNTParams p) {
             const int dy = (short)(tw & 0xffff), dx = tw >> 16;
             const bool ok = m < p.m_end && (unsigned)(oy + dy) < (unsigned)p.IH && (unsigned)(ox + dx) < (unsigned)p.IW;
             const int wr = wm * WTM + i * MM::MT + fr - p.win_dmin + dy * p.IW + dx;          // window row of this tap's input pixel
-            wa[t][i] = (unsigned)WOFF + (ok ? (unsigned)(wr << 7) + (unsigned)((fc ^ (wr & 7)) << 4) : (unsigned)(P << 7) + (unsigned)(fc << 4));
+            // a tap outside the image reads zeros — from the zero row with the SAME bank image as the row it replaces (rows P8 + (wr & 7), P8 = P rounded up to 8:
+            // same row parity, same swizzle key): with one shared zero row the redirected lanes collide with their neighbours' banks and a fragment read with
+            // any border pixel in its 16-lane group takes 8 LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT 26 % of SQ_LDS_IDX_ACTIVE on the 7x7 layer -> 0; same-box A/B: no change in time,
+            // profiles/round4_pmc_layers_bf16.txt)
+            const int zr = ((P + 7) & ~7) + (wr & 7);
+            wa[t][i] = (unsigned)WOFF + (unsigned)((ok ? wr : zr) << 7) + (unsigned)((fc ^ (wr & 7)) << 4);
         }
     }
     const unsigned ba = (unsigned)((wn * WTN + fr) * 128 + ((fc ^ ((fr >> 1) & 7)) << 4));      // slab 0 of the wave's filter rows in ring slot 0
