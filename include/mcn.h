@@ -295,6 +295,17 @@ int mcn_channel_scale_bwd_dm(const void* dy, const void* x, void* dm, int32_t N,
 int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
                   const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C,
                   mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Round 4: the same pair with ONE pass fewer over the widest activations of an MBConv block.  mcn_channel_scale_bwd_dm_bnsums reads the BN's INPUT x (not the
+ * stored x_se: x_se = round(swish(bn(x))) is rebuilt on the fly, dm as above) and also writes per-image(-slice) sums, fp32, mcn_se_bwd_sums_floats() of them (dm partial, sum dy s', sum dy s' xh,
+ * sum s', sum s' xh; s' = swish'(bn(x)), xh = (x - mean) * invstd) from which mcn_bn_bwd_se_sums forms the BN-backward sums in a loop over N instead of its
+ * reduction pass (sum g s' = sum_n m A + dgap / HW B ...; g unrounded there: dgamma / dbeta equal mcn_bn_bwd_se's to fp32 summation accuracy, dx up to
+ * one rounding of the storage type around the two coefficients they feed).  Replaces efficientnet.py:152-163's backward like the pair above. */
+size_t mcn_se_bwd_sums_floats(int32_t N, int64_t HW, int32_t C, mcn_dtype dtype);      /* floats of `sums` for this shape (the pass slices every image's pixels over several workgroups) */
+int mcn_channel_scale_bwd_dm_bnsums(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dm,
+                                    float* sums, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream);
+int mcn_bn_bwd_se_sums(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_invstd, const float* sums, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C,
+                       mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* mcn_bn_bwd(act = ReLU, no fused residual) for a BN whose output feeds ONLY a 3x3 / stride-2 max-pool (the stem): takes the
  * pooled gradient [N,OH,OW,C] and the pool's arg-max and routes it inside its two passes; the full-resolution gradient of the BN

@@ -696,6 +696,123 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_se_kernel(const T* __restri
         }
     }
 }
+// ---- the reduction pass of mcn_bn_bwd_se folded into the channel scale's own reduction (round 4) -------------------------------------
+// The BN-backward sums over g = dy * m[n,c] + dgap[n,c] / HW separate per image:
+//   sum g * s'       = sum_n ( m[n,c] * A[n,c]  + dgap[n,c] / HW * B[n,c]  ),   A = sum_hw dy * s',        B = sum_hw s'
+//   sum g * s' * xh  = sum_n ( m[n,c] * A2[n,c] + dgap[n,c] / HW * B2[n,c] ),   A2 = sum_hw dy * s' * xh,  B2 = sum_hw s' * xh
+// (s' = swish'(bn(x)), xh = (x - mean) * invstd), and A, A2, B, B2 need neither the SE mask nor the pooled branch's gradient: the pass that
+// computes dm[n,c] = sum_hw dy * x_se — which must run BEFORE the SE branch's backward — produces them too, reading the BN's INPUT x and
+// rebuilding x_se = round_T(swish(bn(x))) from it (same two tensor reads as before), and the pass bn_bwd_reduce_se_kernel (two more reads of the widest
+// activations of the network per block) becomes a loop over [N][4][C] floats.  The sums are those of the unrounded g (the apply pass still
+// forms the rounded g per element): dgamma / dbeta agree with the three-step composition to fp32 summation accuracy, not bit for bit.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void se_bwd_pre_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums, long HW, int C,
+                                                         int TX, int TY, int HS, long rps) {
+    // grid.y = image x slice of its HW pixels (HS slices of rps rows: enough workgroups to fill the chip at every layer shape); sums: [N * HS][5][C], plane 0 = the dm partial
+    extern __shared__ float red[];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    const long n = blockIdx.y / HS;
+    const long r_lo = (long)(blockIdx.y % HS) * rps, r_hi = min(HW, r_lo + rps);
+    const bool active = ty < TY && col * VEC < C;
+    float acc[5][VEC];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+    if (active) {
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+        ldc<VEC>(mean + col * VEC, mu);
+        ldc<VEC>(invstd + col * VEC, is);
+        ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+        ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] *= is[i];
+            sh[i] -= mu[i] * sc[i];
+        }
+        for (long r = r_lo + ty; r < r_hi; r += TY) {
+            const long off = (n * HW + r) * C + (long)col * VEC;
+            float g[VEC], v[VEC];
+            ldv<T, VEC>(dy + off, g);
+            ldv<T, VEC>(x + off, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float z = fmaf(v[i], sc[i], sh[i]);
+                const float sig = fast_sigmoid(z);
+                const float xse = to_f32(from_f32<T>(z * sig));                   // the BN + swish output as the forward stored it
+                const float sp = sig * (1.f + z * (1.f - sig));                     // swish'(z)
+                const float xh = (v[i] - mu[i]) * is[i];
+                acc[0][i] = fmaf(g[i], xse, acc[0][i]);
+                const float gs = g[i] * sp;
+                acc[1][i] += gs;
+                acc[2][i] = fmaf(gs, xh, acc[2][i]);
+                acc[3][i] += sp;
+                acc[4][i] = fmaf(sp, xh, acc[4][i]);
+            }
+        }
+    }
+    const int cols = TX * VEC;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (ty < TY) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) red[ty * cols + tx * VEC + i] = acc[k][i];
+        }
+        __syncthreads();
+        if (ty == 0 && col * VEC < C) {
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float t = 0.f;
+                for (int q = 0; q < TY; ++q) t += red[q * cols + tx * VEC + i];
+                o[i] = t;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) sums[((long)blockIdx.y * 5 + k) * C + (long)col * VEC + i] = o[i];
+        }
+        __syncthreads();
+    }
+}
+// dm[n,c] = round_T(sum over the image's slices of plane 0)
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_dm_fold_kernel(const float* __restrict__ sums, T* __restrict__ dm, long NC, int C, int HS) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    const long n = i / C;
+    const int c = (int)(i - n * C);
+    float t = 0.f;
+    for (int h = 0; h < HS; ++h) t += sums[((n * HS + h) * 5) * C + c];
+    dm[i] = from_f32<T>(t);
+}
+// partial rows part[nb][0][c] = sum g * s', part[nb][1][c] = sum g * s' * xh over the images [nb * NB, nb * NB + NB) from the per-image(-slice) sums, the SE
+// mask and the pooled branch's gradient (bn_bwd_finalize_kernel adds the rows)
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_sums_kernel(const float* __restrict__ sums, const T* __restrict__ m, const T* __restrict__ dgap, float* __restrict__ part, int N, long HW, int C, int HS,
+                                                          int NB) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float inv_hw = 1.f / (float)HW;
+    float s1 = 0.f, s2 = 0.f;
+    const int n0 = blockIdx.y * NB, n1 = min(N, n0 + NB);
+    for (int n = n0; n < n1; ++n) {
+        const float mm = to_f32(m[(long)n * C + c]), q = to_f32(dgap[(long)n * C + c]) * inv_hw;
+        float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int h = 0; h < HS; ++h) {
+            const float* const sp = sums + ((long)n * HS + h) * 5 * C + c;
+            a1 += sp[(long)C];
+            a2 += sp[2 * (long)C];
+            b1 += sp[3 * (long)C];
+            b2 += sp[4 * (long)C];
+        }
+        s1 += fmaf(mm, a1, q * b1);
+        s2 += fmaf(mm, a2, q * b2);
+    }
+    part[((long)blockIdx.y * 2 + 0) * C + c] = s1;
+    part[((long)blockIdx.y * 2 + 1) * C + c] = s2;
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restrict__ dy, const T* __restrict__ m, const T* __restrict__ dgap, long HW, const T* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -1572,17 +1689,54 @@ extern "C" int mcn_bn_bwd_maxpool(const void* dy_pooled, const int8_t* argmax, c
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_maxpool: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
 }
 
+// launch shape of se_bwd_pre_kernel, shared with the consumers of its sums [N * HS][5][C] (mcn_se_bwd_sums_floats)
+struct SeBwdLayout { int TX, TY, gx, HS; long rps; };
+static SeBwdLayout se_bwd_layout(int N, long HW, int C, int vec) {
+    SeBwdLayout L;
+    const int cols = C / vec;
+    L.TX = 1;
+    for (int d = 1; d <= 32 && d <= cols; ++d)
+        if (cols % d == 0) L.TX = d;
+    if (L.TX < 8 && cols > 32) L.TX = 32;                         // awkward chunk counts: accept idle lanes
+    L.TY = 256 / L.TX;
+    L.gx = (cols + L.TX - 1) / L.TX;
+    // ~8 workgroups per CU, every slice at least 4 row passes of the block
+    long hs = (8L * 256 + (long)L.gx * N - 1) / ((long)L.gx * (N > 0 ? N : 1));      // (256 CUs)
+    const long cap = (HW + 4L * L.TY - 1) / (4L * L.TY);
+    if (hs > cap) hs = cap;
+    if (hs < 1) hs = 1;
+    L.rps = (HW + hs - 1) / hs;
+    L.HS = (int)((HW + L.rps - 1) / L.rps);
+    return L;
+}
+extern "C" size_t mcn_se_bwd_sums_floats(int32_t N, int64_t HW, int32_t C, mcn_dtype dtype) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    const int vec = dtype == MCN_F32 ? 4 : 8;
+    if (C % vec) return 0;
+    return (size_t)N * se_bwd_layout(N, (long)HW, C, vec).HS * 5 * C;
+}
 template <typename T, int VEC>
 static int bn_bwd_se_t(const void* dy, const void* m, const void* dgap, long HW, const void* x, const float* gamma, const float* beta, const float* save_mean,
-                       const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, long M, int C, void* ws, hipStream_t st) {
+                       const float* save_invstd, void* dx, float* dgamma, float* dbeta, float grad_scale, long M, int C, void* ws, hipStream_t st, const float* sums = nullptr) {
     const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
     float* part = (float*)ws;
     float* coef = (float*)((char*)ws + bn_parts_bytes(M, C));
     const dim3 grid(L.gx, L.gy), block(256);
-    hipLaunchKernelGGL((bn_bwd_reduce_se_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)m, (const T*)dgap, HW, (const T*)x, save_mean,
-                       save_invstd, gamma, beta, part, M, C, L.TX, L.TY, L.rpb);
+    int nparts = L.gy;
+    if (sums) {                                                   // the per-image sums of mcn_channel_scale_bwd_dm_bnsums: no pass over the activations
+        const int N = (int)(M / HW);
+        const int rows = N < 64 ? N : 64;                         // partial rows: the workspace holds L.gy of them
+        const int use = rows < L.gy ? rows : L.gy;
+        const int NB = (N + use - 1) / use;
+        nparts = (N + NB - 1) / NB;
+        hipLaunchKernelGGL((se_bwd_sums_kernel<T>), dim3((C + 255) / 256, nparts), dim3(256), 0, st, sums, (const T*)m, (const T*)dgap, part, N, HW, C,
+                           se_bwd_layout(N, HW, C, VEC).HS, NB);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_reduce_se_kernel<T, VEC>), grid, block, 2 * 256 * VEC * sizeof(float), st, (const T*)dy, (const T*)m, (const T*)dgap, HW, (const T*)x, save_mean,
+                           save_invstd, gamma, beta, part, M, C, L.TX, L.TY, L.rpb);
+    }
     MCN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, L.gy, M, C, gamma, save_invstd, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)part, nparts, M, C, gamma, save_invstd, dgamma,
                        dbeta, grad_scale, coef, 0);
     MCN_CHECK_LAUNCH();
     hipLaunchKernelGGL((bn_bwd_apply_se_kernel<T, VEC>), grid, block, 0, st, (const T*)dy, (const T*)m, (const T*)dgap, HW, (const T*)x, save_mean, save_invstd, gamma, beta,
@@ -1605,6 +1759,46 @@ extern "C" int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dg
     if (dtype == MCN_BF16 && C % 8 == 0) return bn_bwd_se_t<bf16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
     if (dtype == MCN_F16 && C % 8 == 0) return bn_bwd_se_t<f16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st);
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
+}
+
+// mcn_bn_bwd_se with the reduction pass replaced by the per-image sums of mcn_channel_scale_bwd_dm_bnsums (sums: fp32 [N][4][C])
+extern "C" int mcn_bn_bwd_se_sums(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                                  const float* save_invstd, const float* sums, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C,
+                                  mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    const int64_t M = (int64_t)N * HW;
+    if (!dy || !se_mask || !dgap || !x || !dx || !save_mean || !save_invstd || !sums || N <= 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_bwd_se_sums: bad argument");
+    if (M >= 0xffffffffll) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se_sums: more than 2^32 pixels");
+    if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_bwd_se_sums: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32 && C % 4 == 0) return bn_bwd_se_t<float, 4>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st, sums);
+    if (dtype == MCN_BF16 && C % 8 == 0) return bn_bwd_se_t<bf16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st, sums);
+    if (dtype == MCN_F16 && C % 8 == 0) return bn_bwd_se_t<f16_t, 8>(dy, se_mask, dgap, (long)HW, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, (long)M, C, ws, st, sums);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se_sums: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
+}
+template <typename T, int VEC>
+static int se_bwd_pre_t(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dm, float* sums, int N, long HW, int C,
+                        hipStream_t st) {
+    const SeBwdLayout L = se_bwd_layout(N, HW, C, VEC);
+    const dim3 grid((unsigned)L.gx, (unsigned)(N * L.HS)), block(256);
+    hipLaunchKernelGGL((se_bwd_pre_kernel<T, VEC>), grid, block, (size_t)L.TY * L.TX * VEC * sizeof(float), st, (const T*)dy, (const T*)x, save_mean, save_invstd, gamma, beta, sums, HW, C,
+                       L.TX, L.TY, L.HS, L.rps);
+    MCN_CHECK_LAUNCH();
+    const long NC = (long)N * C;
+    hipLaunchKernelGGL((se_bwd_dm_fold_kernel<T>), dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, (const float*)sums, (T*)dm, NC, C, L.HS);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+// dm[n,c] = sum_hw dy * x_se (what mcn_channel_scale_bwd_dm gives on the stored x_se) from the BN's INPUT x — x_se = round(swish(bn(x))) is rebuilt on
+// the fly — plus the per-image sums [N][4][C] (sum dy s', sum dy s' xh, sum s', sum s' xh) that let mcn_bn_bwd_se_sums skip its reduction pass
+extern "C" int mcn_channel_scale_bwd_dm_bnsums(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dm,
+                                               float* sums, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream) {
+    if (!dy || !x || !dm || !sums || !save_mean || !save_invstd || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_bwd_dm_bnsums: bad argument");
+    if (N == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32 && C % 4 == 0) return se_bwd_pre_t<float, 4>(dy, x, gamma, beta, save_mean, save_invstd, dm, sums, N, (long)HW, C, st);
+    if (dtype == MCN_BF16 && C % 8 == 0) return se_bwd_pre_t<bf16_t, 8>(dy, x, gamma, beta, save_mean, save_invstd, dm, sums, N, (long)HW, C, st);
+    if (dtype == MCN_F16 && C % 8 == 0) return se_bwd_pre_t<f16_t, 8>(dy, x, gamma, beta, save_mean, save_invstd, dm, sums, N, (long)HW, C, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "channel_scale_bwd_dm_bnsums: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
 }
 
 // groups of rpg rows of [nparts][2][C] sums -> fold[(g*2 + {0,1})*C + c] (summed in double, fixed order)

@@ -514,6 +514,35 @@ extern "C" int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dg
     });
 }
 
+// round 4: the pair with the BN-backward sums taken from per-image sums (mcn.h).  Here: dm from the rebuilt x_se, the sums left at zero, and
+// mcn_bn_bwd_se_sums = mcn_bn_bwd_se (the exact composition: what the GPU pair approximates to fp32 summation accuracy)
+extern "C" size_t mcn_se_bwd_sums_floats(int32_t N, int64_t, int32_t C, mcn_dtype) { return N > 0 && C > 0 ? (size_t)N * 5 * C : 0; }
+extern "C" int mcn_channel_scale_bwd_dm_bnsums(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dm,
+                                               float* sums, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void*) {
+    if (!dy || !x || !dm || !sums || !save_mean || !save_invstd || N < 0 || HW <= 0 || C <= 0) return fail(MCN_E_BADARG, "channel_scale_bwd_dm_bnsums: bad argument");
+    return by_dtype(dtype, "channel_scale_bwd_dm_bnsums", [&](auto s) {
+        typedef decltype(s) S;
+        typedef typename S::T T;
+        std::vector<T> xse((size_t)N * HW * C);
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < (int64_t)N * HW; ++r)
+            for (int c = 0; c < C; ++c) {
+                const float sc = (gamma ? gamma[c] : 1.f) * save_invstd[c], sh = (beta ? beta[c] : 0.f) - save_mean[c] * sc;
+                const float z = fmaf(S::ld((const T*)x + r * C + c), sc, sh);
+                S::st(xse.data() + r * C + c, z * sigmoidf(z));
+            }
+        chscale_dm<S>(dy, xse.data(), dm, N, HW, C);
+        std::fill(sums, sums + (size_t)N * 5 * C, 0.f);
+        return (int)MCN_OK;
+    });
+}
+extern "C" int mcn_bn_bwd_se_sums(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                                  const float* save_invstd, const float* sums, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C,
+                                  mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!sums) return fail(MCN_E_BADARG, "bn_bwd_se_sums: bad argument");
+    return mcn_bn_bwd_se(dy, se_mask, dgap, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, grad_scale, N, HW, C, dtype, ws, ws_bytes, stream);
+}
+
 // ---- depthwise convolution, multiplier 1 (convnet.py:1645) ------------------------------------------------------------------------------
 extern "C" size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom*, mcn_dtype) { return 0; }
 extern "C" int mcn_dwconv2d_fwd(const void* x, const float* w, void* y, const mcn_conv_geom* gg, mcn_dtype dtype, void*) {

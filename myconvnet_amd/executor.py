@@ -43,6 +43,7 @@ class Lowering(object):
         self.fused_gaps = set()        # ids of global-average nodes whose forward runs inside the BN apply pass in front of them
         self.dw_wgrad_side = bool(model._parameters.get('dw_wgrad_side', _env_flag('MCN_DW_WGRAD_SIDE', True)))     # depthwise wgrad on the wgrad stream
         self.fuse_bn_gap = bool(model._parameters.get('fuse_bn_gap', _env_flag('MCN_FUSE_BN_GAP', True)))
+        self.fuse_se_sums = bool(model._parameters.get('fuse_se_sums', _env_flag('MCN_FUSE_SE_SUMS', True)))        # squeeze-excite: BN-backward sums from the channel scale's reduction pass
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
         self.aff_skips = {}            # shortcut-BN output tensor id -> (its input tensor, its affine [2][C]): applied by the consumer BN
@@ -99,6 +100,14 @@ class Lowering(object):
             d[op] = _ffi.ConvGeom(*[getattr(src, f) for f, _ in _ffi.ConvGeom._fields_])
             d[op]._flop_scale = n.attrs.get('flop_scale', 1.0)       # (pixel-pair form: real MACs per MAC of the launched geometry; bench.py)
         return d[op]
+
+    def se_sums_buffer(self, n):
+        """fp32 [N][4][C] per-image sums of mcn_channel_scale_bwd_dm_bnsums, shared by the squeeze-excite blocks of one size (written and consumed
+        inside one block's backward, on the main stream)"""
+        k = ('se_sums', n)                                     # (one buffer per size: the launch lists hold raw pointers)
+        if k not in self.scratch:
+            self.scratch[k] = torch.zeros(n, dtype=torch.float32, device=self.g.device)
+        return self.scratch[k]
 
     def scratch_like(self, t, key):
         k = (key, t.shape, t.dtype)
@@ -509,10 +518,21 @@ class Lowering(object):
                 sc = self.scratch_like(m, 'chscale_dm')
                 dm = sc.data_ptr()
                 post.append((m.grad.data_ptr(), sc.data_ptr(), m.grad.numel(), MCN_DT[m.dtype]))
-            self.bwd.add(lib.mcn_channel_scale_bwd_dm, y.grad.data_ptr(), x.buf.data_ptr(), dm, N, H * W, C, dt)
+            route = {'dy': y.grad.data_ptr(), 'm': m.buf.data_ptr(), 'gap': gap}
+            if self.fuse_se_sums:
+                # (round 4) the same reduction reads the BN's INPUT and also leaves the per-image sums from which the BN backward forms its own sums:
+                # mcn_bn_bwd_se_sums then runs without its reduction pass over the expanded activations (MCN_FUSE_SE_SUMS=0: the two-pass form)
+                bn = x.producer
+                sa, st = bn.attrs, bn.attrs['saved']
+                sums = self.se_sums_buffer(int(lib.mcn_se_bwd_sums_floats(N, H * W, C, dt)))
+                self.bwd.add(lib.mcn_channel_scale_bwd_dm_bnsums, y.grad.data_ptr(), bn.inputs[0].buf.data_ptr(), self.vptr(sa.get('gamma')), self.vptr(sa.get('beta')),
+                             st['mean'].data_ptr(), st['invstd'].data_ptr(), dm, sums.data_ptr(), N, H * W, C, dt)
+                route['sums'] = sums.data_ptr()
+            else:
+                self.bwd.add(lib.mcn_channel_scale_bwd_dm, y.grad.data_ptr(), x.buf.data_ptr(), dm, N, H * W, C, dt)
             for a in post:
                 self.bwd.add(lib.mcn_accumulate, *a)
-            self.se_routes[x.id] = {'dy': y.grad.data_ptr(), 'm': m.buf.data_ptr(), 'gap': gap}
+            self.se_routes[x.id] = route
             return
 
         def target(t, key):
@@ -726,6 +746,11 @@ class Lowering(object):
             if se is not None:
                 assert act == _ffi.ACT_SWISH and skip is None and lazy is None and 'dgap' in se
                 N_, HW_ = x.shape[0], M // x.shape[0]
+                if 'sums' in se:
+                    self.bwd.add(lib.mcn_bn_bwd_se_sums, se['dy'], se['m'], se['dgap'], x.buf.data_ptr(), self.vptr(g), self.vptr(b), st['mean'].data_ptr(), st['invstd'].data_ptr(),
+                                 se['sums'], dst, g.grad.data_ptr() if g is not None and g.trainable else 0, b.grad.data_ptr() if b is not None and b.trainable else 0, gs,
+                                 N_, HW_, C, MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
+                    return
                 self.bwd.add(lib.mcn_bn_bwd_se, se['dy'], se['m'], se['dgap'], x.buf.data_ptr(), self.vptr(g), self.vptr(b), st['mean'].data_ptr(), st['invstd'].data_ptr(),
                              dst, g.grad.data_ptr() if g is not None and g.trainable else 0, b.grad.data_ptr() if b is not None and b.trainable else 0, gs,
                              N_, HW_, C, MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)

@@ -234,3 +234,26 @@ def test_bn_backward_composes_squeeze_excite_gradient(shape, dtype):
     for a, b in ((dx, dx_ref), (dg, dg_ref), (db, db_ref), (dm, dm_ref)):
         np.testing.assert_array_equal(u.host(a), u.host(b))
     assert np.abs(u.host(dx)).max() > 0
+    # round 4: the pair that skips the BN backward's reduction pass — dm from the BN's INPUT (x_se rebuilt on the fly), the BN-backward sums from
+    # per-image sums of the unrounded gradient: dm identical where the rebuilt x_se is (it is the forward's expression), dgamma / dbeta to fp32
+    # summation accuracy, dx to one rounding of the storage type around the two coefficients
+    dm2 = torch.full((n, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    sums = torch.full((int(lib.mcn_se_bwd_sums_floats(n, hw, c, u.MDT[dtype])),), float('nan'), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_channel_scale_bwd_dm_bnsums(dy.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dm2.data_ptr(), sums.data_ptr(), n, hw, c,
+                                                  u.MDT[dtype], st))
+    dx2 = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg2, db2 = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
+    _ffi.check(lib.mcn_bn_bwd_se_sums(dy.data_ptr(), mk.data_ptr(), dgap.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), sums.data_ptr(), dx2.data_ptr(),
+                                      dg2.data_ptr(), db2.data_ptr(), 0.5, n, hw, c, u.MDT[dtype], ws.data_ptr(), ws.numel() * 4, st))
+    assert np.isfinite(u.host(sums)).all()
+    dmh, dmr = u.host(dm2).astype(np.float64), u.host(dm_ref).astype(np.float64)
+    ulp = {'float32': 2.0 ** -22, 'bfloat16': 2.0 ** -7, 'float16': 2.0 ** -10}[dtype]
+    # (the pass slices an image's pixels over workgroups: fp32 sums in another order; for the 2-byte types the rounded result rarely moves)
+    assert np.abs(dmh - dmr).max() <= ulp * np.abs(dmr).max() and (dtype == 'float32' or (dmh != dmr).mean() <= 0.02), (np.abs(dmh - dmr).max(), (dmh != dmr).mean())
+    # dgamma / dbeta of the composition sum the ROUNDED g, the pair the unrounded one: |difference| <= rounding unit x sum |g s'| / sqrt(M) (random signs), with margin
+    tol = {'float32': 2e-5, 'bfloat16': 4e-3, 'float16': 6e-4}[dtype]
+    gq = np.abs(u.host(dxse).astype(np.float64))
+    np.testing.assert_allclose(u.host(db2), u.host(db_ref), rtol=tol, atol=4 * tol * gq.sum((0, 1, 2)).max() / np.sqrt(m_))
+    np.testing.assert_allclose(u.host(dg2), u.host(dg_ref), rtol=tol, atol=8 * tol * gq.sum((0, 1, 2)).max() / np.sqrt(m_))
+    check(u.host(dx2), u.host(dx_ref), dtype, 'dx of the sums pair vs the composition', rel={'float32': 1e-5, 'bfloat16': 3e-3, 'float16': 4e-4}[dtype],
+          mx={'float32': 1e-4, 'bfloat16': 2e-2, 'float16': 3e-3}[dtype])
