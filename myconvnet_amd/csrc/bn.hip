@@ -732,24 +732,34 @@ __global__ __launch_bounds__(256) void se_bwd_pre_kernel(const T* __restrict__ d
             sc[i] *= is[i];
             sh[i] -= mu[i] * sc[i];
         }
+        // packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): with scalar math the pass is VALU bound (~24 instructions per element), not HBM bound
+        typedef float se_f32x2 __attribute__((ext_vector_type(2)));
         for (long r = r_lo + ty; r < r_hi; r += TY) {
             const long off = (n * HW + r) * C + (long)col * VEC;
             float g[VEC], v[VEC];
             ldv<T, VEC>(dy + off, g);
             ldv<T, VEC>(x + off, v);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const float z = fmaf(v[i], sc[i], sh[i]);
-                const float sig = fast_sigmoid(z);
-                const float xse = to_f32(from_f32<T>(z * sig));                   // the BN + swish output as the forward stored it
-                const float sp = sig * (1.f + z * (1.f - sig));                     // swish'(z)
-                const float xh = (v[i] - mu[i]) * is[i];
-                acc[0][i] = fmaf(g[i], xse, acc[0][i]);
-                const float gs = g[i] * sp;
-                acc[1][i] += gs;
-                acc[2][i] = fmaf(gs, xh, acc[2][i]);
-                acc[3][i] += sp;
-                acc[4][i] = fmaf(sp, xh, acc[4][i]);
+            for (int i = 0; i < VEC; i += 2) {
+                const se_f32x2 v2 = {v[i], v[i + 1]}, g2 = {g[i], g[i + 1]};
+                const se_f32x2 z = __builtin_elementwise_fma(v2, se_f32x2{sc[i], sc[i + 1]}, se_f32x2{sh[i], sh[i + 1]});
+                const se_f32x2 sig = {fast_sigmoid(z[0]), fast_sigmoid(z[1])};
+                const se_f32x2 sw = z * sig;
+                const se_f32x2 xse = {to_f32(from_f32<T>(sw[0])), to_f32(from_f32<T>(sw[1]))};      // the BN + swish output as the forward stored it
+                const se_f32x2 one = {1.f, 1.f};
+                const se_f32x2 sp = sig * __builtin_elementwise_fma(z, one - sig, one);               // swish'(z)
+                const se_f32x2 xh = (v2 - se_f32x2{mu[i], mu[i + 1]}) * se_f32x2{is[i], is[i + 1]};
+                const se_f32x2 gs = g2 * sp;
+                const se_f32x2 a0 = __builtin_elementwise_fma(g2, xse, se_f32x2{acc[0][i], acc[0][i + 1]});
+                const se_f32x2 a1 = se_f32x2{acc[1][i], acc[1][i + 1]} + gs;
+                const se_f32x2 a2 = __builtin_elementwise_fma(gs, xh, se_f32x2{acc[2][i], acc[2][i + 1]});
+                const se_f32x2 a3 = se_f32x2{acc[3][i], acc[3][i + 1]} + sp;
+                const se_f32x2 a4 = __builtin_elementwise_fma(sp, xh, se_f32x2{acc[4][i], acc[4][i + 1]});
+                acc[0][i] = a0[0]; acc[0][i + 1] = a0[1];
+                acc[1][i] = a1[0]; acc[1][i + 1] = a1[1];
+                acc[2][i] = a2[0]; acc[2][i + 1] = a2[1];
+                acc[3][i] = a3[0]; acc[3][i + 1] = a3[1];
+                acc[4][i] = a4[0]; acc[4][i + 1] = a4[1];
             }
         }
     }
@@ -1700,8 +1710,9 @@ static SeBwdLayout se_bwd_layout(int N, long HW, int C, int vec) {
     if (L.TX < 8 && cols > 32) L.TX = 32;                         // awkward chunk counts: accept idle lanes
     L.TY = 256 / L.TX;
     L.gx = (cols + L.TX - 1) / L.TX;
-    // ~8 workgroups per CU, every slice at least 4 row passes of the block
-    long hs = (8L * 256 + (long)L.gx * N - 1) / ((long)L.gx * (N > 0 ? N : 1));      // (256 CUs)
+    // ~4 workgroups per CU, every slice at least 4 row passes of the block
+    static const int per_cu = [] { const char* e = getenv("MCN_SE_PRE_WGS"); return e ? atoi(e) : 4; }();      // (same-box sweep 2 / 4 / 8 / 16 / 32: 27.49 / 27.28 / 27.51 / 28.11 / 28.78 ms per step)
+    long hs = ((long)per_cu * 256 + (long)L.gx * N - 1) / ((long)L.gx * (N > 0 ? N : 1));      // (256 CUs)
     const long cap = (HW + 4L * L.TY - 1) / (4L * L.TY);
     if (hs > cap) hs = cap;
     if (hs < 1) hs = 1;
