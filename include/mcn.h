@@ -300,6 +300,10 @@ int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dgap, const v
  * sum s', sum s' xh; s' = swish'(bn(x)), xh = (x - mean) * invstd) from which mcn_bn_bwd_se_sums forms the BN-backward sums in a loop over N instead of its
  * reduction pass (sum g s' = sum_n m A + dgap / HW B ...; g unrounded there: dgamma / dbeta equal mcn_bn_bwd_se's to fp32 summation accuracy, dx up to
  * one rounding of the storage type around the two coefficients they feed).  Replaces efficientnet.py:152-163's backward like the pair above. */
+/* ... and its forward half: with mcn_bn_fwd_train_gap(y = NULL) (the pooled means only) and y = round(round(act(bn(x))) * m[n,c]) from the BN's INPUT here, the BN + swish
+ * output x_se of a squeeze-excite block is never written or read (models/efficientnet.py:150-163; the backward pair above does not read it either). */
+int mcn_bn_act_scale_fwd(const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const void* m, void* y, int32_t N, int64_t HW,
+                         int32_t C, mcn_act act, mcn_dtype dtype, void* stream);
 size_t mcn_se_bwd_sums_floats(int32_t N, int64_t HW, int32_t C, mcn_dtype dtype);      /* floats of `sums` for this shape (the pass slices every image's pixels over several workgroups) */
 int mcn_channel_scale_bwd_dm_bnsums(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dm,
                                     float* sums, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream);

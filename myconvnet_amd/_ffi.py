@@ -76,6 +76,7 @@ SIGNATURES = {
     'mcn_channel_scale_bwd_dm': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_bn_bwd_se': (c_int, [c_void_p] * 11 + [c_float, c_int32, c_int64, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_bn_bwd_se_sums': (c_int, [c_void_p] * 12 + [c_float, c_int32, c_int64, c_int32, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_bn_act_scale_fwd': (c_int, [c_void_p] * 7 + [c_int32, c_int64, c_int32, c_int, c_int, c_void_p]),
     'mcn_se_bwd_sums_floats': (c_size_t, [c_int32, c_int64, c_int32, c_int]),
     'mcn_channel_scale_bwd_dm_bnsums': (c_int, [c_void_p] * 8 + [c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_bn_bwd_maxpool': (c_int, [c_void_p] * 10 + [c_float] + [c_int32] * 12 + [c_int, c_void_p, c_size_t, c_void_p]),

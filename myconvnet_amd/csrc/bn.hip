@@ -911,6 +911,7 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
 template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_gap_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ gap, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int HW, int C, int TX, int TY) {
+    // y == nullptr (round 4): the output itself is not stored — a squeeze-excite block whose channel scale rebuilds it from x (mcn_bn_act_scale_fwd) needs the means only
     extern __shared__ float gapred[];                              // [TY][TX * VEC]
     const int cv = C / VEC;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -935,7 +936,7 @@ __global__ __launch_bounds__(256) void bn_apply_gap_kernel(const T* __restrict__
                 v[i] = to_f32(from_f32<T>(o));                     // the value as stored: what a separate pooling pass would read back
                 acc[i] += v[i];
             }
-            stv<T, VEC>(y + base + (long)q * C, v);
+            if (y) stv<T, VEC>(y + base + (long)q * C, v);                      // (uniform)
         }
     }
     const int cols = TX * VEC;
@@ -986,7 +987,7 @@ static int bn_fwd_train_gap_t(const void* x, const float* gamma, const float* be
 extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const float* beta, void* y, void* gap, float* save_mean, float* save_invstd,
                                     float* batch_mean, float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t HW,
                                     int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !y || !gap || !save_mean || !save_invstd || N <= 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_gap: bad argument (N=%d HW=%d C=%d)", N, HW, C);
+    if (!x || !gap || !save_mean || !save_invstd || N <= 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_gap: bad argument (N=%d HW=%d C=%d)", N, HW, C);      // (y may be NULL: means only)
     if (N > 65535) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: more than 65535 images (one block row per image)");
     const int64_t M = (int64_t)N * HW;
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_gap: workspace too small");
@@ -997,6 +998,66 @@ extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const flo
     if (dtype == MCN_F16) { if (C % 8 == 0) BN_GAP_T(f16_t, 8); BN_GAP_T(f16_t, 1); }
 #undef BN_GAP_T
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: dtype %d unsupported", (int)dtype);
+}
+
+// y = round(round(act(bn(x))) * m[n,c]): the channel scale of a squeeze-excite block applied to the BN + swish output REBUILT from the BN's input (the value
+// mcn_bn_fwd_train_gap would have stored, up to the last bit of scale / shift: here gamma * invstd and beta - mean * gamma * invstd in fp32, the expression the
+// backward passes use) — with mcn_bn_fwd_train_gap(y = NULL) the BN's output is never written: one pass fewer over the expanded activations of an MBConv block
+template <typename T, int VEC, int ACT>
+__global__ __launch_bounds__(256) void bn_act_scale_kernel(const T* __restrict__ x, const T* __restrict__ m, T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, long HW, long M, int C, int TX, int TY, long rpb) {
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + tx;
+    if (ty >= TY || col * VEC >= C) return;
+    float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+    ldc<VEC>(mean + col * VEC, mu);
+    ldc<VEC>(invstd + col * VEC, is);
+    ldc<VEC>(gamma ? gamma + col * VEC : nullptr, sc, 1.f);
+    ldc<VEC>(beta ? beta + col * VEC : nullptr, sh, 0.f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sc[i] *= is[i];
+        sh[i] -= mu[i] * sc[i];
+    }
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    for (long r = r0 + ty; r < r1; r += TY) {
+        const long off = r * C + (long)col * VEC;
+        float v[VEC], mm[VEC];
+        ldv<T, VEC>(x + off, v);
+        ldv<T, VEC>(m + (long)((unsigned)r / (unsigned)HW) * C + (long)col * VEC, mm);      // (32-bit division: the host checks M < 2^32)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float o = fmaf(v[i], sc[i], sh[i]);
+            if (ACT == 1) o = fmaxf(o, 0.f);
+            if (ACT == 2) o = o * fast_sigmoid(o);
+            v[i] = to_f32(from_f32<T>(o)) * mm[i];
+        }
+        stv<T, VEC>(y + off, v);
+    }
+}
+template <typename T, int VEC>
+static int bn_act_scale_t(const void* x, const void* m, void* y, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, long HW, long M, int C, int act,
+                          hipStream_t st) {
+    const ColLayout L = make_layout(M, C, VEC, bn_target<T>());
+    const dim3 grid(L.gx, L.gy), block(256);
+#define BN_ACT_SCALE(AA) hipLaunchKernelGGL((bn_act_scale_kernel<T, VEC, AA>), grid, block, 0, st, (const T*)x, (const T*)m, (T*)y, save_mean, save_invstd, gamma, beta, HW, M, C, L.TX, L.TY, L.rpb)
+    if (act == 1) BN_ACT_SCALE(1); else if (act == 2) BN_ACT_SCALE(2); else BN_ACT_SCALE(0);
+#undef BN_ACT_SCALE
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_bn_act_scale_fwd(const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const void* m, void* y, int32_t N, int64_t HW,
+                                    int32_t C, mcn_act act, mcn_dtype dtype, void* stream) {
+    const int64_t M = (int64_t)N * HW;
+    if (!x || !m || !y || !save_mean || !save_invstd || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_act_scale_fwd: bad argument");
+    if ((int)act < 0 || (int)act > 2) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_act_scale_fwd: activation %d (none, relu, swish)", (int)act);
+    if (M >= 0xffffffffll) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_act_scale_fwd: more than 2^32 pixels");
+    if (N == 0) return MCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32 && C % 4 == 0) return bn_act_scale_t<float, 4>(x, m, y, gamma, beta, save_mean, save_invstd, (long)HW, (long)M, C, (int)act, st);
+    if (dtype == MCN_BF16 && C % 8 == 0) return bn_act_scale_t<bf16_t, 8>(x, m, y, gamma, beta, save_mean, save_invstd, (long)HW, (long)M, C, (int)act, st);
+    if (dtype == MCN_F16 && C % 8 == 0) return bn_act_scale_t<f16_t, 8>(x, m, y, gamma, beta, save_mean, save_invstd, (long)HW, (long)M, C, (int)act, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bn_act_scale_fwd: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
 }
 
 // ---- statistics from conv-epilogue partials -----------------------------------------------------------------------

@@ -943,9 +943,32 @@ extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const flo
                                     float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t HW, int32_t C, float eps, mcn_act act,
                                     mcn_dtype dtype, void* ws, size_t ws_bytes, void* st) {
     if (!gap || N <= 0 || HW <= 0) return fail(MCN_E_BADARG, "bn_fwd_train_gap: bad argument");
+    std::vector<char> tmp;                                // y == NULL: the means only
+    if (!y) { tmp.resize((size_t)N * HW * C * (dtype == MCN_F32 ? 4 : 2)); y = tmp.data(); }
     const int rc = mcn_bn_fwd_train(x, gamma, beta, nullptr, y, nullptr, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, (int64_t)N * HW, C,
                                     eps, act, dtype, ws, ws_bytes, st);
     return rc ? rc : mcn_global_avgpool_fwd(y, gap, N, HW, C, dtype, st);
+}
+// y = round(round(act(bn(x))) * m[n,c]) from the BN's input (mcn.h)
+extern "C" int mcn_bn_act_scale_fwd(const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const void* m, void* y, int32_t N, int64_t HW,
+                                    int32_t C, mcn_act act, mcn_dtype dtype, void*) {
+    if (!x || !m || !y || !save_mean || !save_invstd || N < 0 || HW <= 0 || C <= 0) return fail(MCN_E_BADARG, "bn_act_scale_fwd: bad argument");
+    return by_dtype(dtype, "bn_act_scale_fwd", [&](auto s) {
+        typedef decltype(s) S;
+        typedef typename S::T T;
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < (int64_t)N * HW; ++r) {
+            const int64_t n = r / HW;
+            for (int c = 0; c < C; ++c) {
+                const float sc = (gamma ? gamma[c] : 1.f) * save_invstd[c], sh = (beta ? beta[c] : 0.f) - save_mean[c] * sc;
+                float o = fmaf(S::ld((const T*)x + r * C + c), sc, sh);
+                if (act == MCN_ACT_RELU) o = o > 0.f ? o : 0.f;
+                else if (act == MCN_ACT_SWISH) o = o * sigmoidf(o);
+                S::st((T*)y + r * C + c, rnd<S>(o) * S::ld((const T*)m + n * C + c));
+            }
+        }
+        return (int)MCN_OK;
+    });
 }
 extern "C" int mcn_global_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void*) { return gap_bwd<false>(dy, dx, N, HW, C, dtype); }
 extern "C" int mcn_global_avgpool_bwd_acc(const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, mcn_dtype dtype, void*) { return gap_bwd<true>(dy, dx, N, HW, C, dtype); }

@@ -43,6 +43,8 @@ class Lowering(object):
         self.fused_gaps = set()        # ids of global-average nodes whose forward runs inside the BN apply pass in front of them
         self.dw_wgrad_side = bool(model._parameters.get('dw_wgrad_side', _env_flag('MCN_DW_WGRAD_SIDE', True)))     # depthwise wgrad on the wgrad stream
         self.fuse_bn_gap = bool(model._parameters.get('fuse_bn_gap', _env_flag('MCN_FUSE_BN_GAP', True)))
+        self.fuse_se_fwd = bool(model._parameters.get('fuse_se_fwd', _env_flag('MCN_FUSE_SE_FWD', True)))          # ... and its BN + swish output never stored (needs fuse_se_sums)
+        self.se_elided = set()          # ids of BN-output tensors that are not materialised (rebuilt inside mcn_bn_act_scale_fwd)
         self.fuse_se_sums = bool(model._parameters.get('fuse_se_sums', _env_flag('MCN_FUSE_SE_SUMS', True)))        # squeeze-excite: BN-backward sums from the channel scale's reduction pass
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
@@ -486,7 +488,32 @@ class Lowering(object):
     def fwd_chscale(self, n):
         x, m, y = n.inputs[0], n.inputs[1], n.outputs[0]
         N, H, W, C = x.shape
+        if x.id in self.se_elided:
+            # x = the BN + swish output of a squeeze-excite block that was never stored (_se_elide): rebuilt from the BN's input inside the scale pass
+            bn = x.producer
+            a, st = bn.attrs, bn.attrs['saved']
+            self.fwd.add(lib.mcn_bn_act_scale_fwd, bn.inputs[0].buf.data_ptr(), self.vptr(a.get('gamma')), self.vptr(a.get('beta')), st['mean'].data_ptr(), st['invstd'].data_ptr(),
+                         m.buf.data_ptr(), y.buf.data_ptr(), N, H * W, C, a.get('act', 0), MCN_DT[x.dtype])
+            return
         self.fwd.add(lib.mcn_channel_scale_fwd, x.buf.data_ptr(), m.buf.data_ptr(), y.buf.data_ptr(), N, H * W, C, MCN_DT[x.dtype])
+
+    def _se_elide(self, bn, gap):
+        """(round 4) training-mode BN + swish whose output x_se is read only by the squeeze-excite squeeze — produced by this BN's own apply pass — and by the
+        channel scale, with the backward taking dm and the BN's sums from the BN's INPUT (fuse_se_sums): x_se is never needed in memory.  The apply pass then
+        leaves the pooled means only and the scale pass rebuilds x_se on the fly (mcn_bn_act_scale_fwd): one write of the expanded activations per MBConv
+        block less.  Returns the channel-scale node or None.  MCN_FUSE_SE_FWD=0 switches it off."""
+        y = bn.outputs[0]
+        if not (self.train and self.fuse_se_sums and self.fuse_se_fwd) or os.environ.get('MCN_FUSE_SE', '1') == '0':
+            return None
+        if bn.attrs.get('act', 0) != _ffi.ACT_SWISH or not bn.attrs.get('update') or bn.attrs.get('skip') is not None:
+            return None
+        others = [c for c in y.consumers if c is not gap]
+        if len(others) != 1 or others[0].op != 'chscale' or others[0].inputs[0] is not y or len(y.shape) != 4 or y.shape[-1] % (4 if y.dtype == 'float32' else 8):
+            return None
+        n = others[0]
+        if not y.needs_grad or not n.inputs[1].needs_grad or self.g.nodes.index(n) < self.g.nodes.index(bn):
+            return None
+        return n
 
     def _se_route(self, n):
         """squeeze-excite pattern around this channel scale: its input x is the output of a training-mode BN + swish and is read only by
@@ -509,6 +536,8 @@ class Lowering(object):
         dt = MCN_DT[x.dtype]
         post = []
         gap = self._se_route(n)
+        if gap is None and x.id in self.se_elided:
+            raise RuntimeError('channel scale: the BN output was not stored in the forward pass but its backward route is not the squeeze-excite one')
         if gap is not None:
             # reduction half only; the BN in front composes round(round(dy * m) + dgap / HW) itself (bwd_gap adds its part of the route)
             if m.id not in self.written:
@@ -654,7 +683,11 @@ class Lowering(object):
                 # BN + swish in front of a squeeze-excite block: the apply pass also leaves the per-image channel means (the SE branch's
                 # tf.reduce_mean, models/efficientnet.py:183) — fwd_gap then emits nothing
                 self.fused_gaps.add(id(gap))
-                self.fwd.add(lib.mcn_bn_fwd_train_gap, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), y.buf.data_ptr(), gap.outputs[0].buf.data_ptr(),
+                y_ptr = y.buf.data_ptr()
+                if self._se_elide(n, gap) is not None:     # the channel scale rebuilds this output from x: means only
+                    self.se_elided.add(y.id)
+                    y_ptr = 0
+                self.fwd.add(lib.mcn_bn_fwd_train_gap, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), y_ptr, gap.outputs[0].buf.data_ptr(),
                              st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
                              a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,
                              float(a['momentum']), x.shape[0], M // x.shape[0], C, float(a['eps']), a.get('act', 0), MCN_DT[x.dtype], self.ws_ptr, self.ws_bytes)
