@@ -98,6 +98,9 @@ def run_steps(opt, n, fetch=False):
 CALL_KERNELS = {
     'mcn_bn_bwd': ['bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel'],
     'mcn_bn_bwd_se': ['bn_bwd_reduce_se_kernel', 'bn_bwd_apply_se_kernel'],
+    'mcn_bn_bwd_se_sums': ['bn_bwd_apply_se_kernel', 'se_bwd_sums_kernel'],
+    'mcn_channel_scale_bwd_dm_bnsums': ['se_bwd_pre_kernel', 'se_bwd_dm_fold_kernel'],
+    'mcn_bn_act_scale_fwd': ['bn_act_scale_kernel'],
     'mcn_bn_fwd_train_fused': ['bn_apply_kernel', 'bn_fwd_finalize_fused_kernel', 'bn_fold_partials_kernel'],
     'mcn_bn_fwd_train_gap': ['bn_apply_gap_kernel'],
     'mcn_dwconv2d_fwd': ['dw_band_kernel', 'dw_strip_kernel'],
@@ -194,8 +197,10 @@ def _hbm_call_bytes(name, a, es):
         return es * mc(17) * 3
     if name == 'mcn_bn_fwd_train':                       # statistics pass + apply pass
         return es * mc(13) * (3 + (1 if a[3] else 0))
-    if name == 'mcn_bn_fwd_train_gap':                   # statistics pass + apply pass (the pooled means ride in the apply pass)
-        return es * float(a[12]) * float(a[13]) * float(a[14]) * 3
+    if name == 'mcn_bn_fwd_train_gap':                   # statistics pass + apply pass (the pooled means ride in the apply pass; y = NULL: means only, no write)
+        return es * float(a[12]) * float(a[13]) * float(a[14]) * (3 if a[3] else 2)
+    if name == 'mcn_bn_act_scale_fwd':                   # BN input -> scaled output (the BN + swish output is rebuilt on the fly)
+        return es * float(a[7]) * float(a[8]) * float(a[9]) * 2
     if name == 'mcn_bn_fwd_train_fused_maxpool':         # x -> pooled + arg-max
         n, h, w, c, oh, ow = a[15], a[16], a[17], a[18], a[-6], a[-5]
         return es * n * h * w * c + (es + 1) * n * oh * ow * c
@@ -205,6 +210,10 @@ def _hbm_call_bytes(name, a, es):
         return es * mc(13) * 3
     if name == 'mcn_bn_bwd_se':                          # both passes read dy and x, the apply pass writes dx
         return es * float(a[12]) * float(a[13]) * float(a[14]) * 5
+    if name == 'mcn_bn_bwd_se_sums':                     # the apply pass only (dy, x -> dx): the sums come from mcn_channel_scale_bwd_dm_bnsums
+        return es * float(a[13]) * float(a[14]) * float(a[15]) * 3
+    if name == 'mcn_channel_scale_bwd_dm_bnsums':        # dy and the BN's input, once
+        return es * float(a[8]) * float(a[9]) * float(a[10]) * 2
     if name == 'mcn_bn_bwd_maxpool':                     # both passes read x and the pooled gradient + arg-max, one writes dx
         n, h, w, c, oh, ow = a[11], a[12], a[13], a[14], a[-6], a[-5]
         return es * n * h * w * c * 3 + 2 * (es + 1) * n * oh * ow * c
