@@ -140,6 +140,25 @@ def pmc_traffic(kernel, dtype, batch, model='resnet50'):
     return {'traffic': k['bytes_per_launch'], 'traffic_unit': 'bytes/launch', 'traffic_source': 'profiles/pmc_traffic_%s.json' % dtype}
 
 
+def pmc_group_traffic(prefixes, dtype, batch, model='resnet50'):
+    """HBM bytes PER STEP of every kernel symbol starting with one of `prefixes` (same committed PMC summary, same build-id rule as pmc_traffic);
+    None when the summary is absent / stale."""
+    tag = dtype if model == 'resnet50' else '%s_%s' % (model, dtype)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_%s.json' % tag)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    from myconvnet_amd._ffi import lib
+    if d.get('batch') != batch or d.get('build_id') != lib.mcn_build_id().decode() or not d.get('steps_profiled'):
+        return None
+    mine = [v for name, v in d.get('kernels', {}).items() if any(name.startswith(p) for p in prefixes)]
+    if not mine:
+        return None
+    return sum(v['bytes_per_launch'] * v['launches_profiled'] for v in mine) / d['steps_profiled']
+
+
 def timed(opt, steps, warmup, world, autotune=False):
     import torch.distributed as dist
     if autotune:                                       # untimed start-up: two steps to fill the buffers, then time the tile candidates
@@ -232,6 +251,63 @@ def _hbm_call_bytes(name, a, es):
 
 WINO_DIRECT_FLOP = {}
 
+CONV_OPS = ('mcn_conv2d_fwd', 'mcn_conv2d_fwd_bnstats', 'mcn_conv2d_dgrad', 'mcn_conv2d_dgrad_addmasked', 'mcn_conv2d_dgrad_bnred', 'mcn_conv2d_dgrad_addmasked_bnred',
+            'mcn_conv2d_wgrad')
+WINO_TAIL_LAUNCHES = {}
+WINO_TAIL_SYMBOLS = {}
+
+
+def conv_call_launches(name, a, dtype):
+    """The kernel launches behind ONE conv C-ABI call of the launch lists, named as rocprofv3 names them.  name = the entry point, a = its
+    argument list (executor.py), dtype = 'fp32' | 'bf16' | 'fp16'.  Returns (geom, [(symbol, weight)], dominant symbol, direct-convolution
+    FLOP, algorithmic HBM bytes).  A call that launches several kernels lists them all: a strided dgrad one per stride-parity class (weight =
+    its taps), a Winograd call with a K-sliced tail its body, slice and reduce symbols (body first).  tests/test_gpu_fullsize_fused.py calls
+    this with its own argument lists, so that the launches it checks against the oracle are BY NAME the ones the bench line reports."""
+    import ctypes
+    from myconvnet_amd import _ffi
+    from myconvnet_amd._ffi import lib
+    op = {'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}.get(name, _ffi.CONV_FWD if name.startswith('mcn_conv2d_fwd') else _ffi.CONV_DGRAD)
+    mdt = {'fp32': _ffi.F32, 'bf16': _ffi.BF16, 'fp16': _ffi.F16}[dtype]
+    lbuf = ctypes.create_string_buffer(1024)
+    gm = [x for x in a if hasattr(x, '_obj')][0]._obj          # ctypes.byref(geom)
+    oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
+    ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
+    flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout * getattr(gm, '_flop_scale', 1.0)   # (pixel-pair stem: count the 7x7x3 MACs)
+    # one entry per GEMM launch of the call (a strided dgrad: one per stride-parity class, not all the same symbol)
+    lib.mcn_conv2d_launch_list(op, ctypes.byref(gm), mdt, lbuf, 1024)
+    launches = [ln.rsplit(':', 1) for ln in lbuf.value.decode().splitlines()]
+    epi = None
+    if name == 'mcn_conv2d_fwd_bnstats':                       # the instantiation with the BN-statistics epilogue
+        epi = ', 1>'
+    elif (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
+        epi = ', 2>'                                           # ... with the accumulate epilogue
+    elif name == 'mcn_conv2d_dgrad_bnred':
+        epi = ', 4>'                                           # ... with the BN-backward sums
+    elif name == 'mcn_conv2d_dgrad_addmasked_bnred':
+        epi = ', 5>'                                           # ... with the masked residual fan-in AND the BN-backward sums (round 4)
+    wino = bool(launches) and launches[0][0].startswith('conv_wino')
+    if wino:                                                   # (the slices store plain accumulators: <128, 0> whatever the call's epilogue)
+        launches = [(k.replace(', 0>', epi) if (epi and not k.startswith('conv_wino_f2k3_w8<128')) else k, int(t)) for k, t in launches]
+    else:
+        launches = [(k.replace(', 0>', epi) if epi else k, int(t)) for k, t in launches]
+    if (epi == ', 2>' and dtype == 'fp32') or epi in (', 4>', ', 5>') or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
+        # fp32 keeps conv_gemm_nt for the accumulate epilogue; by default only the statistics forward is persistent
+        launches = [(_not_persistent(k), t) for k, t in launches]
+    key = launches[0][0] if wino else max(launches, key=lambda kt: kt[1])[0]               # (per-layer table: the launch with the most taps)
+    es = 4 if dtype == 'fp32' else 2
+    # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)
+    xe = gm.N * gm.H * gm.W * gm.Cin if (gm.KH > 1 or gm.SH == 1) else gm.N * oh * ow * gm.Cin
+    byt = es * (xe + gm.N * oh * ow * gm.Cout) + (4 if name == 'mcn_conv2d_wgrad' else es) * gm.KH * gm.KW * gm.Cin * gm.Cout
+    if (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
+        byt += es * xe                                         # accumulate / fused residual fan-in: one more read of a dx-sized tensor
+    if name == 'mcn_conv2d_dgrad_bnred':
+        byt += es * xe                                         # the BN's input, read beside the dx tile for sum dy' * x
+    if name == 'mcn_conv2d_dgrad_addmasked_bnred':
+        byt += 2 * es * xe                                     # the next unit's gradient (masked fan-in) and the BN's input
+    return gm, launches, key, flop, float(byt)
+
+
+
 
 def instrumented_pass(model, dtype, reps=3, layers=False):
     """Time every C-ABI launch of forward+backward with HIP events on the launch stream (torch's current stream IS the
@@ -249,6 +325,9 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
     lbuf = ctypes.create_string_buffer(1024)
     table, rows = {}, {}
     calls = low.fwd.calls + low.bwd.calls
+    WINO_TAIL_LAUNCHES.clear()
+    WINO_TAIL_SYMBOLS.clear()
+    WINO_DIRECT_FLOP.clear()
     low.prepack.run(sp)
     # cost of an empty event bracket on this stream (two records back to back), subtracted from every bracket below
     empt = []
@@ -305,39 +384,16 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
                     r[0] += 1
                     r[1] += ms
             else:
-                gm = [x for x in a if hasattr(x, '_obj')][0]._obj          # ctypes.byref(geom)
-                oh = (gm.H + gm.padT + gm.padB - (gm.KH - 1) * gm.DH - 1) // gm.SH + 1
-                ow = (gm.W + gm.padL + gm.padR - (gm.KW - 1) * gm.DW - 1) // gm.SW + 1
-                flop = 2.0 * gm.N * oh * ow * gm.KH * gm.KW * gm.Cin * gm.Cout * getattr(gm, '_flop_scale', 1.0)   # (pixel-pair stem: count the 7x7x3 MACs)
-                # one entry per GEMM launch of the call (a strided dgrad: one per stride-parity class, not all the same symbol)
-                nl = lib.mcn_conv2d_launch_list(ops[name], ctypes.byref(gm), mdt, lbuf, 1024)
-                launches = [ln.rsplit(':', 1) for ln in lbuf.value.decode().splitlines()]
-                epi = None
-                if name == 'mcn_conv2d_fwd_bnstats':                       # the instantiation with the BN-statistics epilogue
-                    epi = ', 1>'
-                elif (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
-                    epi = ', 2>'                                           # ... with the accumulate epilogue
-                elif name == 'mcn_conv2d_dgrad_bnred':
-                    epi = ', 4>'                                           # ... with the BN-backward sums
-                elif name == 'mcn_conv2d_dgrad_addmasked_bnred':
-                    epi = ', 5>'                                           # ... with the masked residual fan-in AND the BN-backward sums (round 4)
-                if launches and launches[0][0].startswith('conv_wino'):
-                    launches = launches[:1]                                # (a K-sliced Winograd tail adds a slice and a reduce launch: booked with the body)
-                launches = [(k.replace(', 0>', epi) if epi else k, int(t)) for k, t in launches]
-                if (epi == ', 2>' and dtype == 'fp32') or epi in (', 4>', ', 5>') or (name == 'mcn_conv2d_fwd' and int(os.environ.get('MCN_NT_PERS', '1')) < 2):
-                    # fp32 keeps conv_gemm_nt for the accumulate epilogue; by default only the statistics forward is persistent
-                    launches = [(_not_persistent(k), t) for k, t in launches]
-                key = max(launches, key=lambda kt: kt[1])[0]               # (per-layer table: the launch with the most taps)
-                es = 4 if dtype == 'fp32' else 2
-                # algorithmic HBM bytes: each activation tensor once + the filter once (a stride-s 1x1 reads 1/s^2 of x)
-                xe = gm.N * gm.H * gm.W * gm.Cin if (gm.KH > 1 or gm.SH == 1) else gm.N * oh * ow * gm.Cin
-                byt = es * (xe + gm.N * oh * ow * gm.Cout) + (4 if name == 'mcn_conv2d_wgrad' else es) * gm.KH * gm.KW * gm.Cin * gm.Cout
-                if (name == 'mcn_conv2d_dgrad' and a[5]) or name == 'mcn_conv2d_dgrad_addmasked':
-                    byt += es * xe                                         # accumulate / fused residual fan-in: one more read of a dx-sized tensor
-                if name == 'mcn_conv2d_dgrad_bnred':
-                    byt += es * xe                                         # the BN's input, read beside the dx tile for sum dy' * x
-                if name == 'mcn_conv2d_dgrad_addmasked_bnred':
-                    byt += 2 * es * xe                                     # the next unit's gradient (masked fan-in) and the BN's input
+                gm, launches, key, flop, byt = conv_call_launches(name, a, dtype)
+                nl = len(launches)
+                if key.startswith('conv_wino'):
+                    # a K-sliced Winograd tail adds a slice and a reduce launch to the call: the bracket covers all three, the entry is booked per
+                    # CALL under the body's symbol (launches = calls, so that bytes per launch and PMC traffic share one denominator) and the
+                    # tail launches ride along as `tail_launches_per_step`
+                    WINO_TAIL_LAUNCHES[key] = WINO_TAIL_LAUNCHES.get(key, 0) + (len(launches) - 1)
+                    WINO_TAIL_SYMBOLS.setdefault(key, set()).update(k for k, _ in launches[1:])
+                    launches = launches[:1]
+                    nl = 1
                 if layers:
                     r = rows.setdefault((name[11:], gm.H, gm.Cin, gm.Cout, gm.KH, gm.SH, key), [0, 0.0, flop, byt])
                     r[0] += 1
@@ -370,6 +426,8 @@ def instrumented_pass(model, dtype, reps=3, layers=False):
             us = ms / n * 1e3
             print('{:5s} {:3d} {:5d} {:5d} {} {} {:2d} {:10.1f} {:8.1f} {:8.0f}  {}'.format(key[0], key[1], key[2], key[3], key[4], key[5],
                   n // (reps - 1), us, flop / us / 1e6, byt / us / 1e3, key[6]), file=sys.stderr)
+    for k in WINO_TAIL_LAUNCHES:
+        WINO_TAIL_LAUNCHES[k] //= (reps - 1)
     for k, t in table.items():
         if k == '_bracket_us':
             continue
@@ -524,6 +582,73 @@ def executed_flop_per_image(dtype):
     return float(TRAIN_FLOP_PER_IMAGE) - saved
 
 
+def verify_line(out):
+    """Recompute every derived figure of a bench line from the line's OWN fields (a line must be self-consistent) and
+    return the list of disagreements (empty = consistent).  main() asserts it on the line it is about to print; tests/test_bench_line.py runs
+    it over the committed lines under profiles/."""
+    bad = []
+
+    def close(what, got, want, rel=2e-3, absol=0.0):
+        if got is None or want is None:
+            return
+        if abs(float(got) - float(want)) > max(rel * abs(float(want)), absol):
+            bad.append('{}: stored {} but its own fields give {:.6g}'.format(what, got, want))
+    dt = {'f32': 'fp32', 'bf16': 'bf16', 'f16': 'fp16'}.get(out.get('dtype'))
+    gb = out.get('config', {}).get('global_batch')
+    if gb and out.get('ms_per_step'):
+        close('value', out['value'], gb / out['ms_per_step'] * 1e3, rel=1e-3)
+    n = max(int(out.get('n_gpus', 1)), 1)
+    if dt and 'executed_flop_per_image' in out:
+        close('e2e_mfma_frac', out.get('e2e_mfma_frac'), out['value'] / n * out['executed_flop_per_image'] / (PEAK_TFLOPS[dt] * 1e12), absol=1e-4)
+        close('direct_equivalent_frac', out.get('direct_equivalent_frac'), out['value'] / n * out['train_flop_per_image'] / (PEAK_TFLOPS[dt] * 1e12), absol=1e-4)
+    rf = out.get('roofline')
+    if rf:
+        close('roofline.frac', rf['frac'], rf['achieved'] / rf['peak'], absol=2e-4)
+        if dt:
+            close('roofline.peak', rf['peak'], PEAK_HBM_GBS if rf['unit'] == 'GB/s' else PEAK_TFLOPS[dt], rel=1e-9)
+        kms = out.get('kernel_ms_per_step', {}).get(rf.get('kernel'))
+        if kms:
+            close('roofline.avg_launch_us x launches_per_step', rf['avg_launch_us'] * rf['launches_per_step'] * 1e-3, kms, rel=5e-3)
+        e = out.get('roofline_by_kernel', {}).get(rf.get('kernel'))
+        if e and rf['unit'] == 'TFLOP/s':
+            close('roofline.achieved vs roofline_by_kernel.tflops', rf['achieved'], e['tflops'], absol=0.06)
+        if e:
+            close('roofline.algorithmic_bytes_per_launch', rf.get('algorithmic_bytes_per_launch'), e['algorithmic_bytes_per_launch'], rel=1e-6)
+    for k, e in out.get('roofline_by_kernel', {}).items():
+        if dt and 'frac' in e:
+            close('roofline_by_kernel[{}].frac'.format(k), e['frac'], e['tflops'] / PEAK_TFLOPS[dt], absol=1e-3)
+        if e.get('ms_per_step') and 'gbs' in e:
+            close('roofline_by_kernel[{}].gbs'.format(k), e['gbs'], e['algorithmic_bytes_per_launch'] * e['launches_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=1e-2, absol=1.0)
+        if 'hbm_frac' in e:
+            close('roofline_by_kernel[{}].hbm_frac'.format(k), e['hbm_frac'], e['gbs'] / PEAK_HBM_GBS, absol=1e-3)
+        if k.startswith('conv_wino') and 'tail_launches_per_step' not in e:
+            bad.append('roofline_by_kernel[{}]: a Winograd entry must say how many tail launches its brackets include'.format(k))
+    for k, e in out.get('hbm_by_call', {}).items():
+        if 'gbs' in e:
+            close('hbm_by_call[{}].gbs'.format(k), e['gbs'], e['algorithmic_bytes_per_call'] * e['calls_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=1e-2, absol=1.0)
+            close('hbm_by_call[{}].hbm_frac'.format(k), e['hbm_frac'], e['gbs'] / PEAK_HBM_GBS, absol=1e-3)
+        if 'traffic_per_step' in e:
+            close('hbm_by_call[{}].traffic_gbs'.format(k), e['traffic_gbs'], e['traffic_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=1e-2, absol=1.0)
+            close('hbm_by_call[{}].traffic_hbm_frac'.format(k), e['traffic_hbm_frac'], e['traffic_gbs'] / PEAK_HBM_GBS, absol=1e-3)
+    for key in ('bf16', 'fp16'):
+        e = out.get(key)
+        if e and 'e2e_mfma_frac' in e and gb:
+            close(key + '.value', e['value'], gb / e['ms_per_step'] * 1e3, rel=1e-3)
+            close(key + '.e2e_mfma_frac', e['e2e_mfma_frac'], e['value'] * TRAIN_FLOP_PER_IMAGE / (PEAK_TFLOPS[key] * 1e12), absol=1e-4)
+    for key in ('efficientnet_b0_bf16', 'deeplabv3plus_bf16'):
+        e = out.get(key)
+        if e:
+            close(key + '.value', e['value'], e['batch'] / e['ms_per_step'] * 1e3, rel=1e-3)
+            if 'roofline' in e:
+                close(key + '.roofline.frac', e['roofline']['frac'], e['roofline']['achieved'] / e['roofline']['peak'], absol=2e-4)
+    cb = out.get('cpu_baseline')
+    if cb is not None:
+        for f in ('value', 'unit', 'cores', 'kind', 'sample'):
+            if f not in cb:
+                bad.append('cpu_baseline.{} missing'.format(f))
+    return bad
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: N fresh child processes, one per GPU, started BEFORE this process makes any GPU call
     (a process that has initialised the GPU must never exec or fork into another one; this parent only ever waits).  Rank 0's stdout is
@@ -653,7 +778,41 @@ def main():
                                      for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])[:8] if v[1] > 0}
         for k, d in WINO_DIRECT_FLOP.items():                            # (tflops / frac above: executed Winograd flop)
             if k in out['roofline_by_kernel']:
-                out['roofline_by_kernel'][k]['direct_equivalent_tflops'] = round(d / (table[k][1] * 1e-3) / 1e12, 1)
+                e = out['roofline_by_kernel'][k]
+                e['direct_equivalent_tflops'] = round(d / (table[k][1] * 1e-3) / 1e12, 1)
+                # a Winograd entry is per C-ABI CALL: `launches_per_step` = launches of the body symbol = calls; the calls with a K-sliced tail add one
+                # slice and one reduce launch each, inside the same event bracket (`tail_launches_per_step`, `tail_symbols`).  `traffic` = PMC bytes of
+                # the body launch + the tail symbols' launches of an average call, so that it shares its denominator with `algorithmic_bytes_per_launch`
+                tail = WINO_TAIL_LAUNCHES.get(k, 0)
+                e['tail_launches_per_step'] = tail
+                e['tail_symbols'] = sorted(WINO_TAIL_SYMBOLS.get(k, ()))
+                if e.get('traffic') is not None and tail:
+                    tb = [pmc_traffic(sym, args.dtype, args.batch).get('traffic') for sym in e['tail_symbols']]
+                    if all(t is not None for t in tb):
+                        e['traffic_body_launch'] = e['traffic']
+                        e['traffic'] = int(e['traffic'] + sum(tb) * (tail / max(len(tb), 1)) / max(e['launches_per_step'], 1))
+        # SURVEY 8(d) asks for BOTH roofs: the batch-norm calls of the step against the HBM roof (algorithmic bytes = every tensor once per pass that
+        # needs it, _hbm_call_bytes; PMC traffic of the calls' kernel symbols where a call owns its symbols, else of the group)
+        hb = {}
+        for k in ('mcn_bn_fwd_train_fused', 'mcn_bn_fwd_train_fused_affskip', 'mcn_bn_fwd_train_fused_maxpool', 'mcn_bn_bwd', 'mcn_bn_bwd_from_partials', 'mcn_bn_bwd_maxpool'):
+            v = table.get(k)
+            if v and v[1] > 0 and v[3] > 0:
+                hb[k] = {'calls_per_step': v[0], 'ms_per_step': round(v[1], 3), 'algorithmic_bytes_per_call': int(v[3] / max(v[0], 1)),
+                         'gbs': round(v[3] / (v[1] * 1e-3) / 1e9, 0), 'hbm_frac': round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)}
+        grp = pmc_group_traffic(['bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel', 'bn_bwd_fold_partials_kernel'], args.dtype, args.batch)
+        bw = [hb[k] for k in ('mcn_bn_bwd', 'mcn_bn_bwd_from_partials') if k in hb]
+        if grp is not None and bw:
+            ms_g = sum(e['ms_per_step'] for e in bw)
+            hb['bn_backward_calls'] = {'what': 'mcn_bn_bwd + mcn_bn_bwd_from_partials (they share kernel symbols: PMC traffic is per group)', 'ms_per_step': round(ms_g, 3),
+                                       'algorithmic_bytes_per_step': int(sum(e['algorithmic_bytes_per_call'] * e['calls_per_step'] for e in bw)), 'traffic_per_step': int(grp),
+                                       'traffic_gbs': round(grp / (ms_g * 1e-3) / 1e9, 0), 'traffic_hbm_frac': round(grp / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)}
+        t_f = pmc_traffic('mcn_bn_fwd_train_fused', args.dtype, args.batch).get('traffic')
+        if t_f is not None and 'mcn_bn_fwd_train_fused' in hb:
+            e = hb['mcn_bn_fwd_train_fused']
+            e['traffic'] = t_f
+            e['traffic_gbs'] = round(t_f * e['calls_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, 0)
+        if hb:
+            out['hbm_by_call'] = hb
         tot = sum(v[1] for v in table.values())
         out['kernel_ms_per_step'] = {k: round(v[1], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if args.all_kernels else 12)]}
         out['kernel_ms_total'] = round(tot, 3)
@@ -694,6 +853,8 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
+        problems = verify_line(out)
+        assert not problems, 'bench line is not self-consistent: ' + '; '.join(problems)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

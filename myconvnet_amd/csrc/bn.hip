@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_se_kernel(const T* __restri
 // (s' = swish'(bn(x)), xh = (x - mean) * invstd), and A, A2, B, B2 need neither the SE mask nor the pooled branch's gradient: the pass that
 // computes dm[n,c] = sum_hw dy * x_se — which must run BEFORE the SE branch's backward — produces them too, reading the BN's INPUT x and
 // rebuilding x_se = round_T(swish(bn(x))) from it (same two tensor reads as before), and the pass bn_bwd_reduce_se_kernel (two more reads of the widest
-// activations of the network per block) becomes a loop over [N][4][C] floats.  The sums are those of the unrounded g (the apply pass still
+// activations of the network per block) becomes a loop over [N * HS][5][C] floats (HS = pixel slices per image, se_bwd_layout; plane 0 = the dm partial).  The sums are those of the unrounded g (the apply pass still
 // forms the rounded g per element): dgamma / dbeta agree with the three-step composition to fp32 summation accuracy, not bit for bit.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void se_bwd_pre_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -989,6 +989,7 @@ extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const flo
                                     int32_t C, float eps, mcn_act act, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !gap || !save_mean || !save_invstd || N <= 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bn_fwd_train_gap: bad argument (N=%d HW=%d C=%d)", N, HW, C);      // (y may be NULL: means only)
     if (N > 65535) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: more than 65535 images (one block row per image)");
+    if ((int)act < 0 || (int)act > 2) MCN_FAIL(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: activation %d (none / relu / swish only)", (int)act);
     const int64_t M = (int64_t)N * HW;
     if (!ws || ws_bytes < mcn_bn_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bn_fwd_train_gap: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1773,7 +1774,7 @@ static SeBwdLayout se_bwd_layout(int N, long HW, int C, int vec) {
     L.gx = (cols + L.TX - 1) / L.TX;
     // ~4 workgroups per CU, every slice at least 4 row passes of the block
     static const int per_cu = [] { const char* e = getenv("MCN_SE_PRE_WGS"); return e ? atoi(e) : 4; }();      // (same-box sweep 2 / 4 / 8 / 16 / 32: 27.49 / 27.28 / 27.51 / 28.11 / 28.78 ms per step)
-    long hs = ((long)per_cu * 256 + (long)L.gx * N - 1) / ((long)L.gx * (N > 0 ? N : 1));      // (256 CUs)
+    long hs = ((long)per_cu * MCN_NUM_CU + (long)L.gx * N - 1) / ((long)L.gx * (N > 0 ? N : 1));
     const long cap = (HW + 4L * L.TY - 1) / (4L * L.TY);
     if (hs > cap) hs = cap;
     if (hs < 1) hs = 1;
@@ -1833,7 +1834,7 @@ extern "C" int mcn_bn_bwd_se(const void* dy, const void* se_mask, const void* dg
     MCN_FAIL(MCN_E_UNSUPPORTED, "bn_bwd_se: dtype %d / C = %d (a multiple of the 16-byte chunk) unsupported", (int)dtype, C);
 }
 
-// mcn_bn_bwd_se with the reduction pass replaced by the per-image sums of mcn_channel_scale_bwd_dm_bnsums (sums: fp32 [N][4][C])
+// mcn_bn_bwd_se with the reduction pass replaced by the per-image sums of mcn_channel_scale_bwd_dm_bnsums (sums: fp32 [N * HS][5][C], mcn_se_bwd_sums_floats() of them)
 extern "C" int mcn_bn_bwd_se_sums(const void* dy, const void* se_mask, const void* dgap, const void* x, const float* gamma, const float* beta, const float* save_mean,
                                   const float* save_invstd, const float* sums, void* dx, float* dgamma, float* dbeta, float grad_scale, int32_t N, int64_t HW, int32_t C,
                                   mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
@@ -1861,7 +1862,7 @@ static int se_bwd_pre_t(const void* dy, const void* x, const float* gamma, const
     return MCN_OK;
 }
 // dm[n,c] = sum_hw dy * x_se (what mcn_channel_scale_bwd_dm gives on the stored x_se) from the BN's INPUT x — x_se = round(swish(bn(x))) is rebuilt on
-// the fly — plus the per-image sums [N][4][C] (sum dy s', sum dy s' xh, sum s', sum s' xh) that let mcn_bn_bwd_se_sums skip its reduction pass
+// the fly — plus the per-image-slice sums [N * HS][5][C] (dm partial, sum dy s', sum dy s' xh, sum s', sum s' xh) that let mcn_bn_bwd_se_sums skip its reduction pass
 extern "C" int mcn_channel_scale_bwd_dm_bnsums(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dm,
                                                float* sums, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype, void* stream) {
     if (!dy || !x || !dm || !sums || !save_mean || !save_invstd || N < 0 || HW <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "channel_scale_bwd_dm_bnsums: bad argument");

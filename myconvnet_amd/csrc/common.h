@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include "../../include/mcn.h"
 
+#define MCN_NUM_CU 256                       // compute units of one MI355X (8 XCDs x 32): launch-shape heuristics only
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

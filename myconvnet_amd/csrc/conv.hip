@@ -28,7 +28,6 @@ static bool force_naive() {
 }
 
 // ---- geometry helpers ----------------------------------------------------------------------------
-#define MCN_NUM_CU 256
 // worst case of the stream-K partials (sk_plan): tail tiles x slices <= resident workgroup slots, largest tile
 #define MCN_SK_MAX_BYTES ((size_t)MCN_NUM_CU * 256 * 128 * sizeof(float))
 
@@ -369,6 +368,7 @@ static SkPlan sk_plan(int tile, long W, int nk, size_t es) {
     static const int enabled = [] { const char* e = getenv("MCN_NT_STREAMK"); return e ? atoi(e) : 1; }();
     SkPlan sp = {(int)W, 0, 1, 0};
     if (!enabled || (es != 4 && enabled < 2)) return sp;
+    if (kNtCand[tile].wpp) return sp;                      // (launch_nt hands the window ping-pong tiles to launch_nt_wpp before any split: never K-sliced)
     const long S = (long)kNtSlotsPerCU[tile] * MCN_NUM_CU;
     const long tail = W % S;
     if (W < S || W / S >= MCN_SK_MAX_ROUNDS || tail == 0 || 4 * tail >= 3 * S) return sp;   // last round already >= 75 % full

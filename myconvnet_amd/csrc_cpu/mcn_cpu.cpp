@@ -943,6 +943,7 @@ extern "C" int mcn_bn_fwd_train_gap(const void* x, const float* gamma, const flo
                                     float* batch_var, float* running_mean, float* running_var, float momentum, int32_t N, int32_t HW, int32_t C, float eps, mcn_act act,
                                     mcn_dtype dtype, void* ws, size_t ws_bytes, void* st) {
     if (!gap || N <= 0 || HW <= 0) return fail(MCN_E_BADARG, "bn_fwd_train_gap: bad argument");
+    if ((int)act < 0 || (int)act > 2) return fail(MCN_E_UNSUPPORTED, "bn_fwd_train_gap: activation (none / relu / swish only)");
     std::vector<char> tmp;                                // y == NULL: the means only
     if (!y) { tmp.resize((size_t)N * HW * C * (dtype == MCN_F32 ? 4 : 2)); y = tmp.data(); }
     const int rc = mcn_bn_fwd_train(x, gamma, beta, nullptr, y, nullptr, save_mean, save_invstd, batch_mean, batch_var, running_mean, running_var, momentum, (int64_t)N * HW, C,

@@ -45,6 +45,7 @@ class Lowering(object):
         self.fuse_bn_gap = bool(model._parameters.get('fuse_bn_gap', _env_flag('MCN_FUSE_BN_GAP', True)))
         self.fuse_se_fwd = bool(model._parameters.get('fuse_se_fwd', _env_flag('MCN_FUSE_SE_FWD', True)))          # ... and its BN + swish output never stored (needs fuse_se_sums)
         self.se_elided = set()          # ids of BN-output tensors that are not materialised (rebuilt inside mcn_bn_act_scale_fwd)
+        self.fuse_se = os.environ.get('MCN_FUSE_SE', '1') != '0'        # (read once: the forward decision and the backward route must agree)
         self.fuse_se_sums = bool(model._parameters.get('fuse_se_sums', _env_flag('MCN_FUSE_SE_SUMS', True)))        # squeeze-excite: BN-backward sums from the channel scale's reduction pass
         self.pool_routes = {}          # BN-output tensor id -> max-pool node whose gradient that BN's backward routes itself
         self.se_routes = {}            # BN-output tensor id -> {dy, m, dgap, gap}: squeeze-excite gradient composed inside that BN's backward
@@ -104,7 +105,7 @@ class Lowering(object):
         return d[op]
 
     def se_sums_buffer(self, n):
-        """fp32 [N][4][C] per-image sums of mcn_channel_scale_bwd_dm_bnsums, shared by the squeeze-excite blocks of one size (written and consumed
+        """fp32 [N * HS][5][C] per-image-slice sums of mcn_channel_scale_bwd_dm_bnsums (mcn_se_bwd_sums_floats() of them), shared by the squeeze-excite blocks of one size (written and consumed
         inside one block's backward, on the main stream)"""
         k = ('se_sums', n)                                     # (one buffer per size: the launch lists hold raw pointers)
         if k not in self.scratch:
@@ -165,6 +166,13 @@ class Lowering(object):
                 if f is not None and any(t.needs_grad for t in n.outputs):
                     f(n)
             assert not self.lazy_grad, 'deferred residual gradients were not consumed: {}'.format(list(self.lazy_grad))
+        if self.train and os.environ.get('MCN_PROBE_FWD_BN_SIDE') == '1' and self.g.device.type == 'cuda':
+            # TIMING PROBE (wrong results): every forward BN call on a second stream and nobody waits for it — the upper bound of what hiding
+            # the forward's bandwidth-bound apply passes under the next conv could buy
+            for i, (fn, _) in enumerate(self.fwd.calls):
+                if getattr(fn, '__name__', '').startswith('mcn_bn_fwd_train'):
+                    self.fwd.side[i] = None
+            self.fwd.side_stream = torch.cuda.Stream(device=self.g.device)
         return self
 
     def plan_packed_weights(self):
@@ -228,7 +236,8 @@ class Lowering(object):
         """Measure, don't guess: time every tile candidate of every conv launch of this lowering on the GPU (HIP events
         on the launch stream, data already in the buffers) and pin the fastest through mcn_conv_geom.tile.  The result
         of a conv does not depend on the tile except for the fp32 summation order of the split wgrad."""
-        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
+        names = {'mcn_conv2d_fwd': _ffi.CONV_FWD, 'mcn_conv2d_fwd_bnstats': _ffi.CONV_FWD, 'mcn_conv2d_dgrad': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked': _ffi.CONV_DGRAD,
+                 'mcn_conv2d_dgrad_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_dgrad_addmasked_bnred': _ffi.CONV_DGRAD, 'mcn_conv2d_wgrad': _ffi.CONV_WGRAD}
         sp = torch.cuda.current_stream(self.g.device).cuda_stream
         self.prepack.run(sp)
         chosen = {}
@@ -503,7 +512,7 @@ class Lowering(object):
         leaves the pooled means only and the scale pass rebuilds x_se on the fly (mcn_bn_act_scale_fwd): one write of the expanded activations per MBConv
         block less.  Returns the channel-scale node or None.  MCN_FUSE_SE_FWD=0 switches it off."""
         y = bn.outputs[0]
-        if not (self.train and self.fuse_se_sums and self.fuse_se_fwd) or os.environ.get('MCN_FUSE_SE', '1') == '0':
+        if not (self.train and self.fuse_se_sums and self.fuse_se_fwd and self.fuse_se):
             return None
         if bn.attrs.get('act', 0) != _ffi.ACT_SWISH or not bn.attrs.get('update') or bn.attrs.get('skip') is not None:
             return None
@@ -520,7 +529,10 @@ class Lowering(object):
         the SE branch's global average pool and by this node -> x's gradient is composed inside that BN's backward passes
         (mcn_bn_bwd_se) and never written.  Returns the pool node or None.  MCN_FUSE_SE=0 switches it off."""
         x, m = n.inputs[0], n.inputs[1]
-        if os.environ.get('MCN_FUSE_SE', '1') == '0' or not self.train or not x.needs_grad or not m.needs_grad or x.id in self.written:
+        if 'se_route' in n.attrs:                           # decided once, at forward lowering (the BN output was elided on the strength of it)
+            assert x.id not in self.written
+            return n.attrs['se_route']
+        if not self.fuse_se or not self.train or not x.needs_grad or not m.needs_grad or x.id in self.written:
             return None
         bn = x.producer
         if bn is None or bn.op != 'bn' or bn.attrs.get('act', 0) != _ffi.ACT_SWISH or not bn.attrs.get('update') or bn.attrs.get('skip') is not None:
@@ -684,9 +696,15 @@ class Lowering(object):
                 # tf.reduce_mean, models/efficientnet.py:183) — fwd_gap then emits nothing
                 self.fused_gaps.add(id(gap))
                 y_ptr = y.buf.data_ptr()
-                if self._se_elide(n, gap) is not None:     # the channel scale rebuilds this output from x: means only
+                for c_ in y.consumers:                     # (a re-lowering decides afresh)
+                    c_.attrs.pop('se_route', None)
+                chs = self._se_elide(n, gap)
+                if chs is not None:                        # the channel scale rebuilds this output from x: means only
                     self.se_elided.add(y.id)
+                    chs.attrs['se_route'] = gap            # ... and its backward takes the squeeze-excite route: ONE decision for both halves
                     y_ptr = 0
+                    if y.buf is not None and y.buf.is_floating_point():
+                        y.buf.fill_(float('nan'))           # never written by the training passes: a stray reader must not see plausible zeros
                 self.fwd.add(lib.mcn_bn_fwd_train_gap, x.buf.data_ptr(), self.vptr(a['gamma']), self.vptr(a['beta']), y_ptr, gap.outputs[0].buf.data_ptr(),
                              st['mean'].data_ptr(), st['invstd'].data_ptr(), st['bmean'].data_ptr(), st['bvar'].data_ptr(),
                              a['mu'].data.data_ptr() if single else 0, a['sigma'].data.data_ptr() if single else 0,

@@ -180,65 +180,7 @@ def test_batch_norm_at_stem_size(dtype):
     assert float((dg.double() - (dyd * xhat).sum(0)).abs().max() / (dyd * xhat).sum(0).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
-@pytest.mark.parametrize('layer', [(56, 64, 64, 3, 1), (56, 64, 256, 1, 1), (56, 128, 128, 3, 2), (14, 256, 1024, 1, 1), (7, 512, 512, 3, 1)],
-                         ids=lambda l: 'h{}_{}to{}_k{}s{}'.format(*l))
-def test_dgrad_with_bn_backward_sums_at_b256(layer, dtype):
-    """mcn_conv2d_dgrad_bnred at B = 256 (25 088 partial rows on the 56 x 56 layers, the fold stage, the window / stream-K kernels in fp32,
-    four parity launches for stride 2): dx bit-identical to mcn_conv2d_dgrad, the column sums of the partial rows against a float64
-    reduction of the stored dx, and mcn_bn_bwd_from_partials against mcn_bn_bwd (whose parity is in test_gpu_ops.py and above)."""
-    from myconvnet_amd import _ffi
-    u = _u()
-    lib = _ffi.lib
-    h, cin, cout, k, s = layer
-    td = u.TDT[dtype]
-    gen = torch.Generator(device=u.DEV).manual_seed(11)
-    m = B * h * h
-    xbn = (torch.randn((B, h, h, cin), device=u.DEV, generator=gen) * 1.3 + 0.4).to(td)               # the BN's input
-    gamma = (0.5 + torch.rand(cin, device=u.DEV, generator=gen)).float()
-    beta = (0.3 * torch.randn(cin, device=u.DEV, generator=gen)).float()
-    y = torch.empty_like(xbn)
-    mask = torch.zeros(int(lib.mcn_bn_relu_mask_bytes(m, cin, u.MDT[dtype])), dtype=torch.uint8, device=u.DEV)
-    sm, si, bm, bv = [torch.zeros(cin, dtype=torch.float32, device=u.DEV) for _ in range(4)]
-    bws = u.workspace(lib.mcn_bn_workspace_bytes(m, cin))
-    st = u.stream()
-    _ffi.check(lib.mcn_bn_fwd_train(xbn.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0, y.data_ptr(), mask.data_ptr(), sm.data_ptr(), si.data_ptr(), bm.data_ptr(),
-                                    bv.data_ptr(), 0, 0, 0.99, m, cin, 1e-3, 1, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, st))
-    g = u.geom((B, h, h, cin), (k, k, cin, cout), s, 'SAME')
-    oh = (h + s - 1) // s
-    w = (torch.randn((k, k, cin, cout), device=u.DEV, generator=gen) / np.sqrt(k * k * cin)).float()
-    dy = torch.randn((B, oh, oh, cout), device=u.DEV, generator=gen).to(td)
-    rows = lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(g), u.MDT[dtype])
-    assert rows > 0
-    ws = u.workspace(lib.mcn_conv2d_workspace_bytes(_ffi.CONV_DGRAD, ctypes.byref(g), u.MDT[dtype]))
-    dx0, dx1 = torch.empty_like(xbn), torch.full_like(xbn, float('nan'))
-    part = torch.full((rows, 2, cin), float('nan'), dtype=torch.float32, device=u.DEV)
-    _ffi.check(lib.mcn_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), 0, dx0.data_ptr(), ctypes.byref(g), 0, u.MDT[dtype], _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
-    _ffi.check(lib.mcn_conv2d_dgrad_bnred(dy.data_ptr(), w.data_ptr(), 0, dx1.data_ptr(), xbn.data_ptr(), mask.data_ptr(), part.data_ptr(), ctypes.byref(g), u.MDT[dtype],
-                                          _ffi.NHWC, ws.data_ptr(), ws.numel() * 4, st))
-    assert torch.equal(dx0, dx1)
-    assert not bool(torch.isnan(part).any())
-    on = (y.reshape(m, cin) > 0).double()
-    dxm = dx1.reshape(m, cin).double() * on
-    s1, s2 = dxm.sum(0), (dxm * xbn.reshape(m, cin).double()).sum(0)
-    p = part.double().sum(0)
-    assert float((p[0] - s1).abs().max()) <= 1e-5 * float(dxm.abs().sum(0).max())
-    assert float((p[1] - s2).abs().max()) <= 1e-5 * float((dxm * xbn.reshape(m, cin).double()).abs().sum(0).max())
-
-    def run(fn):
-        o = torch.full_like(xbn, float('nan'))
-        dg, db = torch.zeros(cin, device=u.DEV), torch.zeros(cin, device=u.DEV)
-        fn(o, dg, db)
-        return o, dg, db
-    a = run(lambda o, dg, db: _ffi.check(lib.mcn_bn_bwd(dx1.data_ptr(), xbn.data_ptr(), 0, mask.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(), o.data_ptr(), 0,
-                                                        dg.data_ptr(), db.data_ptr(), 1.0, m, cin, 1, u.MDT[dtype], bws.data_ptr(), bws.numel() * 4, st)))
-    b = run(lambda o, dg, db: _ffi.check(lib.mcn_bn_bwd_from_partials(dx1.data_ptr(), xbn.data_ptr(), mask.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
-                                                                      part.data_ptr(), rows, o.data_ptr(), dg.data_ptr(), db.data_ptr(), 1.0, m, cin, u.MDT[dtype],
-                                                                      bws.data_ptr(), bws.numel() * 4, st)))
-    ref = float(a[0].double().abs().max())
-    assert float((a[0].double() - b[0].double()).abs().max()) <= (1e-5 if dtype == 'float32' else 8e-3) * ref        # (bf16: one ulp of the largest element)
-    for i in (1, 2):
-        assert float((a[i].double() - b[i].double()).abs().max()) <= 2e-5 * float(dxm.abs().sum(0).max())
+# (mcn_conv2d_dgrad_bnred / _addmasked_bnred / mcn_conv2d_fwd_bnstats at B = 256: tests/test_gpu_fullsize_fused.py)
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])

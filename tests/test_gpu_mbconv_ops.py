@@ -274,3 +274,77 @@ def test_bn_backward_composes_squeeze_excite_gradient(shape, dtype):
     np.testing.assert_allclose(u.host(dg2), u.host(dg_ref), rtol=tol, atol=8 * tol * gq.sum((0, 1, 2)).max() / np.sqrt(m_))
     check(u.host(dx2), u.host(dx_ref), dtype, 'dx of the sums pair vs the composition', rel={'float32': 1e-5, 'bfloat16': 3e-3, 'float16': 4e-4}[dtype],
           mx={'float32': 1e-4, 'bfloat16': 2e-2, 'float16': 3e-3}[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 7, 7, 32), (4, 5, 9, 144), (2, 14, 14, 480), (6, 28, 28, 240)])
+def test_squeeze_excite_fused_entry_points_against_the_oracle(shape, dtype):
+    """The three squeeze-excite entry points of round 4 against oracle.ops DIRECTLY (not against other HIP kernels): BN(train) + swish + channel scale
+    forward (mcn_bn_fwd_train_gap(y = NULL) + mcn_bn_act_scale_fwd), and the backward pair mcn_channel_scale_bwd_dm_bnsums + mcn_bn_bwd_se_sums,
+    composed in the oracle from bn_fwd_train / swish / channel_scale / global_avgpool / bn_bwd (models/efficientnet.py:150-163, 179-197).
+    Tolerances: storage rounding of the composed tensors (x_se, dy * m) sits inside the 2-byte bars of check(); the BN-backward sums of the
+    fused pair are those of the UNROUNDED gradient (dx then no longer sums to exactly zero per channel in bf16 — the residual is
+    bounded below)."""
+    import torch
+    from myconvnet_amd import _ffi
+    u = _u()
+    lib = _ffi.lib
+    n, h, w_, c = shape
+    hw, m_ = h * w_, n * h * w_
+    md = u.MDT[dtype]
+    x = (1.2 * RNG.standard_normal(shape) + 0.1).astype(np.float32)
+    gamma = (0.5 + RNG.random(c)).astype(np.float32)
+    beta = (0.3 * RNG.standard_normal(c)).astype(np.float32)
+    mk = RNG.random((n, c)).astype(np.float32)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    dgap = RNG.standard_normal((n, c)).astype(np.float32)
+    xq, mq, dyq, dgq = (q(a, dtype).astype(np.float64) for a in (x, mk, dy, dgap))
+    # ---- oracle: forward ----
+    bn_out, _, _, mean, invstd = O.bn_fwd_train(xq, gamma.astype(np.float64), beta.astype(np.float64), 1e-3)
+    xse = q(O.swish_fwd(bn_out), dtype).astype(np.float64)                       # the tensor the unfused graph stores
+    gap_ref = O.global_avgpool_fwd(xse)
+    y_ref = O.channel_scale_fwd(xse, mq)
+    # ---- device: forward ----
+    xd, gd, bd, mkd = u.dev(x, dtype), u.dev(gamma), u.dev(beta), u.dev(mk, dtype)
+    sm, si, bm, bv = [torch.zeros(c, dtype=torch.float32, device=u.DEV) for _ in range(4)]
+    gap = torch.full((n, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    ws = u.workspace(lib.mcn_bn_workspace_bytes(m_, c))
+    st = u.stream()
+    _ffi.check(lib.mcn_bn_fwd_train_gap(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 0, gap.data_ptr(), sm.data_ptr(), si.data_ptr(), bm.data_ptr(), bv.data_ptr(), 0, 0, 0.99,
+                                        n, hw, c, 1e-3, _ffi.ACT_SWISH, md, ws.data_ptr(), ws.numel() * 4, st))
+    check(u.host(sm), mean, 'float32', 'save_mean', rel=1e-5, mx=1e-4)
+    check(u.host(si), invstd, 'float32', 'save_invstd', rel=1e-5)
+    check(u.host(gap), gap_ref, dtype, 'pooled means of the unstored BN + swish output')
+    y = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    _ffi.check(lib.mcn_bn_act_scale_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), mkd.data_ptr(), y.data_ptr(), n, hw, c, _ffi.ACT_SWISH, md, st))
+    check(u.host(y), y_ref, dtype, 'bn + swish + channel scale')
+    # an activation the fused passes do not implement is refused, not run as the identity (ADVICE r4)
+    assert lib.mcn_bn_fwd_train_gap(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 0, gap.data_ptr(), sm.data_ptr(), si.data_ptr(), bm.data_ptr(), bv.data_ptr(), 0, 0, 0.99,
+                                    n, hw, c, 1e-3, _ffi.ACT_RELU6, md, ws.data_ptr(), ws.numel() * 4, st) == _ffi.E_UNSUPPORTED
+    # ---- oracle: backward ----
+    dxse, dm_ref = O.channel_scale_bwd(dyq, xse, mq)
+    g = q(dxse, dtype).astype(np.float64) + O.global_avgpool_bwd(dgq, shape)     # the unfused graph stores dy * m, then accumulates the pooled branch
+    g_store = q(g, dtype).astype(np.float64)
+    dsw = O.swish_bwd(g_store, bn_out)
+    dx_ref, dg_ref, db_ref = O.bn_bwd(dsw, xq, gamma.astype(np.float64), mean, invstd)
+    # ---- device: backward ----
+    dyd, dgd = u.dev(dy, dtype), u.dev(dgap, dtype)
+    dm = torch.full((n, c), float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    sums = torch.full((int(lib.mcn_se_bwd_sums_floats(n, hw, c, md)),), float('nan'), dtype=torch.float32, device=u.DEV)
+    _ffi.check(lib.mcn_channel_scale_bwd_dm_bnsums(dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), dm.data_ptr(), sums.data_ptr(), n, hw, c, md, st))
+    dx = torch.full(shape, float('nan'), dtype=u.TDT[dtype], device=u.DEV)
+    dg, db = torch.zeros(c, device=u.DEV), torch.zeros(c, device=u.DEV)
+    _ffi.check(lib.mcn_bn_bwd_se_sums(dyd.data_ptr(), mkd.data_ptr(), dgd.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), sums.data_ptr(), dx.data_ptr(),
+                                      dg.data_ptr(), db.data_ptr(), 1.0, n, hw, c, md, ws.data_ptr(), ws.numel() * 4, st))
+    check(u.host(dm), dm_ref, dtype, 'dm = sum dy * x_se (x_se rebuilt from the BN input)')
+    ptol = {'float32': 1e-4, 'bfloat16': 6e-3, 'float16': 1e-3}[dtype]         # parameter gradients are fp32 sums of terms rounded to the storage type upstream
+    check(u.host(dg), dg_ref, 'float32', 'dgamma', rel=ptol, mx=max(ptol * 4, 1e-3))
+    check(u.host(db), db_ref, 'float32', 'dbeta', rel=ptol, mx=max(ptol * 4, 1e-3))
+    check(u.host(dx), dx_ref, dtype, 'dx')
+    # the residual the unrounded sums leave: per channel |sum dx| and |sum dx * xhat| stay below one storage rounding of every element (sqrt(M) growth)
+    dxh = u.host(dx).astype(np.float64).reshape(-1, c)
+    xhat = (xq.reshape(-1, c) - mean) * invstd
+    ulp = {'float32': 2.0 ** -23, 'bfloat16': 2.0 ** -8, 'float16': 2.0 ** -11}[dtype]
+    bound = 8.0 * ulp * np.sqrt(m_) * np.abs(dxh).max() + 1e-6 * np.abs(dxh).sum(0).max()
+    assert np.abs(dxh.sum(0)).max() <= bound, (np.abs(dxh.sum(0)).max(), bound)
+    assert np.abs((dxh * xhat).sum(0)).max() <= 3.0 * bound, (np.abs((dxh * xhat).sum(0)).max(), bound)

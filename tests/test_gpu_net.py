@@ -257,6 +257,35 @@ def test_resnet_l1_regulariser_and_focal_losses():
         M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, gradient_threshold=1.0)        # l1_reg + clipping: not built
 
 
+def test_resnet_autotuned_tiles_step_matches_oracle():
+    """ConvNet.autotune() (bench.py --autotune) pins a tile per conv launch — including the dgrads that carry the masked fan-in and the
+    unit-output BN's backward sums (mcn_conv2d_dgrad_addmasked_bnred), whose partial-row count follows the tile — and the step behind
+    it is still the oracle's step."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(63)
+    model, spec, params, stats = make_resnet(50, 'float32', True, fuse_bn_stats=True, fuse_bn_bwd_red=True, fuse_bn_out_red=True)
+    names = [getattr(fn, '__name__', '') for fn, _ in model._train_low.bwd.calls]
+    assert 'mcn_conv2d_dgrad_addmasked_bnred' in names and 'mcn_conv2d_dgrad_bnred' in names
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0)
+    x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+    model.feed(x, LABELS)
+    model.forward(train=True)                            # fill the buffers the timed launches read
+    model.backward()
+    chosen = model.autotune()
+    tuned = {id(a._obj) for fn, args in model._train_low.bwd.calls if getattr(fn, '__name__', '') == 'mcn_conv2d_dgrad_addmasked_bnred'
+             for a in args if hasattr(a, '_obj')}
+    assert tuned and tuned <= set(chosen), 'the fan-in + BN-sums dgrads were not tile-tuned'
+    model.set_variables(dict(params, **stats))           # (the tuner's launches never touch variables; reset anyway: a fresh step)
+    state = ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()})
+    loss, _, y_pred = opt._step(None)
+    rloss, rpred, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), batch_total=BATCH)
+    assert abs(loss - rloss) <= 1e-4 * abs(rloss)
+    assert rel_l2(y_pred, rpred) <= 1e-4
+    grads = model.get_variables('grad')
+    worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads)
+    assert worst[0] <= 1e-3, worst
+
+
 def test_resnet_fp32_bn_statistics_from_conv_epilogue():
     """fuse_bn_stats (default on for bf16 only) / defer_dskip: the fp32 network with the BN statistics taken in the conv
     epilogues and the residual fan-in applied in the dgrad epilogue / projection BN backward."""
@@ -451,12 +480,14 @@ def test_resnet_eval_uses_ema_and_running_stats():
     np.testing.assert_array_equal(y_pred.argmax(-1), pred.argmax(-1))
 
 
-@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
-def test_vgg16_trunk_config1(dtype):
-    """BASELINE config #1: VGG-16 on 8x8x3 random images, batch 4 (trunk only: the head needs 224x224)."""
+@pytest.mark.parametrize('dtype,width_div', [('float32', 4), ('bfloat16', 4), ('float32', 1)])
+def test_vgg16_trunk_config1(dtype, width_div):
+    """BASELINE config #1: VGG-16 on 8x8x3 random images, batch 4 (trunk only: the head needs 224x224).
+    width_div = 1 is the configuration as BASELINE.json states it (64 ... 512 channels: models/vggnet.py:29-103); width_div = 4 keeps the
+    2-byte variant and a quick case."""
     import myconvnet_amd as M
-    spec = ON.VGGSpec(16, 10, backbone_only=True, width_div=4)
-    model = M.VGG16([8, 8, 3], 10, batch_size=4, backbone_only=True, width_div=4, half_precision=(dtype == 'bfloat16'), num_gpus=1)
+    spec = ON.VGGSpec(16, 10, backbone_only=True, width_div=width_div)
+    model = M.VGG16([8, 8, 3], 10, batch_size=4, backbone_only=True, width_div=width_div, half_precision=(dtype == 'bfloat16'), num_gpus=1)
     params, _ = ON.init_variables(spec.variables(), seed=1, dtype=np.float32)
     rng = np.random.default_rng(2)
     for k in params:
@@ -473,7 +504,7 @@ def test_vgg16_trunk_config1(dtype):
     tape, rout, _, _, _ = ON.forward_loss(spec, state, x.astype(np.float64), None, quant=(bf16q if dtype == 'bfloat16' else None))
     got = model.fetch(out)
     tol = 1e-4 if dtype == 'float32' else 5e-2
-    assert got.shape == rout.a.shape == (4, 1, 1, 128)
+    assert got.shape == rout.a.shape == (4, 1, 1, 512 // width_div)
     assert rel_l2(got, rout.a) <= tol
     # backward from an injected output gradient
     dy = RNG.standard_normal(rout.a.shape).astype(np.float32)
