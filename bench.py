@@ -223,10 +223,11 @@ def _hbm_call_bytes(name, a, es):
     if name == 'mcn_bn_fwd_train_fused_maxpool':         # x -> pooled + arg-max
         n, h, w, c, oh, ow = a[15], a[16], a[17], a[18], a[-6], a[-5]
         return es * n * h * w * c + (es + 1) * n * oh * ow * c
-    if name == 'mcn_bn_bwd':                             # reduce (dy, x [, y]) + apply (dy, x [, y] -> dx [, dskip])
-        return es * mc(13) * (5 + (2 if a[2] else 0) + (1 if a[9] else 0))
-    if name == 'mcn_bn_bwd_from_partials':               # apply pass only
-        return es * mc(13) * 3
+    if name == 'mcn_bn_bwd':                             # reduce (dy, x [, y | byte mask]) + apply (dy, x [, y | byte mask] -> dx [, dskip])
+        sign = (2.0 / 16.0) if a[3] else (2.0 if a[2] else 0.0)          # the ReLU sign pattern: one byte per 16-byte chunk when the forward left a mask, else y itself
+        return es * mc(13) * (5 + sign + (1 if a[9] else 0))
+    if name == 'mcn_bn_bwd_from_partials':               # apply pass only (dy, x, byte mask -> dx)
+        return es * mc(13) * (3 + 1.0 / 16.0)
     if name == 'mcn_bn_bwd_se':                          # both passes read dy and x, the apply pass writes dx
         return es * float(a[12]) * float(a[13]) * float(a[14]) * 5
     if name == 'mcn_bn_bwd_se_sums':                     # the apply pass only (dy, x -> dx): the sums come from mcn_channel_scale_bwd_dm_bnsums

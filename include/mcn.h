@@ -340,6 +340,18 @@ size_t mcn_dwconv2d_workspace_bytes(const mcn_conv_geom* geom, mcn_dtype dtype);
 int mcn_dwconv2d_wgrad(const void* x, const void* dy, float* dw, const mcn_conv_geom* geom, float grad_scale,
                        mcn_dtype dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* depthwise channel multiplier != 1 and biased depthwise convolution (convnet.py:1634-1650 filter [kh, kw, cin, mult], output channel c * mult + q;
+ * bias: tf.nn.bias_add, convnet.py:1678-1694).  A multiplier-`mult` depthwise convolution = mcn_dwconv2d_* on C * mult channels applied to the input
+ * with every channel repeated `mult` times (the filter buffer [kh][kw][cin][mult] read as [kh][kw][cin * mult] is already in that order):
+ *   mcn_channel_repeat_fwd: y[m][c * mult + q] = x[m][c];   mcn_channel_repeat_bwd: dx[m][c] = sum_q dy[m][c * mult + q] (fp32 sum, one rounding).
+ * The bias is added by mcn_channel_affine(scale = 1, shift = bias); its gradient dbias[c] = grad_scale * sum_m dy[m][c] by mcn_bias_grad
+ * (deterministic two-stage column sum; workspace: mcn_bias_grad_workspace_bytes(M, C)). */
+int mcn_channel_repeat_fwd(const void* x, void* y, int64_t M, int32_t C, int32_t mult, mcn_dtype dtype, void* stream);
+int mcn_channel_repeat_bwd(const void* dy, void* dx, int64_t M, int32_t C, int32_t mult, mcn_dtype dtype, void* stream);
+size_t mcn_bias_grad_workspace_bytes(int64_t M, int32_t C);
+int mcn_bias_grad(const void* dy, float* dbias, int64_t M, int32_t C, float grad_scale, mcn_dtype dtype, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 /* squeeze-excite scale (models/efficientnet.py:161 `x = x*se_mask`): y[n,h,w,c] = x[n,h,w,c] * m[n,c];
  * backward: dx = dy * m, dm[n,c] = sum_hw dy * x.  x/y/m in `dtype`, HW = H*W. */
 int mcn_channel_scale_fwd(const void* x, const void* m, void* y, int32_t N, int64_t HW, int32_t C, mcn_dtype dtype,

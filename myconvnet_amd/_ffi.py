@@ -91,6 +91,10 @@ SIGNATURES = {
     'mcn_dwconv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_int32, c_int, c_void_p]),
     'mcn_dwconv2d_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom), c_int]),
     'mcn_dwconv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGeom), c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    'mcn_channel_repeat_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    'mcn_channel_repeat_bwd': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    'mcn_bias_grad_workspace_bytes': (c_size_t, [c_int64, c_int32]),
+    'mcn_bias_grad': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     'mcn_channel_scale_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_channel_scale_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int, c_void_p]),
     'mcn_act_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -596,10 +596,8 @@ class ConvNet(object):
         """reference convnet.py:1634-1650 -> tf.nn.depthwise_conv2d (:1645), filter [kh, kw, cin, multiplier]."""
         n, h, w, cin = x.shape
         mult = max(out_channels // cin, 1)
-        if mult != 1:
-            raise NotImplementedError('depthwise channel multiplier {} (only 1, the EfficientNet case, is built)'.format(mult))
-        if biased:
-            raise NotImplementedError('biased depthwise convolution is outside the built path')
+        if biased and out_channels != cin * mult:             # (tf.nn.bias_add would refuse the shapes: convnet.py:1679,1694)
+            raise ValueError('biased depthwise convolution: {} biases for {} output channels'.format(out_channels, cin * mult))
         oh = out_size(h, kernel[0], stride[0], padding, dilation[0])
         ow = out_size(w, kernel[1], stride[1], padding, dilation[1])
         if padding.upper() == 'SAME':
@@ -610,12 +608,29 @@ class ConvNet(object):
         with self.variable_scope(scope) if scope is not None else nullcontext():
             wv = self.weight_variable([kernel[0], kernel[1], cin, mult], initializer=weight_initializer, weight_standardization=ws,
                                       paddings=kernel_paddings)
+            bv = self.bias_variable(out_channels, initializer=bias_initializer) if biased else None
             name = self.scope_name()
-        y = self.graph.tensor((n, oh, ow, cin * mult), x.dtype, name + '/dwconv', self._channel_first)
-        geom = _ffi.conv_geom(n, h, w, cin, cin, kernel[0], kernel[1], stride[0], stride[1], dilation[0], dilation[1], (pt, pb, pl, pr), 0)
+        cm = cin * mult
+        if mult != 1:
+            # channel multiplier (convnet.py:1635-1645, output channel c * mult + q): the multiplier-1 kernels on the input with every channel
+            # repeated `mult` times — the [kh, kw, cin, mult] filter read as [kh, kw, cin * mult] is already in that order (include/mcn.h)
+            xr = self.graph.tensor((n, h, w, cm), x.dtype, name + '/repeat', self._channel_first)
+            self.graph.node('chrepeat', [x], [xr], scope=name, mult=mult)
+            x = xr
+        y = self.graph.tensor((n, oh, ow, cm), x.dtype, name + '/dwconv', self._channel_first)
+        geom = _ffi.conv_geom(n, h, w, cm, cm, kernel[0], kernel[1], stride[0], stride[1], dilation[0], dilation[1], (pt, pb, pl, pr), 0)
         self.graph.node('dwconv', [x], [y], scope=name, geom=geom, w=wv, has_params=True)
-        flops = oh * ow * kernel[0] * kernel[1] * cin * mult
-        self._log_layer(name, [None, oh, ow, cin * mult], flops, kernel[0] * kernel[1] * cin * mult, oh * ow * cin * mult)
+        flops = oh * ow * kernel[0] * kernel[1] * cm
+        params = kernel[0] * kernel[1] * cm
+        if biased:
+            # tf.nn.bias_add behind the depthwise convolution (convnet.py:1678-1694): its own pass (the stored conv output is rounded to the
+            # storage type before the add, as TF's two ops do)
+            yb = self.graph.tensor((n, oh, ow, cm), x.dtype, name + '/bias_add', self._channel_first)
+            self.graph.node('biasadd', [y], [yb], scope=name, b=bv, has_params=True)
+            y = yb
+            flops += oh * ow * cm
+            params += cm
+        self._log_layer(name, [None, oh, ow, cm], flops, params, oh * ow * cm)
         return y
 
     def conv_bn_act(self, x, kernel, stride, out_channels=None, padding='SAME', biased=False, depthwise=False, scope=None,

@@ -1293,6 +1293,22 @@ static int colsum_t(const void* x, float* out, long M, int C, float scale, void*
     return MCN_OK;
 }
 
+// bias gradient on its own (tf.nn.bias_add's BiasAddGrad, convnet.py:1694, behind a convolution that has no dbias output of its own: the
+// depthwise convolution): dbias[c] = grad_scale * sum_m dy[m][c], the two-stage column sum of the conv wgrad (fixed order: bit-reproducible)
+extern "C" size_t mcn_bias_grad_workspace_bytes(int64_t M, int32_t C) {
+    if (M <= 0 || C <= 0) return 0;
+    return align_up(colsum_parts((long)M) * (size_t)C * 4, 256);
+}
+extern "C" int mcn_bias_grad(const void* dy, float* dbias, int64_t M, int32_t C, float grad_scale, mcn_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !dbias || M <= 0 || C <= 0) MCN_FAIL(MCN_E_BADARG, "bias_grad: bad argument (M=%ld C=%d)", (long)M, C);
+    if (!ws || ws_bytes < mcn_bias_grad_workspace_bytes(M, C)) MCN_FAIL(MCN_E_WORKSPACE, "bias_grad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) return colsum_t<float>(dy, dbias, (long)M, C, grad_scale, ws, st);
+    if (dtype == MCN_BF16) return colsum_t<bf16_t>(dy, dbias, (long)M, C, grad_scale, ws, st);
+    if (dtype == MCN_F16) return colsum_t<f16_t>(dy, dbias, (long)M, C, grad_scale, ws, st);
+    MCN_FAIL(MCN_E_UNSUPPORTED, "bias_grad: dtype %d unsupported", (int)dtype);
+}
+
 template <typename T>
 static int conv_wgrad_t(const void* x, const void* dy, float* dw, float* dbias, const Geo& g, float scale, mcn_dtype dt, void* ws,
                         size_t ws_bytes, hipStream_t st) {

@@ -243,3 +243,51 @@ extern "C" int mcn_one_hot(const float* labels, float* onehot, int32_t B, int32_
     MCN_CHECK_LAUNCH();
     return MCN_OK;
 }
+
+
+// ---- depthwise channel multiplier (convnet.py:1634-1650: tf.nn.depthwise_conv2d with a [kh, kw, cin, mult] filter, output channel c * mult + q) ----
+// A depthwise convolution with multiplier `mult` IS the multiplier-1 convolution of the input with every channel repeated `mult` times against the
+// same filter buffer read as [kh][kw][cin * mult]: y_rep[m][c * mult + q] = x[m][c] here, then mcn_dwconv2d_* on cin * mult channels; backwards the
+// data gradient of the repeated tensor is summed over each channel's `mult` copies (fp32, rounded once), the filter gradient needs nothing extra.
+// One thread per element, consecutive threads on consecutive (output / input) channels: coalesced on the wide side of either pass.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_repeat_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n_out, int C, int mult) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int CO = C * mult;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        const long m = i / CO;
+        const int j = (int)(i - m * CO);
+        y[i] = x[m * C + j / mult];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void channel_repeat_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, long n_in, int mult) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += stride) {
+        float a = 0.f;
+        for (int q = 0; q < mult; ++q) a += to_f32(dy[i * mult + q]);
+        dx[i] = from_f32<T>(a);
+    }
+}
+extern "C" int mcn_channel_repeat_fwd(const void* x, void* y, int64_t M, int32_t C, int32_t mult, mcn_dtype dtype, void* stream) {
+    if (!x || !y || M <= 0 || C <= 0 || mult < 1) MCN_FAIL(MCN_E_BADARG, "channel_repeat_fwd: bad argument (M=%ld C=%d mult=%d)", (long)M, C, mult);
+    const long n = (long)M * C * mult;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) hipLaunchKernelGGL((channel_repeat_fwd_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, st, (const float*)x, (float*)y, n, C, mult);
+    else if (dtype == MCN_BF16) hipLaunchKernelGGL((channel_repeat_fwd_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n, C, mult);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((channel_repeat_fwd_kernel<f16_t>), dim3(ew_blocks(n)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, n, C, mult);
+    else MCN_FAIL(MCN_E_UNSUPPORTED, "channel_repeat_fwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}
+extern "C" int mcn_channel_repeat_bwd(const void* dy, void* dx, int64_t M, int32_t C, int32_t mult, mcn_dtype dtype, void* stream) {
+    if (!dy || !dx || M <= 0 || C <= 0 || mult < 1) MCN_FAIL(MCN_E_BADARG, "channel_repeat_bwd: bad argument (M=%ld C=%d mult=%d)", (long)M, C, mult);
+    const long n = (long)M * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MCN_F32) hipLaunchKernelGGL((channel_repeat_bwd_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, st, (const float*)dy, (float*)dx, n, mult);
+    else if (dtype == MCN_BF16) hipLaunchKernelGGL((channel_repeat_bwd_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, n, mult);
+    else if (dtype == MCN_F16) hipLaunchKernelGGL((channel_repeat_bwd_kernel<f16_t>), dim3(ew_blocks(n)), dim3(256), 0, st, (const f16_t*)dy, (f16_t*)dx, n, mult);
+    else MCN_FAIL(MCN_E_UNSUPPORTED, "channel_repeat_bwd: dtype %d unsupported", (int)dtype);
+    MCN_CHECK_LAUNCH();
+    return MCN_OK;
+}

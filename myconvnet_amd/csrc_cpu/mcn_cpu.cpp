@@ -649,6 +649,45 @@ extern "C" int mcn_channel_affine(const void* x, const float* scale, const float
         return map_n<S>(M * C, [&](int64_t i) { const int c = (int)(i % C); S::st((T*)y + i, fmaf(S::ld((const T*)x + i), scale[c], shift[c])); });
     });
 }
+// ---- depthwise channel multiplier / bias (convnet.py:1634-1650, 1678-1694; mcn.h) -------------------------------------------------------
+extern "C" int mcn_channel_repeat_fwd(const void* x, void* y, int64_t M, int32_t C, int32_t mult, mcn_dtype dtype, void*) {
+    if (!x || !y || M <= 0 || C <= 0 || mult < 1) return fail(MCN_E_BADARG, "channel_repeat_fwd: bad argument");
+    return by_dtype(dtype, "channel_repeat_fwd", [&](auto s) {
+        typedef decltype(s) S;
+        typedef typename S::T T;
+        const int64_t CO = (int64_t)C * mult;
+        return map_n<S>(M * CO, [&](int64_t i) { const int64_t m = i / CO, j = i % CO; ((T*)y)[i] = ((const T*)x)[m * C + j / mult]; });
+    });
+}
+extern "C" int mcn_channel_repeat_bwd(const void* dy, void* dx, int64_t M, int32_t C, int32_t mult, mcn_dtype dtype, void*) {
+    if (!dy || !dx || M <= 0 || C <= 0 || mult < 1) return fail(MCN_E_BADARG, "channel_repeat_bwd: bad argument");
+    return by_dtype(dtype, "channel_repeat_bwd", [&](auto s) {
+        typedef decltype(s) S;
+        typedef typename S::T T;
+        return map_n<S>(M * C, [&](int64_t i) {
+            float a = 0.f;
+            for (int q = 0; q < mult; ++q) a += S::ld((const T*)dy + i * mult + q);
+            S::st((T*)dx + i, a);
+        });
+    });
+}
+extern "C" size_t mcn_bias_grad_workspace_bytes(int64_t M, int32_t C) { return (M > 0 && C > 0) ? 256 : 0; }
+extern "C" int mcn_bias_grad(const void* dy, float* dbias, int64_t M, int32_t C, float grad_scale, mcn_dtype dtype, void* ws, size_t ws_bytes, void*) {
+    if (!dy || !dbias || M <= 0 || C <= 0) return fail(MCN_E_BADARG, "bias_grad: bad argument");
+    if (!ws || ws_bytes < mcn_bias_grad_workspace_bytes(M, C)) return fail(MCN_E_WORKSPACE, "bias_grad: workspace too small");
+    return by_dtype(dtype, "bias_grad", [&](auto s) {
+        typedef decltype(s) S;
+        typedef typename S::T T;
+#pragma omp parallel for schedule(static)
+        for (int c = 0; c < C; ++c) {
+            double a = 0.0;
+            for (int64_t m = 0; m < M; ++m) a += (double)S::ld((const T*)dy + m * C + c);
+            dbias[c] = (float)(a * grad_scale);
+        }
+        return (int)MCN_OK;
+    });
+}
+
 extern "C" int mcn_relu_fwd(const void* x, void* y, int64_t n, mcn_dtype dtype, void*) {
     return by_dtype(dtype, "relu_fwd", [&](auto s) {
         typedef decltype(s) S;

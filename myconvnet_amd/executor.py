@@ -90,6 +90,9 @@ class Lowering(object):
             elif n.op == 'fc':
                 x = n.inputs[0]
                 need = max(need, lib.mcn_fc_workspace_bytes(x.shape[0], x.shape[1], n.outputs[0].shape[1], self.dt))
+            elif n.op == 'biasadd':
+                x = n.inputs[0]
+                need = max(need, lib.mcn_bias_grad_workspace_bytes(x.numel // x.shape[-1], x.shape[-1]))
         return int(need)
 
     def op_geom(self, n, op):
@@ -493,6 +496,39 @@ class Lowering(object):
                                                              self.dt))
         if late:
             emit_wgrad()
+
+    # ---- depthwise channel multiplier / bias (convnet.py:1634-1650, 1678-1694) --------------------------------------
+    def fwd_chrepeat(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        C = x.shape[-1]
+        self.fwd.add(lib.mcn_channel_repeat_fwd, x.buf.data_ptr(), y.buf.data_ptr(), x.numel // C, C, n.attrs['mult'], MCN_DT[x.dtype])
+
+    def bwd_chrepeat(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        C = x.shape[-1]
+        self.contribute_via_scratch(x, lambda dst: self.bwd.add(lib.mcn_channel_repeat_bwd, y.grad.data_ptr(), dst, x.numel // C, C, n.attrs['mult'], MCN_DT[x.dtype]))
+
+    def fwd_biasadd(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        C = x.shape[-1]
+        if 'ones' not in n.attrs:
+            n.attrs['ones'] = torch.ones(C, dtype=torch.float32, device=self.g.device)
+        self.fwd.add(lib.mcn_channel_affine, x.buf.data_ptr(), n.attrs['ones'].data_ptr(), self.vptr(n.attrs['b']), y.buf.data_ptr(), x.numel // C, C, MCN_DT[x.dtype])
+
+    def bwd_biasadd(self, n):
+        x, y = n.inputs[0], n.outputs[0]
+        C = x.shape[-1]
+        b = n.attrs['b']
+        dt = MCN_DT[x.dtype]
+        if b.trainable:
+            self.bwd.add(lib.mcn_bias_grad, y.grad.data_ptr(), b.grad.data_ptr(), x.numel // C, C, 1.0 / self.loss_scale, dt, self.ws_ptr, self.ws_bytes)
+            self.bwd.mark(('grad_ready', (b.name,)))
+        if x.needs_grad:                                     # the add passes the gradient through
+            if x.id not in self.written:
+                self.written.add(x.id)
+                self.bwd.add(lib.mcn_cast, y.grad.data_ptr(), dt, x.grad.data_ptr(), dt, y.buf.numel())
+            else:
+                self.bwd.add(lib.mcn_accumulate, x.grad.data_ptr(), y.grad.data_ptr(), y.buf.numel(), dt)
 
     def fwd_chscale(self, n):
         x, m, y = n.inputs[0], n.inputs[1], n.outputs[0]

@@ -85,8 +85,6 @@ class Optimizer(object):
         self.momentum = optimizer['momentum']
         self.l2_reg = float(m._parameters.get('l2_reg', 1e-4))
         self.l1_reg = float(m._parameters.get('l1_reg', 0.0))              # convnet.py:529,553-557: l1_factor * sum |w| over the regularised variables
-        if self.l1_reg > 0.0 and self.gradient_threshold is not None:
-            raise NotImplementedError('l1_reg together with gradient clipping (the clip would have to see the L1 gradient) is not built')
         self.use_ema = bool(kwargs.get('update_ema', True))
         st = m.store
         nw, n = m.n_l2_elems, st.size
@@ -120,7 +118,7 @@ class Optimizer(object):
                     P.add(lib.mcn_ema_update_h, ema_w + off, st.data.data_ptr() + off, e1 - s1, hp)
                 continue
             reg = s1 < nw
-            if reg and self.l1_reg > 0.0:                # d/dw l1 * |w| = l1 * sign(w), added unscaled by the tower mean (the update kernel scales g by 1 / towers)
+            if reg and self.l1_reg > 0.0 and not clipping:   # d/dw l1 * |w| = l1 * sign(w), added unscaled by the tower mean (the update kernel scales g by 1 / towers)
                 P.add(lib.mcn_l1_grad_h, st.grad.data_ptr() + off, st.data.data_ptr() + off, e1 - s1, self.l1_reg, hp)
             # (with clipping the L2 gradient was folded into g by mcn_clip_by_global_norm: l2 = 0 here)
             P.add(lib.mcn_sgd_nesterov_fused_h, st.data.data_ptr() + off, st.grad.data_ptr() + off, st.accum.data_ptr() + off,
@@ -135,6 +133,13 @@ class Optimizer(object):
         if self.gradient_threshold is not None:
             self.grad_norm = torch.zeros(1, dtype=torch.float32, device=m.device)
             low = m._train_low
+            if self.l1_reg > 0.0:
+                # l1_reg with clipping: the reference clips the gradient of the FULL loss per tower (optimizers.py:106-113; the L1 term is part of it,
+                # convnet.py:553-557), so l1 * sign(w) enters this tower's gradient — as is, no tower-mean factor — in front of the clip
+                self._hyper_one = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=m.device)
+                for s1, e1, trainable in runs:
+                    if trainable and s1 < nw:
+                        self._clip.add(lib.mcn_l1_grad_h, st.grad.data_ptr() + 4 * s1, st.data.data_ptr() + 4 * s1, e1 - s1, self.l1_reg, self._hyper_one.data_ptr())
             if not frozen:
                 self._clip.add(lib.mcn_clip_by_global_norm, st.grad.data_ptr(), st.data.data_ptr(), n, nw, self.l2_reg, float(self.gradient_threshold),
                                self.grad_norm.data_ptr(), low.ws_ptr, low.ws_bytes)

@@ -842,7 +842,9 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
         g = {k: v for k, v in g.items() if trainable_name(k, hp.get('blocks_to_train'))}      # update_vars = tf.trainable_variables(), optimizers.py:53,106
         if hp.get('gradient_threshold') is not None:
             # the reference differentiates the full loss (CE + L2) and clips per tower (optimizers.py:106-113)
-            g = {k: (v + hp['l2_reg'] * state.params[k] if _regularised(k, hp) else v) for k, v in g.items()}
+            # (with l1_reg the L1 term l1 * sum |w| is part of that loss too, convnet.py:553-557: its gradient l1 * sign(w) is clipped with the rest)
+            l1 = hp.get('l1_reg', 0.0)
+            g = {k: (v + hp['l2_reg'] * state.params[k] + (l1 * np.sign(state.params[k]) if l1 > 0.0 else 0.0) if _regularised(k, hp) else v) for k, v in g.items()}
             g, _ = ops.clip_by_global_norm(g, hp['gradient_threshold'])
         grads_sum = g if grads_sum is None else {k: grads_sum[k] + g[k] for k in g}
         losses.append(loss)
@@ -866,7 +868,7 @@ def train_step(spec, state, x_raw, y_float, hp=None, lr_mult=1.0, batch_total=No
             state.ema[k] = (d * state.ema[k] + (1.0 - d) * state.params[k]).astype(state.params[k].dtype)
             continue
         is_w = _regularised(k, hp)
-        if is_w and hp.get('l1_reg', 0.0) > 0.0:              # d/dw l1 * |w| = l1 * sign(w): part of the gradient the update sees (and of the returned dict,
+        if is_w and hp.get('l1_reg', 0.0) > 0.0 and hp.get('gradient_threshold') is None:   # d/dw l1 * |w| = l1 * sign(w): part of the gradient the update sees (and of the returned dict,
             grads[k] = grads[k] + hp['l1_reg'] * np.sign(state.params[k])      # like the device's flat buffer after mcn_l1_grad_h; one tower)
         w, a, e = ops.sgd_nesterov_step(state.params[k], grads[k], state.accum[k], lr, hp['momentum'],
                                         l2=hp['l2_reg'] if (is_w and hp.get('gradient_threshold') is None) else 0.0, ema=state.ema[k], ema_d=d,

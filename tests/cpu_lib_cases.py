@@ -51,7 +51,7 @@ def resnet(kind, dtype='float32', steps=2, model_kw=None, **opt_kw):
                 half_precision_dtype=(dtype if dtype != 'float32' else 'bfloat16'), **(model_kw or {}))
     model.set_variables(dict(params, **stats))
     opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, **opt_kw)
-    if model_kw and opt_kw.get('gradient_threshold') is not None:
+    if model_kw and 'blocks_to_train' in model_kw and opt_kw.get('gradient_threshold') is not None:
         assert 'mcn_clip_by_global_norm_runs' in [getattr(fn, '__name__', '') for fn, _ in opt._clip.calls]
     names = [getattr(fn, '__name__', '') for fn, _ in model._train_low.fwd.calls + model._train_low.bwd.calls]
     assert 'mcn_conv2d_fwd' in names and 'mcn_bn_fwd_train' in names and 'mcn_conv2d_fwd_bnstats' not in names      # the plain lowering
@@ -274,6 +274,14 @@ if __name__ == '__main__':
         resnet(18, steps=2, model_kw=dict(blocks_to_train=[0, None]), gradient_threshold=0.05)
     elif case == 'resnet18_l1_focal':                      # l1_reg + both focal factors (convnet.py:553-557, 581-592)
         resnet(18, steps=2, model_kw=dict(l1_reg=1e-5, focal_loss_factor=2.0, sigmoid_focal_loss_factor=3.0))
+    elif case == 'resnet18_l1_clip':                       # l1_reg inside the clipped full-loss gradient (convnet.py:553-557 + optimizers.py:106-113)
+        resnet(18, steps=2, model_kw=dict(l1_reg=3e-4), gradient_threshold=0.5)
+    elif case == 'dw_mult_bias':                           # conv_layer(depthwise=True) with a channel multiplier / a bias (convnet.py:1634-1650, 1678-1694)
+        import dw_mult_case
+        from test_gpu_ops import check, q
+        for c in dw_mult_case.CASES:
+            dw_mult_case.run_case(M, c, 'float32', check, q, device='cpu')
+        print('depthwise multiplier / bias cases ok')
     elif case == 'train_loop':
         train_loop()
     elif case == 'efficientnet':

@@ -53,7 +53,7 @@ def test_the_product_never_loads_the_cpu_library_by_itself(cpu_lib, tmp_path):
             model.compile()
 
 
-@pytest.mark.parametrize('case', ['resnet50', 'resnet18', 'resnet18_bf16', 'resnet50_fp16', 'resnet18_decay_clip', 'resnet18_frozen_clip', 'resnet18_l1_focal', 'train_loop', 'efficientnet', 'deeplab', 'deeplab_ls', 'deeplab_level', 'dist2', 'dist2_frozen'])
+@pytest.mark.parametrize('case', ['resnet50', 'resnet18', 'resnet18_bf16', 'resnet50_fp16', 'resnet18_decay_clip', 'resnet18_frozen_clip', 'resnet18_l1_focal', 'resnet18_l1_clip', 'dw_mult_bias', 'train_loop', 'efficientnet', 'deeplab', 'deeplab_ls', 'deeplab_level', 'dist2', 'dist2_frozen'])
 def test_host_code_executes_on_the_cpu_library(case, cpu_lib):
     env = dict(os.environ, MCN_LIB_PATH=cpu_lib, OMP_NUM_THREADS='4')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'cpu_lib_cases.py'), case], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,

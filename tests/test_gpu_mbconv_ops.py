@@ -337,14 +337,29 @@ def test_squeeze_excite_fused_entry_points_against_the_oracle(shape, dtype):
     _ffi.check(lib.mcn_bn_bwd_se_sums(dyd.data_ptr(), mkd.data_ptr(), dgd.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(), si.data_ptr(), sums.data_ptr(), dx.data_ptr(),
                                       dg.data_ptr(), db.data_ptr(), 1.0, n, hw, c, md, ws.data_ptr(), ws.numel() * 4, st))
     check(u.host(dm), dm_ref, dtype, 'dm = sum dy * x_se (x_se rebuilt from the BN input)')
-    ptol = {'float32': 1e-4, 'bfloat16': 6e-3, 'float16': 1e-3}[dtype]         # parameter gradients are fp32 sums of terms rounded to the storage type upstream
+    # parameter gradients: the oracle sums the gradient g as the unfused graph STORES it (two roundings to the storage type), the fused pair sums the
+    # unrounded g.  Both are sums of M random-sign terms, so the difference relative to the sum is a few storage ulps (bf16 2^-8, fp16 2^-11), measured
+    # 6-8e-3 / 1.6e-3 at these shapes
+    ptol = {'float32': 1e-4, 'bfloat16': 2e-2, 'float16': 4e-3}[dtype]
     check(u.host(dg), dg_ref, 'float32', 'dgamma', rel=ptol, mx=max(ptol * 4, 1e-3))
     check(u.host(db), db_ref, 'float32', 'dbeta', rel=ptol, mx=max(ptol * 4, 1e-3))
     check(u.host(dx), dx_ref, dtype, 'dx')
-    # the residual the unrounded sums leave: per channel |sum dx| and |sum dx * xhat| stay below one storage rounding of every element (sqrt(M) growth)
+    # the residual the unrounded sums leave: per channel |sum dx| stays below one storage rounding of every element (sqrt(M) growth)
     dxh = u.host(dx).astype(np.float64).reshape(-1, c)
     xhat = (xq.reshape(-1, c) - mean) * invstd
     ulp = {'float32': 2.0 ** -23, 'bfloat16': 2.0 ** -8, 'float16': 2.0 ** -11}[dtype]
     bound = 8.0 * ulp * np.sqrt(m_) * np.abs(dxh).max() + 1e-6 * np.abs(dxh).sum(0).max()
     assert np.abs(dxh.sum(0)).max() <= bound, (np.abs(dxh.sum(0)).max(), bound)
-    assert np.abs((dxh * xhat).sum(0)).max() <= 3.0 * bound, (np.abs((dxh * xhat).sum(0)).max(), bound)
+    # (sum dx * xhat is not zero by construction: eps sits inside the square root, so sum xhat^2 = M * var / (var + eps); against the oracle's dx instead)
+    ref_x = (np.asarray(dx_ref, np.float64).reshape(-1, c) * xhat).sum(0)
+    assert np.abs((dxh * xhat).sum(0) - ref_x).max() <= 3.0 * bound + 1e-5 * np.abs(dxh * xhat).sum(0).max()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('case', __import__('dw_mult_case').CASES)
+def test_depthwise_channel_multiplier_and_bias_through_the_layer_api(case, dtype):
+    """conv_layer(depthwise=True) with out_channels = cin * mult (mult != 1) and / or biased=True — forward, data gradient (through the channel repeat),
+    filter gradient [kh, kw, cin, mult] and bias gradient against oracle.ops.depthwise_conv2d_* / bias_add_* (tests/dw_mult_case.py)."""
+    import myconvnet_amd as M
+    import dw_mult_case
+    dw_mult_case.run_case(M, case, dtype, check, q)

@@ -253,8 +253,42 @@ def test_resnet_l1_regulariser_and_focal_losses():
         got = model.get_variables('data')
         worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
         assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
-    with pytest.raises(NotImplementedError):
-        M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, gradient_threshold=1.0)        # l1_reg + clipping: not built
+
+
+@pytest.mark.parametrize('freeze', [dict(), dict(blocks_to_train=[3, 4, None])])
+def test_resnet_l1_regulariser_with_gradient_clipping(freeze):
+    """l1_reg together with gradient_threshold (convnet.py:553-557 + optimizers.py:106-113): the reference differentiates the FULL loss — cross-entropy +
+    L2 + L1 terms — and clips that gradient per tower by its global norm, so l1 * sign(w) must be inside the clipped vector (and inside the norm), also
+    when only some blocks train."""
+    import myconvnet_amd as M
+    rng = np.random.default_rng(93)
+    hp = dict(l1_reg=3e-4, gradient_threshold=0.5)
+    model, spec, params, stats = make_resnet(18, 'float32', True, l1_reg=hp['l1_reg'], **freeze)
+    opt = M.MomentumOptimizer(model, None, None, base_learning_rate=0.1, steps_per_epoch=1, learning_warmup_epochs=0.0, gradient_threshold=hp['gradient_threshold'])
+    assert 'mcn_l1_grad_h' in [getattr(fn, '__name__', '') for fn, _ in opt._clip.calls]
+    assert 'mcn_l1_grad_h' not in [getattr(fn, '__name__', '') for fn, _ in opt.optimization_operation.calls]
+    ohp = dict(hp, **freeze)
+    state, noclip, nol1 = (ON.TrainState({k: v.astype(np.float64) for k, v in params.items()}, {k: v.astype(np.float64) for k, v in stats.items()}) for _ in range(3))
+    for step in range(2):
+        x = rng.random((BATCH, 64, 64, 3)).astype(np.float32)
+        model.feed(x, LABELS)
+        loss, _, _ = opt._step(None)
+        rloss, _, rgrads = ON.train_step(spec, state, x.astype(np.float64), LABELS.astype(np.float64), hp=ohp, batch_total=BATCH)
+        assert abs(loss - rloss) <= 1e-4 * abs(rloss), (step, loss, rloss)
+        grads = model.get_variables('grad')
+        worst = max((rel_l2(grads[k], rgrads[k]), k) for k in rgrads if np.linalg.norm(rgrads[k]) > 1e-9)
+        assert worst[0] <= 1e-3, 'step {}: worst gradient {}'.format(step, worst)
+        # the clip was active, and the L1 term weighs in the clipped vector: both reference runs without one of the two end somewhere else
+        total = np.sqrt(sum(float((rgrads[k] ** 2).sum()) for k in rgrads))
+        assert abs(total - hp['gradient_threshold']) <= 1e-6 * hp['gradient_threshold'], total
+        got = model.get_variables('data')
+        worst = max((rel_l2(got[k], v), k) for k, v in list(state.params.items()) + list(state.stats.items()))
+        assert worst[0] <= 1e-4, 'step {}: worst variable {}'.format(step, worst)
+        if step == 0:
+            _, _, g1 = ON.train_step(spec, noclip, x.astype(np.float64), LABELS.astype(np.float64), hp=dict(freeze, l1_reg=hp['l1_reg']), batch_total=BATCH)
+            _, _, g2 = ON.train_step(spec, nol1, x.astype(np.float64), LABELS.astype(np.float64), hp=dict(freeze, gradient_threshold=hp['gradient_threshold']), batch_total=BATCH)
+            k = 'block_4/res_1/conv_1/weights'
+            assert rel_l2(g1[k], rgrads[k]) > 1e-2 and rel_l2(g2[k], rgrads[k]) > 1e-2
 
 
 def test_resnet_autotuned_tiles_step_matches_oracle():
