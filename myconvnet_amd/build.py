@@ -32,6 +32,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # MCN_KERNEL_PROBES=1 (set for the build AND for the run): compile the timing probes into the kernels (MCN_NT_EPI_FLAGS / MCN_TN_DBG skip a kind of
 # instruction — wrong results, timing only).  Off by default: as run-time branches they cost the K loops 0.6-0.8 % of the step.  Own object directory
 # and a different source digest, so that the two builds never mix.
+if os.environ.get('MCN_EXTRA_CFLAGS'):                   # experiment builds (e.g. -DMCN_NT_STAGE_ST=2; set for the build AND the run): own objects, own build identity
+    import hashlib as _h
+    FLAGS += os.environ['MCN_EXTRA_CFLAGS'].split()
+    OBJ = os.path.join(CSRC, '_obj_x' + _h.sha1(os.environ['MCN_EXTRA_CFLAGS'].encode()).hexdigest()[:8])
 PROBES = os.environ.get('MCN_KERNEL_PROBES') == '1'
 if PROBES:
     FLAGS.append('-DMCN_KERNEL_PROBES=1')
@@ -47,6 +51,8 @@ def source_digest():
             h.update(f.encode() + b'\0' + fh.read() + b'\0')
     if PROBES:
         h.update(b'MCN_KERNEL_PROBES=1')
+    if os.environ.get('MCN_EXTRA_CFLAGS'):
+        h.update(os.environ['MCN_EXTRA_CFLAGS'].encode())
     return h.hexdigest()
 
 
