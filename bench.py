@@ -164,7 +164,7 @@ def timed(opt, steps, warmup, world, autotune=False):
     if autotune:                                       # untimed start-up: two steps to fill the buffers, then time the tile candidates
         run_steps(opt, 2)
         opt.model.autotune()
-    main_cus = int(os.environ.get('MCN_MAIN_CUS', '0'))       # experiment ("CU masks"): the main stream on a subset of the CUs
+    main_cus = int(os.environ.get('MCN_MAIN_CUS', '0'))       # experiment (LABNOTES.md section 3, "CU masks"): the main stream on a subset of the CUs
     if main_cus > 0:
         from myconvnet_amd.graph import masked_stream
         ctx = torch.cuda.stream(masked_stream(torch.device('cuda', local_device()), main_cus, int(os.environ.get('MCN_MAIN_CU0', '0'))))

@@ -201,7 +201,7 @@ def ptr(t):
 def masked_stream(device, ncu, first=0, total=256):
     """A HIP stream whose kernels may only use `ncu` of the chip's CUs (hipExtStreamCreateWithCUMask; mask bits first .. first + ncu - 1,
     which the driver deals round-robin over the XCDs), wrapped as a torch stream.  Experiment switch of the two-stream backward
-    (MCN_SIDE_CUS / MCN_MAIN_CUS, DESIGN.md section 3 "CU masks"): the default streams are unmasked."""
+    (MCN_SIDE_CUS / MCN_MAIN_CUS, LABNOTES.md section 3 "CU masks"): the default streams are unmasked."""
     import ctypes
     import os
     hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
