@@ -29,4 +29,4 @@ for m in efficientnet_b0 deeplabv3plus; do
   done
   echo "$m done"
 done
-cd $R && python3 profiles/summarize.py $O ${ROUND:-round3}
+cd $R && python3 profiles/summarize.py $O ${ROUND:-round5}
