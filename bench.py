@@ -619,17 +619,20 @@ def verify_line(out):
         if dt and 'frac' in e:
             close('roofline_by_kernel[{}].frac'.format(k), e['frac'], e['tflops'] / PEAK_TFLOPS[dt], absol=1e-3)
         if e.get('ms_per_step') and 'gbs' in e:
-            close('roofline_by_kernel[{}].gbs'.format(k), e['gbs'], e['algorithmic_bytes_per_launch'] * e['launches_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=1e-2, absol=1.0)
+            close('roofline_by_kernel[{}].gbs'.format(k), e['gbs'], e['algorithmic_bytes_per_launch'] * e['launches_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9,
+                  rel=max(1e-2, 6e-4 / max(e['ms_per_step'], 1e-6)), absol=1.0)
         if 'hbm_frac' in e:
             close('roofline_by_kernel[{}].hbm_frac'.format(k), e['hbm_frac'], e['gbs'] / PEAK_HBM_GBS, absol=1e-3)
         if k.startswith('conv_wino') and 'tail_launches_per_step' not in e:
             bad.append('roofline_by_kernel[{}]: a Winograd entry must say how many tail launches its brackets include'.format(k))
     for k, e in out.get('hbm_by_call', {}).items():
         if 'gbs' in e:
-            close('hbm_by_call[{}].gbs'.format(k), e['gbs'], e['algorithmic_bytes_per_call'] * e['calls_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=1e-2, absol=1.0)
+            # (ms_per_step is stored to a microsecond: a 30 us call carries +-1.7 % of rounding)
+            close('hbm_by_call[{}].gbs'.format(k), e['gbs'], e['algorithmic_bytes_per_call'] * e['calls_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9,
+                  rel=max(1e-2, 6e-4 / max(e['ms_per_step'], 1e-6)), absol=1.0)
             close('hbm_by_call[{}].hbm_frac'.format(k), e['hbm_frac'], e['gbs'] / PEAK_HBM_GBS, absol=1e-3)
         if 'traffic_per_step' in e:
-            close('hbm_by_call[{}].traffic_gbs'.format(k), e['traffic_gbs'], e['traffic_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=1e-2, absol=1.0)
+            close('hbm_by_call[{}].traffic_gbs'.format(k), e['traffic_gbs'], e['traffic_per_step'] / (e['ms_per_step'] * 1e-3) / 1e9, rel=max(1e-2, 6e-4 / max(e['ms_per_step'], 1e-6)), absol=1.0)
             close('hbm_by_call[{}].traffic_hbm_frac'.format(k), e['traffic_hbm_frac'], e['traffic_gbs'] / PEAK_HBM_GBS, absol=1e-3)
     for key in ('bf16', 'fp16'):
         e = out.get(key)
@@ -859,7 +862,12 @@ def main():
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        # hold every rank until rank 0 has printed; the measurement is over, so a peer that has already left this last barrier and closed its
+        # sockets (gloo: "Connection closed by peer", seen once with 4 ranks on one GPU) must not turn a finished run into a failed one
+        try:
+            dist.barrier()
+        except RuntimeError as e:
+            print('rank {}: final barrier: {}'.format(rank, str(e).splitlines()[0]), file=sys.stderr)
         dist.destroy_process_group()
 
 

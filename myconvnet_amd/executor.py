@@ -267,6 +267,12 @@ class Lowering(object):
                     best, best_t = cand, t
             gm.tile = best
             chosen[id(gm)] = best
+        self.sync_partial_rows()
+        return chosen
+
+    def sync_partial_rows(self):
+        """After a tile was pinned (autotune, or mcn_conv_geom.tile set by hand): the partial-row counts that the BN calls behind a fused conv / dgrad
+        were emitted with follow the tile."""
         for fn, args in self.fwd.calls:                     # the partial-row count of a fused conv -> BN pair follows the tile
             name = getattr(fn, '__name__', '')
             if name in ('mcn_bn_fwd_train_fused', 'mcn_bn_fwd_train_fused_maxpool', 'mcn_bn_fwd_train_fused_affskip', 'mcn_bn_fwd_train_fused_stats'):
@@ -283,7 +289,6 @@ class Lowering(object):
                     br = nd.attrs.get('bwd_red') if nd.op == 'bn' else None
                     if br is not None and br[0].data_ptr() == args[7]:
                         args[8] = int(lib.mcn_conv2d_dgrad_bnred_rows(ctypes.byref(br[1]), self.dt))
-        return chosen
 
     # ---- input / labels ---------------------------------------------------------------------------------
     def fwd_input(self, n):
