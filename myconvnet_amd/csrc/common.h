@@ -80,8 +80,11 @@ template <>
 __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }          // round to nearest even, overflow -> inf (as tf.cast)
 
 // sigmoid on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1e-6 relative): the precise expf + IEEE division cost
-// ~30 VALU instructions per element, which made the BN+swish kernels VALU-bound instead of HBM-bound
-__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.f + __expf(-z)); }
+// ~30 VALU instructions per element, which made the BN+swish kernels VALU-bound instead of HBM-bound.  The reciprocal is the raw
+// v_rcp_f32 (1 ulp): __frcp_rn is the correctly ROUNDED reciprocal and expands to the whole division sequence (2 v_div_scale, v_rcp,
+// 4 fma, v_div_fmas, v_div_fixup — 10 of the 21 VALU instructions per element of the BN + swish backward, round 5 ISA count).
+// exp(-z) = inf gives rcp(inf) = 0, exp(-z) flushed to 0 gives 1: the ends are exact without a fix-up.
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 
 // 16-byte chunk <-> fp32 lanes
 template <typename T>
