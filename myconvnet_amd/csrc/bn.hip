@@ -705,6 +705,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_se_kernel(const T* __restri
 // rebuilding x_se = round_T(swish(bn(x))) from it (same two tensor reads as before), and the pass bn_bwd_reduce_se_kernel (two more reads of the widest
 // activations of the network per block) becomes a loop over [N * HS][5][C] floats (HS = pixel slices per image, se_bwd_layout; plane 0 = the dm partial).  The sums are those of the unrounded g (the apply pass still
 // forms the rounded g per element): dgamma / dbeta agree with the three-step composition to fp32 summation accuracy, not bit for bit.
+#ifndef MCN_SE_PRE_U
+#define MCN_SE_PRE_U 1       // rows per trip; 2 (four loads in flight) needs 132 registers = 3 waves per SIMD: 26.0 -> 26.3 ms per EfficientNet-B0 step
+#endif
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void se_bwd_pre_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums, long HW, int C,
@@ -734,11 +737,7 @@ __global__ __launch_bounds__(256) void se_bwd_pre_kernel(const T* __restrict__ d
         }
         // packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): with scalar math the pass is VALU bound (~24 instructions per element), not HBM bound
         typedef float se_f32x2 __attribute__((ext_vector_type(2)));
-        for (long r = r_lo + ty; r < r_hi; r += TY) {
-            const long off = (n * HW + r) * C + (long)col * VEC;
-            float g[VEC], v[VEC];
-            ldv<T, VEC>(dy + off, g);
-            ldv<T, VEC>(x + off, v);
+        auto row = [&](const float* g, const float* v) {
 #pragma unroll
             for (int i = 0; i < VEC; i += 2) {
                 const se_f32x2 v2 = {v[i], v[i + 1]}, g2 = {g[i], g[i + 1]};
@@ -761,6 +760,26 @@ __global__ __launch_bounds__(256) void se_bwd_pre_kernel(const T* __restrict__ d
                 acc[3][i] = a3[0]; acc[3][i + 1] = a3[1];
                 acc[4][i] = a4[0]; acc[4][i + 1] = a4[1];
             }
+        };
+        constexpr int U = MCN_SE_PRE_U;
+        long r = r_lo + ty;
+        for (; r + (long)(U - 1) * TY < r_hi; r += (long)U * TY) {
+            float g[U][VEC], v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long off = (n * HW + r + (long)u * TY) * C + (long)col * VEC;
+                ldv<T, VEC>(dy + off, g[u]);
+                ldv<T, VEC>(x + off, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) row(g[u], v[u]);
+        }
+        for (; r < r_hi; r += TY) {
+            const long off = (n * HW + r) * C + (long)col * VEC;
+            float g[VEC], v[VEC];
+            ldv<T, VEC>(dy + off, g);
+            ldv<T, VEC>(x + off, v);
+            row(g, v);
         }
     }
     const int cols = TX * VEC;
@@ -925,9 +944,7 @@ __global__ __launch_bounds__(256) void bn_apply_gap_kernel(const T* __restrict__
         ldc<VEC>(scale + col * VEC, sc);
         ldc<VEC>(shift + col * VEC, sh);
         const long base = n * HW * C + (long)col * VEC;
-        for (int q = ty; q < HW; q += TY) {
-            float v[VEC];
-            ldv<T, VEC>(x + base + (long)q * C, v);
+        auto row = [&](float (&v)[VEC], int q) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float o = fmaf(v[i], sc[i], sh[i]);
@@ -937,6 +954,21 @@ __global__ __launch_bounds__(256) void bn_apply_gap_kernel(const T* __restrict__
                 acc[i] += v[i];
             }
             if (y) stv<T, VEC>(y + base + (long)q * C, v);                      // (uniform)
+        };
+        // U rows per trip, their loads issued first: with one 16-byte load in flight per thread the means-only form (y == nullptr) read at 3.2 TB/s
+        constexpr int U = 4;
+        int q = ty;
+        for (; q + (U - 1) * TY < HW; q += U * TY) {
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ldv<T, VEC>(x + base + (long)(q + u * TY) * C, v[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) row(v[u], q + u * TY);
+        }
+        for (; q < HW; q += TY) {
+            float v[VEC];
+            ldv<T, VEC>(x + base + (long)q * C, v);
+            row(v, q);
         }
     }
     const int cols = TX * VEC;
